@@ -1,0 +1,151 @@
+/*
+ * koopmpc.h -- C ABI of libkoopmpc.so: the batched Koopman online-updated MPC step on MI355X.
+ *
+ * The reference (MichaelMillerCSU/Koopman-online-updated-MPC) has no FFI: its hot path is a
+ * set of statements inlined in script loops.  Each entry point below replaces one of those
+ * call sites, batched over B independent trajectories; the citation is the reference
+ * statement it replaces (file:line under the reference root).
+ *
+ * Conventions
+ *   - plain C, no torch / STL types; every function returns 0 on success, <0 on error
+ *     (kmpc_last_error() gives the text).  Kernels never abort: per-trajectory QP status
+ *     is returned in status[B] (0 optimal, 1 iteration cap, 2 non-finite data).
+ *   - "dev" pointers are device (HBM) pointers of the handle's dtype (float or double);
+ *     "host" pointers are host doubles.  `stream` is a hipStream_t passed as void*.
+ *   - batched vectors are batch-contiguous panels: element (row r, trajectory b) of an
+ *     (R x B) panel is at [r*B + b].  Per-trajectory matrices exported by kmpc_get_model
+ *     are trajectory-major blocks ([b][row][col]).
+ *   - the caller owns every I/O buffer; the handle owns only the encoder weights, the
+ *     persistent RLS state (P, [A B], bar_Q, C), the previous lifted state / input and
+ *     scratch.  No hidden host<->device copies on the step path.
+ *   - one handle per GPU / stream; a handle is not thread-safe.
+ */
+#ifndef KOOPMPC_H
+#define KOOPMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct kmpc_handle kmpc_handle;
+
+enum { KMPC_F32 = 0, KMPC_F64 = 1 };
+enum {
+  KMPC_LIFT_MLP = 0,        /* AutoEncoder.Encoder, duffing.py:17-29                      */
+  KMPC_LIFT_RBF_PY = 1,     /* d^2 log(d + eps), vanderpol_RBF.py:20-23                   */
+  KMPC_LIFT_RBF_MATLAB = 2  /* r2 log(sqrt(r2)), NaN -> 0, rbf.m:24-29                    */
+};
+enum {
+  KMPC_OUT_CX = 0,   /* y = C x, C adapted by RLS (duffing.py:553, 943-953); q = n        */
+  KMPC_OUT_LIFT = 1  /* y = lifted state (vanderpol.py:456-459); q = L, C not used        */
+};
+enum { KMPC_PLANT_DUFFING = 0, KMPC_PLANT_VDP = 1 };
+
+/* kmpc_step / kmpc_run phases (bit mask) */
+enum { KMPC_PH_RLS = 1, KMPC_PH_CONDENSE = 2, KMPC_PH_QP = 4 };
+
+typedef struct kmpc_config {
+  int32_t n;           /* plant state dimension (2)                                        */
+  int32_t m;           /* inputs; 1 as in the reference (duffing.py:170-171)               */
+  int32_t L;           /* lifted dimension Nlift (duffing.py:66)                           */
+  int32_t N;           /* horizon MPCHorizon = ControlHorizon (duffing.py:632-633)         */
+  int32_t hidden;      /* MLP hidden width (100)                                           */
+  int32_t layers;      /* MLP hidden layers (3; Encoder_Tank.m has 2)                      */
+  int32_t lift_kind;   /* KMPC_LIFT_*                                                      */
+  int32_t output_kind; /* KMPC_OUT_*                                                       */
+  int32_t dtype;       /* KMPC_F32 / KMPC_F64                                              */
+  int32_t batch;       /* B: trajectories resident on this GPU                             */
+  int32_t qp_max_iter; /* Newton-solve cap per QP (0 -> 8N + 40)                           */
+  int32_t threads;     /* threads per trajectory block: 0 auto, 64 or 256                  */
+  double lambda;       /* RLS forgetting factor (1.0; Koopman_update.m:258)                */
+  double P0;           /* inv_K_G init scale (1e4 duffing.py:929-930; 1e5 vanderpol.py:874)*/
+  double barQ0;        /* bar_Q init scale (100 duffing.py:946)                            */
+  double Qw, Rw;       /* stage weights (100, 1e-4: duffing.py:580)                        */
+  double lb, ub;       /* input box (+-2 duffing.py:636; +-6 vanderpol.py:542-544)         */
+  double rbf_eps;      /* 1e-4 (vanderpol_RBF.py:22)                                       */
+} kmpc_config;
+
+/* ---- life cycle -------------------------------------------------------------------- */
+int kmpc_create(const kmpc_config* cfg, kmpc_handle** out);
+int kmpc_destroy(kmpc_handle* h);
+const char* kmpc_last_error(const kmpc_handle* h); /* h may be NULL: last create() error */
+int kmpc_version(void);
+
+/* ---- parameters (host pointers, float64, row-major; one-off uploads) ---------------- */
+/* net.Encoder layer `layer` (0-based): y = W x + b, W rows x cols   duffing.py:21-28,
+ * Encoder_Duffing.m:2-6 */
+int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W_host, const double* b_host,
+                           int rows, int cols);
+/* RBF centres cx (L x n)                                             vanderpol_RBF.py:44-46 */
+int kmpc_set_centres(kmpc_handle* h, const double* cx_host, int L, int n);
+/* model used until the first online update exists: Aloc_d, Bloc_d, Cloc_d = offline A, B, C
+ * (duffing.py:811-813).  A (L x L), B (L), C (n x L; ignored for KMPC_OUT_LIFT); broadcast
+ * to every trajectory.                                                                      */
+int kmpc_set_model(kmpc_handle* h, const double* A_host, const double* B_host, const double* C_host);
+/* re-initialise the online state: K_A = 0, inv_K_G = P0 I, bar_X = 0, bar_Q = barQ0 I and
+ * forget the previous transition (duffing.py:927-930, 944-946)                              */
+int kmpc_reset(kmpc_handle* h, void* stream);
+
+/* ---- the hot path, one call per reference statement --------------------------------- */
+/* Psi = lift(X): net.Encoder(x) duffing.py:847 / rbf(x, cx) vanderpol_RBF.py:372.
+ * X_dev (n x B) -> Psi_dev (L x B).                                                         */
+int kmpc_lift(kmpc_handle* h, const void* X_dev, void* Psi_dev, int B, void* stream);
+
+/* The "Koopman update" block duffing.py:900, 927-953, 965-967 for every trajectory:
+ * z = [psi; u]; RLS update of [A B] with target psi_next, and of C with target x_next.
+ * psi (L x B), u (B), psi_next (L x B), x_next (n x B).                                     */
+int kmpc_rls_update(kmpc_handle* h, const void* psi_dev, const void* u_dev, const void* psi_next_dev,
+                    const void* x_next_dev, int B, void* stream);
+
+/* current per-trajectory model: A_dev [B][L][L], B_dev [B][L], C_dev [B][n][L] (any may be
+ * NULL)                                                       duffing.py:965-967, 978-984 */
+int kmpc_get_model(kmpc_handle* h, void* A_dev, void* B_dev, void* C_dev, void* stream);
+
+/* Condensed QP of the current model (Koopman_update.m:455-471, :213; weights duffing.py:580):
+ * H_dev [B][N][N], f_dev [B][N] such that J(u) = u'Hu + f'u + const is costFunction
+ * (duffing.py:540-581).  psi (L x B); ref (q x N) shared by all trajectories when
+ * ref_per_traj == 0, else [B][q][N].                                                        */
+int kmpc_condense(kmpc_handle* h, const void* psi_dev, const void* ref_dev, int ref_per_traj,
+                  void* H_dev, void* f_dev, int B, void* stream);
+
+/* Box QP  min u'Hu + f'u, lb <= u <= ub  -- replaces optimize.minimize(..., bounds=...)
+ * duffing.py:857-861 and quadprog(2H, f, ...) Koopman_update.m:214.  H_dev [B][N][N],
+ * f_dev [B][N] -> U_dev (N x B), status_dev[B], iters_dev[B] (may be NULL).                 */
+int kmpc_qp_solve(kmpc_handle* h, const void* H_dev, const void* f_dev, void* U_dev,
+                  int32_t* status_dev, int32_t* iters_dev, int B, void* stream);
+
+/* One closed-loop control step for all trajectories, in the reference's order
+ * (duffing.py:847-984): lift x_k; if a previous transition exists, RLS-update the model with
+ * (psi_{k-1}, u_{k-1}, psi_k, x_k); condense; solve; u_k.  X_dev (n x B), ref as above,
+ * U0_dev (B), Useq_dev (N x B, may be NULL), status_dev / iters_dev [B] (may be NULL).
+ * The handle keeps psi_k and u_k for the next call.                                         */
+int kmpc_step(kmpc_handle* h, const void* X_dev, const void* ref_dev, int ref_per_traj,
+              void* U0_dev, void* Useq_dev, int32_t* status_dev, int32_t* iters_dev, void* stream);
+
+/* ---- adjacent to the path: the plant on the device ---------------- */
+/* X <- RK4(f, X, U, h) in place: duffing.py:250-261 / vanderpol_RBF.py:113; `switched`
+ * selects the parameters after step 100 (duffing.py:991-992, vanderpol.py:923-931).         */
+int kmpc_plant_step(kmpc_handle* h, int plant, void* X_dev, const void* U_dev, double hstep,
+                    int switched, int B, void* stream);
+
+/* ---- state hand-over / checkpoint ------------------------------------------------------ */
+/* bytes of the persistent state blob (P, K, bar_Q, C, psi_prev, u_prev, flags)              */
+int64_t kmpc_state_bytes(const kmpc_handle* h);
+int kmpc_state_export(kmpc_handle* h, void* host_blob, int64_t bytes);
+int kmpc_state_import(kmpc_handle* h, const void* host_blob, int64_t bytes);
+
+/* ---- measurement ------------------------------------------------------------------------ */
+/* when enabled, kmpc_step brackets its kernels with HIP events on `stream`                  */
+int kmpc_profile_enable(kmpc_handle* h, int on);
+/* accumulated milliseconds since enable/reset: [0] lift kernel, [1] step kernel; count =
+ * number of steps measured.  Synchronises the recorded events.                              */
+int kmpc_profile_read(kmpc_handle* h, double* ms2, int64_t* count, int reset);
+/* algorithmic bytes of one trajectory-step (SURVEY.md 8d formula) for this configuration   */
+int64_t kmpc_algorithmic_bytes_per_step(const kmpc_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* KOOPMPC_H */

@@ -1,0 +1,450 @@
+// api.hip -- the C ABI of libkoopmpc.so (include/koopmpc.h): handle, parameter upload,
+// persistent state and stream-ordered launches.  No compute happens on the host.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/koopmpc.h"
+#include "kernels.h"
+
+using namespace kmpc;
+
+static thread_local std::string g_create_error;
+
+struct kmpc_handle {
+  kmpc_config cfg{};
+  std::string err;
+  virtual ~kmpc_handle() {}
+  virtual int set_encoder_layer(int layer, const double* W, const double* b, int rows, int cols) = 0;
+  virtual int set_centres(const double* cx, int L, int n) = 0;
+  virtual int set_model(const double* A, const double* B, const double* C) = 0;
+  virtual int reset(hipStream_t s) = 0;
+  virtual int lift(const void* X, void* Psi, int B, hipStream_t s) = 0;
+  virtual int rls_update(const void* psi, const void* u, const void* psin, const void* xn, int B, hipStream_t s) = 0;
+  virtual int get_model(void* A, void* B, void* C, hipStream_t s) = 0;
+  virtual int condense(const void* psi, const void* ref, int rpt, void* H, void* f, int B, hipStream_t s) = 0;
+  virtual int qp_solve(const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, hipStream_t s) = 0;
+  virtual int step(const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it,
+                   hipStream_t s) = 0;
+  virtual int plant_step(int plant, void* X, const void* U, double h, int sw, int B, hipStream_t s) = 0;
+  virtual int64_t state_bytes() const = 0;
+  virtual int state_export(void* blob, int64_t bytes) = 0;
+  virtual int state_import(const void* blob, int64_t bytes) = 0;
+  virtual int profile_enable(int on) = 0;
+  virtual int profile_read(double* ms2, int64_t* count, int reset) = 0;
+  virtual int64_t algorithmic_bytes() const = 0;
+};
+
+#define HIPCHK(expr)                                                                  \
+  do {                                                                                \
+    hipError_t e_ = (expr);                                                           \
+    if (e_ != hipSuccess) {                                                           \
+      err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+      return -(int)(1000 + (int)e_);                                                  \
+    }                                                                                 \
+  } while (0)
+
+#define FAIL(code, msg) \
+  do {                  \
+    err = (msg);        \
+    return (code);      \
+  } while (0)
+
+static inline long even_up(long v) { return (v + 1) & ~1L; }
+
+template <typename T>
+struct Impl : kmpc_handle {
+  int n, m, L, p, q, N, B, threads;
+  int Hp = 0, Lp = 0;
+  long sP, sK, sQ, sC;
+  // persistent state
+  T *dP = nullptr, *dK = nullptr, *dQ = nullptr, *dC = nullptr;
+  T *dPsi[2] = {nullptr, nullptr};  // [B][L] trajectory-major: [cur], [prev]
+  T* dUprev = nullptr;
+  int cur = 0;
+  bool have_prev = false;  // a previous (psi, u) exists -> next step runs the RLS update
+  bool rls_fresh = true;   // next RLS update starts from K_A = 0, bar_X = 0
+  // parameters
+  T *dW1 = nullptr, *db1 = nullptr, *dWh[2] = {nullptr, nullptr}, *dbh[2] = {nullptr, nullptr}, *dWo = nullptr,
+    *dbo = nullptr, *dcx = nullptr, *dTmp = nullptr;
+  std::vector<bool> layer_set;
+  bool centres_set = false;
+  // profiling
+  bool prof = false;
+  std::vector<hipEvent_t> ev;  // triples
+  size_t ev_used = 0;
+  static constexpr size_t EV_CAP = 3 * 4096;
+
+  int init(const kmpc_config& c) {
+    cfg = c;
+    n = c.n; m = c.m; L = c.L; N = c.N; B = c.batch; p = L + 1;
+    q = (c.output_kind == KMPC_OUT_LIFT) ? L : n;
+    if (m != 1) FAIL(-2, "m must be 1 (the reference takes B_hat = K[:, Nlift], duffing.py:170-171)");
+    if (n < 1 || n > 4) FAIL(-2, "n must be in 1..4");
+    if (L < 1 || L > 64) FAIL(-2, "L must be in 1..64");
+    if (N < 1 || N > 64) FAIL(-2, "N must be in 1..64");
+    if (B < 1) FAIL(-2, "batch must be >= 1");
+    if (!(c.lambda > 0.0 && c.lambda <= 1.0)) FAIL(-2, "lambda must be in (0, 1]");
+    if (!(c.ub > c.lb)) FAIL(-2, "need lb < ub");
+    threads = c.threads;
+    if (threads == 0) threads = (p * p > 2048 || N * N > 2048) ? 256 : 64;
+    if (threads != 64 && threads != 256) FAIL(-2, "threads must be 0, 64 or 256");
+    int r1, r2;
+    if (step_lds_bytes(n, L, q, N, sizeof(T), &r1, &r2) > 160 * 1024) FAIL(-2, "configuration exceeds 160 KB of LDS");
+    sP = even_up((long)p * p); sK = even_up((long)L * p); sQ = even_up((long)L * L); sC = even_up((long)n * L);
+    HIPCHK(hipMalloc(&dP, sizeof(T) * sP * B));
+    HIPCHK(hipMalloc(&dK, sizeof(T) * sK * B));
+    HIPCHK(hipMalloc(&dQ, sizeof(T) * sQ * B));
+    HIPCHK(hipMalloc(&dC, sizeof(T) * sC * B));
+    HIPCHK(hipMalloc(&dPsi[0], sizeof(T) * (size_t)L * B));
+    HIPCHK(hipMalloc(&dPsi[1], sizeof(T) * (size_t)L * B));
+    HIPCHK(hipMalloc(&dUprev, sizeof(T) * (size_t)B));
+    HIPCHK(hipMalloc(&dTmp, sizeof(T) * (size_t)(L * p + n * L + 64)));
+    HIPCHK(hipMemset(dK, 0, sizeof(T) * sK * B));
+    HIPCHK(hipMemset(dC, 0, sizeof(T) * sC * B));
+    HIPCHK(hipMemset(dPsi[0], 0, sizeof(T) * (size_t)L * B));
+    HIPCHK(hipMemset(dPsi[1], 0, sizeof(T) * (size_t)L * B));
+    HIPCHK(hipMemset(dUprev, 0, sizeof(T) * (size_t)B));
+    if (c.lift_kind == KMPC_LIFT_MLP) {
+      if (c.layers != 2 && c.layers != 3) FAIL(-2, "layers (hidden layers) must be 2 or 3");
+      if (c.hidden < 1 || c.hidden > 128) FAIL(-2, "hidden must be in 1..128");
+      Hp = c.hidden <= 112 ? 112 : 128;
+      Lp = ((L + 15) / 16) * 16;
+      HIPCHK(hipMalloc(&dW1, sizeof(T) * Hp * n));
+      HIPCHK(hipMalloc(&db1, sizeof(T) * Hp));
+      for (int k = 0; k < c.layers - 1; ++k) {
+        HIPCHK(hipMalloc(&dWh[k], sizeof(T) * Hp * Hp));
+        HIPCHK(hipMalloc(&dbh[k], sizeof(T) * Hp));
+      }
+      HIPCHK(hipMalloc(&dWo, sizeof(T) * Lp * Hp));
+      HIPCHK(hipMalloc(&dbo, sizeof(T) * Lp));
+      layer_set.assign(c.layers + 1, false);
+    } else {
+      HIPCHK(hipMalloc(&dcx, sizeof(T) * L * n));
+    }
+    return reset(nullptr);
+  }
+
+  ~Impl() override {
+    for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev,
+                      (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
+                      (void*)dbo, (void*)dcx, (void*)dTmp})
+      if (ptr) (void)hipFree(ptr);
+    for (auto e : ev) (void)hipEventDestroy(e);
+  }
+
+  // upload a (rows x cols) host double matrix into a zero-padded (prow x pcol) device matrix of T
+  int upload_padded(T* dst, const double* src, int rows, int cols, int prow, int pcol) {
+    std::vector<T> tmp((size_t)prow * pcol, T(0));
+    for (int r = 0; r < rows; ++r)
+      for (int c2 = 0; c2 < cols; ++c2) tmp[(size_t)r * pcol + c2] = (T)src[(size_t)r * cols + c2];
+    HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+
+  int set_encoder_layer(int layer, const double* W, const double* b, int rows, int cols) override {
+    if (cfg.lift_kind != KMPC_LIFT_MLP) FAIL(-3, "handle was not created with KMPC_LIFT_MLP");
+    const int nl = cfg.layers + 1;  // linear layers
+    if (layer < 0 || layer >= nl) FAIL(-3, "layer index out of range");
+    const int in_dim = layer == 0 ? n : cfg.hidden;
+    const int out_dim = layer == nl - 1 ? L : cfg.hidden;
+    if (rows != out_dim || cols != in_dim) FAIL(-3, "encoder layer shape does not match the configuration");
+    int rc;
+    if (layer == 0) {
+      if ((rc = upload_padded(dW1, W, rows, cols, Hp, n))) return rc;
+      if ((rc = upload_padded(db1, b, 1, rows, 1, Hp))) return rc;
+    } else if (layer == nl - 1) {
+      if ((rc = upload_padded(dWo, W, rows, cols, Lp, Hp))) return rc;
+      if ((rc = upload_padded(dbo, b, 1, rows, 1, Lp))) return rc;
+    } else {
+      if ((rc = upload_padded(dWh[layer - 1], W, rows, cols, Hp, Hp))) return rc;
+      if ((rc = upload_padded(dbh[layer - 1], b, 1, rows, 1, Hp))) return rc;
+    }
+    layer_set[layer] = true;
+    return 0;
+  }
+
+  int set_centres(const double* cx, int L_, int n_) override {
+    if (cfg.lift_kind == KMPC_LIFT_MLP) FAIL(-3, "handle was created with KMPC_LIFT_MLP");
+    if (L_ != L || n_ != n) FAIL(-3, "centre shape does not match the configuration");
+    int rc = upload_padded(dcx, cx, L, n, L, n);
+    if (rc) return rc;
+    centres_set = true;
+    return 0;
+  }
+
+  int set_model(const double* A, const double* Bm, const double* C) override {
+    std::vector<T> k((size_t)L * p);
+    for (int r = 0; r < L; ++r) {
+      for (int c2 = 0; c2 < L; ++c2) k[(size_t)r * p + c2] = (T)A[(size_t)r * L + c2];
+      k[(size_t)r * p + L] = (T)Bm[r];
+    }
+    HIPCHK(hipMemcpy(dTmp, k.data(), k.size() * sizeof(T), hipMemcpyHostToDevice));
+    HIPCHK(launch_broadcast<T>(dK, sK, dTmp, L * p, B, nullptr));
+    if (cfg.output_kind == KMPC_OUT_CX) {
+      if (!C) FAIL(-3, "C is required for KMPC_OUT_CX");
+      std::vector<T> c((size_t)n * L);
+      for (size_t i = 0; i < c.size(); ++i) c[i] = (T)C[i];
+      HIPCHK(hipMemcpy(dTmp + L * p, c.data(), c.size() * sizeof(T), hipMemcpyHostToDevice));
+      HIPCHK(launch_broadcast<T>(dC, sC, dTmp + L * p, n * L, B, nullptr));
+    }
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+  }
+
+  int reset(hipStream_t s) override {
+    HIPCHK(launch_fill_state<T>(dP, sP, p, (T)cfg.P0, dQ, sQ, L, (T)cfg.barQ0, nullptr, sK, nullptr, sC, n, B, s));
+    have_prev = false;
+    rls_fresh = true;
+    cur = 0;
+    return 0;
+  }
+
+  int check_lift_ready() {
+    if (cfg.lift_kind == KMPC_LIFT_MLP) {
+      for (size_t i = 0; i < layer_set.size(); ++i)
+        if (!layer_set[i]) FAIL(-4, "encoder layer " + std::to_string(i) + " has not been set");
+    } else if (!centres_set) {
+      FAIL(-4, "RBF centres have not been set");
+    }
+    return 0;
+  }
+
+  int lift_to(const T* X, T* Psi, long ps_l, long ps_b, int Bc, hipStream_t s) {
+    int rc = check_lift_ready();
+    if (rc) return rc;
+    LiftArgs<T> a{};
+    a.B = Bc; a.n = n; a.L = L; a.hidden = cfg.hidden; a.nlayers = cfg.layers;
+    a.X = X; a.Psi = Psi; a.ps_l = ps_l; a.ps_b = ps_b;
+    if (cfg.lift_kind == KMPC_LIFT_MLP) {
+      a.W1 = dW1; a.b1 = db1; a.Wh[0] = dWh[0]; a.Wh[1] = dWh[1]; a.bh[0] = dbh[0]; a.bh[1] = dbh[1];
+      a.Wo = dWo; a.bo = dbo; a.Hp = Hp; a.Lp = Lp;
+      HIPCHK(launch_lift_mlp<T>(a, s));
+    } else {
+      a.cx = dcx; a.eps = (T)cfg.rbf_eps; a.rbf_matlab = cfg.lift_kind == KMPC_LIFT_RBF_MATLAB;
+      HIPCHK(launch_lift_rbf<T>(a, s));
+    }
+    return 0;
+  }
+
+  int lift(const void* X, void* Psi, int Bc, hipStream_t s) override {
+    if (Bc < 0 || !X || !Psi) FAIL(-3, "kmpc_lift: bad arguments");
+    return lift_to((const T*)X, (T*)Psi, Bc, 1, Bc, s);
+  }
+
+  StepArgs<T> base_args(int Bc) {
+    StepArgs<T> a{};
+    a.B = Bc; a.n = n; a.L = L; a.q = q; a.N = N;
+    a.out_kind = cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX;
+    a.max_iter = cfg.qp_max_iter > 0 ? cfg.qp_max_iter : 8 * N + 40;
+    a.P = dP; a.strideP = sP; a.K = dK; a.strideK = sK; a.Qb = dQ; a.strideQ = sQ; a.C = dC; a.strideC = sC;
+    a.lam = (T)cfg.lambda; a.Qw = (T)cfg.Qw; a.Rw = (T)cfg.Rw; a.lb = (T)cfg.lb; a.ub = (T)cfg.ub;
+    return a;
+  }
+
+  int rls_update(const void* psi, const void* u, const void* psin, const void* xn, int Bc, hipStream_t s) override {
+    if (Bc != B) FAIL(-3, "kmpc_rls_update: B must equal the handle's batch (the state is per trajectory)");
+    if (!psi || !u || !psin || !xn) FAIL(-3, "kmpc_rls_update: null pointer");
+    StepArgs<T> a = base_args(Bc);
+    a.phases = PH_RLS;
+    a.first_update = rls_fresh ? 1 : 0;
+    a.psi_prev = (const T*)psi; a.pp_sl = Bc; a.pp_sb = 1;
+    a.psi_now = (const T*)psin; a.pn_sl = Bc; a.pn_sb = 1;
+    a.u_prev = (const T*)u; a.x_now = (const T*)xn;
+    HIPCHK(launch_step<T>(a, threads, s));
+    rls_fresh = false;
+    return 0;
+  }
+
+  int get_model(void* A, void* Bm, void* C, hipStream_t s) override {
+    HIPCHK(launch_export_model<T>(dK, sK, cfg.output_kind == KMPC_OUT_CX ? dC : nullptr, sC, n, L, B, (T*)A, (T*)Bm,
+                                  (T*)C, s));
+    return 0;
+  }
+
+  int condense(const void* psi, const void* ref, int rpt, void* H, void* f, int Bc, hipStream_t s) override {
+    if (Bc != B) FAIL(-3, "kmpc_condense: B must equal the handle's batch");
+    if (!psi || !ref || !H || !f) FAIL(-3, "kmpc_condense: null pointer");
+    StepArgs<T> a = base_args(Bc);
+    a.phases = PH_CONDENSE;
+    a.psi_now = (const T*)psi; a.pn_sl = Bc; a.pn_sb = 1;
+    a.ref = (const T*)ref; a.ref_per_traj = rpt;
+    a.H_out = (T*)H; a.f_out = (T*)f;
+    HIPCHK(launch_step<T>(a, threads, s));
+    return 0;
+  }
+
+  int qp_solve(const void* H, const void* f, void* U, int32_t* st, int32_t* it, int Bc, hipStream_t s) override {
+    if (Bc < 0 || !H || !f || !U) FAIL(-3, "kmpc_qp_solve: bad arguments");
+    StepArgs<T> a = base_args(Bc);
+    a.phases = PH_QP;
+    a.H_in = (const T*)H; a.f_in = (const T*)f;
+    a.Useq = (T*)U; a.status = st; a.iters = it;
+    HIPCHK(launch_step<T>(a, threads, s));
+    return 0;
+  }
+
+  int step(const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it,
+           hipStream_t s) override {
+    if (!X || !ref || !U0) FAIL(-3, "kmpc_step: null pointer");
+    hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
+    const bool rec = prof && ev_used + 3 <= EV_CAP;
+    if (rec) {
+      while (ev.size() < ev_used + 3) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ev.push_back(e);
+      }
+      e0 = ev[ev_used]; e1 = ev[ev_used + 1]; e2 = ev[ev_used + 2];
+      HIPCHK(hipEventRecord(e0, s));
+    }
+    T* psi_now = dPsi[cur];
+    T* psi_prev = dPsi[cur ^ 1];
+    int rc = lift_to((const T*)X, psi_now, 1, L, B, s);
+    if (rc) return rc;
+    if (rec) HIPCHK(hipEventRecord(e1, s));
+    StepArgs<T> a = base_args(B);
+    a.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
+    a.first_update = rls_fresh ? 1 : 0;
+    a.psi_prev = psi_prev; a.pp_sl = 1; a.pp_sb = L;
+    a.psi_now = psi_now; a.pn_sl = 1; a.pn_sb = L;
+    a.u_prev = dUprev; a.x_now = (const T*)X;
+    a.ref = (const T*)ref; a.ref_per_traj = rpt;
+    a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
+    HIPCHK(launch_step<T>(a, threads, s));
+    if (rec) {
+      HIPCHK(hipEventRecord(e2, s));
+      ev_used += 3;
+    }
+    if (have_prev) rls_fresh = false;
+    have_prev = true;
+    cur ^= 1;
+    return 0;
+  }
+
+  int plant_step(int plant, void* X, const void* U, double h, int sw, int Bc, hipStream_t s) override {
+    if (n != 2) FAIL(-3, "plants are two-state systems");
+    if (plant != KMPC_PLANT_DUFFING && plant != KMPC_PLANT_VDP) FAIL(-3, "unknown plant");
+    PlantArgs<T> a{};
+    a.B = Bc; a.plant = plant; a.switched = sw; a.h = (T)h; a.X = (T*)X; a.U = (const T*)U;
+    HIPCHK(launch_plant<T>(a, s));
+    return 0;
+  }
+
+  // ---- state blob: header | P | K | Q | C | psi_prev | u_prev
+  struct BlobHeader { int32_t magic, dtype, n, L, N, B, have_prev, rls_fresh; };
+  int64_t state_bytes() const override {
+    return (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * ((sP + sK + sQ + sC) * (int64_t)B + (int64_t)L * B + B);
+  }
+  int state_export(void* blob, int64_t bytes) override {
+    if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_export: buffer too small");
+    HIPCHK(hipDeviceSynchronize());
+    BlobHeader hd{0x4b4d5043, cfg.dtype, n, L, N, B, have_prev ? 1 : 0, rls_fresh ? 1 : 0};
+    char* o = (char*)blob;
+    memcpy(o, &hd, sizeof(hd)); o += sizeof(hd);
+    struct { const T* ptr; size_t cnt; } parts[] = {{dP, (size_t)sP * B}, {dK, (size_t)sK * B}, {dQ, (size_t)sQ * B},
+                                                    {dC, (size_t)sC * B}, {dPsi[cur ^ 1], (size_t)L * B},
+                                                    {dUprev, (size_t)B}};
+    for (auto& pt : parts) {
+      HIPCHK(hipMemcpy(o, pt.ptr, pt.cnt * sizeof(T), hipMemcpyDeviceToHost));
+      o += pt.cnt * sizeof(T);
+    }
+    return 0;
+  }
+  int state_import(const void* blob, int64_t bytes) override {
+    if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_import: buffer too small");
+    BlobHeader hd;
+    const char* o = (const char*)blob;
+    memcpy(&hd, o, sizeof(hd)); o += sizeof(hd);
+    if (hd.magic != 0x4b4d5043 || hd.dtype != cfg.dtype || hd.n != n || hd.L != L || hd.N != N || hd.B != B)
+      FAIL(-3, "kmpc_state_import: blob does not match this handle");
+    HIPCHK(hipDeviceSynchronize());
+    struct { T* ptr; size_t cnt; } parts[] = {{dP, (size_t)sP * B}, {dK, (size_t)sK * B}, {dQ, (size_t)sQ * B},
+                                              {dC, (size_t)sC * B}, {dPsi[cur ^ 1], (size_t)L * B},
+                                              {dUprev, (size_t)B}};
+    for (auto& pt : parts) {
+      HIPCHK(hipMemcpy(pt.ptr, o, pt.cnt * sizeof(T), hipMemcpyHostToDevice));
+      o += pt.cnt * sizeof(T);
+    }
+    have_prev = hd.have_prev != 0;
+    rls_fresh = hd.rls_fresh != 0;
+    return 0;
+  }
+
+  int profile_enable(int on) override {
+    prof = on != 0;
+    ev_used = 0;
+    return 0;
+  }
+  int profile_read(double* ms2, int64_t* count, int reset_) override {
+    double a0 = 0, a1 = 0;
+    for (size_t i = 0; i + 2 < ev_used + 0 && i + 2 < ev.size(); i += 3) {
+      HIPCHK(hipEventSynchronize(ev[i + 2]));
+      float t0 = 0, t1 = 0;
+      HIPCHK(hipEventElapsedTime(&t0, ev[i], ev[i + 1]));
+      HIPCHK(hipEventElapsedTime(&t1, ev[i + 1], ev[i + 2]));
+      a0 += t0; a1 += t1;
+    }
+    if (ms2) { ms2[0] = a0; ms2[1] = a1; }
+    if (count) *count = (int64_t)(ev_used / 3);
+    if (reset_) ev_used = 0;
+    return 0;
+  }
+
+  int64_t algorithmic_bytes() const override {
+    // s [ 2 (p^2 + L p + L^2 + n L) + (L + L p + n L + N m + n) + (n + m + q N) ]
+    const int64_t s = sizeof(T);
+    return s * (2 * ((int64_t)p * p + L * p + L * L + n * L) + (L + L * p + n * L + N * m + n) + (n + m + q * N));
+  }
+};
+
+// ---------------------------------------------------------------------------------------
+extern "C" {
+
+int kmpc_version(void) { return 100; }
+
+int kmpc_create(const kmpc_config* cfg, kmpc_handle** out) {
+  if (!cfg || !out) { g_create_error = "kmpc_create: null argument"; return -1; }
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) {
+    g_create_error = "kmpc_create: no HIP device visible (libkoopmpc has no CPU path)";
+    return -5;
+  }
+  kmpc_handle* h = nullptr;
+  int rc;
+  if (cfg->dtype == KMPC_F64) { auto* i = new Impl<double>(); rc = i->init(*cfg); h = i; }
+  else if (cfg->dtype == KMPC_F32) { auto* i = new Impl<float>(); rc = i->init(*cfg); h = i; }
+  else { g_create_error = "kmpc_create: dtype must be KMPC_F32 or KMPC_F64"; return -2; }
+  if (rc) { g_create_error = h->err; delete h; return rc; }
+  *out = h;
+  return 0;
+}
+
+int kmpc_destroy(kmpc_handle* h) { delete h; return 0; }
+const char* kmpc_last_error(const kmpc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+#define NN(h) if (!(h)) return -1
+int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { NN(h); return h->set_encoder_layer(layer, W, b, rows, cols); }
+int kmpc_set_centres(kmpc_handle* h, const double* cx, int L, int n) { NN(h); return h->set_centres(cx, L, n); }
+int kmpc_set_model(kmpc_handle* h, const double* A, const double* B, const double* C) { NN(h); return h->set_model(A, B, C); }
+int kmpc_reset(kmpc_handle* h, void* s) { NN(h); return h->reset((hipStream_t)s); }
+int kmpc_lift(kmpc_handle* h, const void* X, void* Psi, int B, void* s) { NN(h); return h->lift(X, Psi, B, (hipStream_t)s); }
+int kmpc_rls_update(kmpc_handle* h, const void* psi, const void* u, const void* psin, const void* xn, int B, void* s) { NN(h); return h->rls_update(psi, u, psin, xn, B, (hipStream_t)s); }
+int kmpc_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->get_model(A, B, C, (hipStream_t)s); }
+int kmpc_condense(kmpc_handle* h, const void* psi, const void* ref, int rpt, void* H, void* f, int B, void* s) { NN(h); return h->condense(psi, ref, rpt, H, f, B, (hipStream_t)s); }
+int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, void* s) { NN(h); return h->qp_solve(H, f, U, st, it, B, (hipStream_t)s); }
+int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
+int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NN(h); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
+int64_t kmpc_state_bytes(const kmpc_handle* h) { return h ? h->state_bytes() : -1; }
+int kmpc_state_export(kmpc_handle* h, void* blob, int64_t bytes) { NN(h); return h->state_export(blob, bytes); }
+int kmpc_state_import(kmpc_handle* h, const void* blob, int64_t bytes) { NN(h); return h->state_import(blob, bytes); }
+int kmpc_profile_enable(kmpc_handle* h, int on) { NN(h); return h->profile_enable(on); }
+int kmpc_profile_read(kmpc_handle* h, double* ms2, int64_t* count, int reset) { NN(h); return h->profile_read(ms2, count, reset); }
+int64_t kmpc_algorithmic_bytes_per_step(const kmpc_handle* h) { return h ? h->algorithmic_bytes() : -1; }
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+// aux_kernels.hip -- small device helpers around the hot path: state initialisation, model
+// export, and the plant simulators used to close the loop on the device.
+//   Duffing   x1' = x2, x2' = -0.5 x2 + x1 - x1^3 + u            duffing.py:255
+//             after step 100: x2' = -5 x2 + 2 x1 - 0.5 x1^3 + u   duffing.py:991-992
+//   Van der Pol  x1' = 2 x2, x2' = 2 x2 - 10 x1^2 x2 - 0.8 x1 + u vanderpol_RBF.py:113
+//             after step 100: x1' = x2, x2' = -3 x2 - 10 x1^2 x2 - 3 x1 + u  vanderpol.py:923-931
+//   RK4, h = 0.05                                                duffing.py:256-261
+#include "kernels.h"
+
+namespace kmpc {
+
+template <typename T> __device__ __forceinline__ void plant_f(int plant, int sw, T x1, T x2, T u, T& d1, T& d2) {
+  if (plant == 0) {
+    if (sw) { d1 = x2; d2 = T(-10.0) * T(0.5) * x2 + T(2.0) * x1 - T(0.5) * x1 * x1 * x1 + u; }
+    else    { d1 = x2; d2 = T(-0.5) * x2 + x1 - x1 * x1 * x1 + u; }
+  } else {
+    if (sw) { d1 = x2; d2 = T(-3.0) * x2 - T(10.0) * x1 * x1 * x2 - T(3.0) * x1 + u; }
+    else    { d1 = T(2.0) * x2; d2 = T(2.0) * x2 - T(10.0) * x1 * x1 * x2 - T(0.8) * x1 + u; }
+  }
+}
+
+template <typename T> __global__ __launch_bounds__(256) void plant_kernel(const PlantArgs<T> a) {
+  const int B = a.B;
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
+    const T x1 = a.X[b], x2 = a.X[(size_t)B + b], u = a.U[b], h = a.h;
+    T k1a, k1b, k2a, k2b, k3a, k3b, k4a, k4b;
+    plant_f(a.plant, a.switched, x1, x2, u, k1a, k1b);
+    plant_f(a.plant, a.switched, x1 + T(0.5) * h * k1a, x2 + T(0.5) * h * k1b, u, k2a, k2b);
+    plant_f(a.plant, a.switched, x1 + T(0.5) * h * k2a, x2 + T(0.5) * h * k2b, u, k3a, k3b);
+    plant_f(a.plant, a.switched, x1 + h * k3a, x2 + h * k3b, u, k4a, k4b);
+    a.X[b] = x1 + (h / T(6.0)) * (k1a + T(2.0) * k2a + T(2.0) * k3a + k4a);
+    a.X[(size_t)B + b] = x2 + (h / T(6.0)) * (k1b + T(2.0) * k2b + T(2.0) * k3b + k4b);
+  }
+}
+
+template <typename T> hipError_t launch_plant(const PlantArgs<T>& a, hipStream_t s) {
+  if (a.B <= 0) return hipSuccess;
+  int grid = (a.B + 255) / 256;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL((plant_kernel<T>), dim3(grid), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
+// P = P0 I, bar_Q = Q0 I, K = 0, C = 0 for every trajectory   (duffing.py:927-930, 944-946)
+template <typename T>
+__global__ __launch_bounds__(256) void fill_state_kernel(T* P, long strideP, int p, T P0, T* Qb, long strideQ, int L,
+                                                         T Q0, T* K, long strideK, T* C, long strideC, int n) {
+  const int b = blockIdx.x;
+  T* Pb = P + (size_t)b * strideP;
+  for (int e = threadIdx.x; e < (int)strideP; e += blockDim.x) Pb[e] = (e < p * p && e / p == e % p) ? P0 : T(0);
+  T* Qq = Qb + (size_t)b * strideQ;
+  for (int e = threadIdx.x; e < (int)strideQ; e += blockDim.x) Qq[e] = (e < L * L && e / L == e % L) ? Q0 : T(0);
+  if (K) {
+    T* Kb = K + (size_t)b * strideK;
+    for (int e = threadIdx.x; e < (int)strideK; e += blockDim.x) Kb[e] = T(0);
+  }
+  if (C) {
+    T* Cb = C + (size_t)b * strideC;
+    for (int e = threadIdx.x; e < (int)strideC; e += blockDim.x) Cb[e] = T(0);
+  }
+}
+
+template <typename T>
+hipError_t launch_fill_state(T* P, long strideP, int p, T P0, T* Qb, long strideQ, int L, T Q0, T* K, long strideK,
+                             T* C, long strideC, int n, int B, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((fill_state_kernel<T>), dim3(B), dim3(256), 0, s, P, strideP, p, P0, Qb, strideQ, L, Q0, K,
+                     strideK, C, strideC, n);
+  return hipGetLastError();
+}
+
+// split K = [A B] (duffing.py:965-967) into dense per-trajectory blocks
+template <typename T>
+__global__ __launch_bounds__(256) void export_model_kernel(const T* K, long strideK, const T* C, long strideC, int n,
+                                                           int L, T* A_out, T* B_out, T* C_out) {
+  const int b = blockIdx.x, p = L + 1;
+  const T* Kb = K + (size_t)b * strideK;
+  if (A_out)
+    for (int e = threadIdx.x; e < L * L; e += blockDim.x) A_out[(size_t)b * L * L + e] = Kb[(e / L) * p + (e % L)];
+  if (B_out)
+    for (int e = threadIdx.x; e < L; e += blockDim.x) B_out[(size_t)b * L + e] = Kb[e * p + L];
+  if (C_out && C) {
+    const T* Cb = C + (size_t)b * strideC;
+    for (int e = threadIdx.x; e < n * L; e += blockDim.x) C_out[(size_t)b * n * L + e] = Cb[e];
+  }
+}
+
+template <typename T>
+hipError_t launch_export_model(const T* K, long strideK, const T* C, long strideC, int n, int L, int B, T* A_out,
+                               T* B_out, T* C_out, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((export_model_kernel<T>), dim3(B), dim3(256), 0, s, K, strideK, C, strideC, n, L, A_out, B_out,
+                     C_out);
+  return hipGetLastError();
+}
+
+// dst[b*stride + e] = src[e]  (offline model handed to every trajectory, duffing.py:811-813)
+template <typename T>
+__global__ __launch_bounds__(256) void broadcast_kernel(T* dst, long stride, const T* src, int count) {
+  T* d = dst + (size_t)blockIdx.x * stride;
+  for (int e = threadIdx.x; e < count; e += blockDim.x) d[e] = src[e];
+}
+template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((broadcast_kernel<T>), dim3(B), dim3(256), 0, s, dst, stride, src, count);
+  return hipGetLastError();
+}
+
+#define INST(T)                                                                                                      \
+  template hipError_t launch_plant<T>(const PlantArgs<T>&, hipStream_t);                                             \
+  template hipError_t launch_fill_state<T>(T*, long, int, T, T*, long, int, T, T*, long, T*, long, int, int,        \
+                                           hipStream_t);                                                             \
+  template hipError_t launch_broadcast<T>(T*, long, const T*, int, int, hipStream_t);                                \
+  template hipError_t launch_export_model<T>(const T*, long, const T*, long, int, int, int, T*, T*, T*, hipStream_t);
+INST(float)
+INST(double)
+
+}  // namespace kmpc

@@ -1,0 +1,76 @@
+// kernels.h -- launch interfaces between the C-ABI layer (api.hip) and the gfx950 kernels.
+// Device code lives in step_kernel.hip (RLS -> condense -> box-QP, one block per trajectory),
+// lift_kernel.hip (MLP encoder on f64/f32 MFMA, RBF dictionary) and plant_kernel.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace kmpc {
+
+enum { PH_RLS = 1, PH_CONDENSE = 2, PH_QP = 4 };
+enum { OUT_CX = 0, OUT_LIFT = 1 };
+
+// Arguments of the per-trajectory step kernel.  Panels are batch-contiguous ((r, b) at
+// r*B + b); state blocks are trajectory-major with 16-byte aligned strides.
+template <typename T>
+struct StepArgs {
+  int B, n, L, q, N;
+  int out_kind;      // OUT_CX / OUT_LIFT
+  int phases;        // PH_* mask
+  int first_update;  // RLS starts from K_A = 0, bar_X = 0 (duffing.py:927-928, 944-945)
+  int max_iter;
+  int ref_per_traj;
+  int r1, r2;        // LDS region sizes in elements (host-computed, see step_lds_elems)
+  // persistent state
+  T* P;   long strideP;   // [B][p*p]   inv_K_G
+  T* K;   long strideK;   // [B][L*p]   [A B] = K_A inv_K_G
+  T* Qb;  long strideQ;   // [B][L*L]   bar_Q
+  T* C;   long strideC;   // [B][n*L]   C = bar_X bar_Q
+  // RLS inputs: psi_prev(l,b) at l*pp_sl + b*pp_sb ; psi_now likewise
+  const T* psi_prev; long pp_sl, pp_sb;
+  const T* psi_now;  long pn_sl, pn_sb;
+  const T* u_prev;   // [B]
+  const T* x_now;    // (n x B)
+  // condense
+  const T* ref;      // (q x N) or [B][q][N]
+  T* H_out; T* f_out;        // optional exports  [B][N*N], [B][N]
+  const T* H_in; const T* f_in;  // QP-only mode inputs
+  // QP
+  T* Useq;           // (N x B) or null
+  T* U0;             // [B] or null
+  T* u_store;        // [B] handle copy of u_k for the next RLS update, or null
+  int32_t* status; int32_t* iters;
+  T lam, Qw, Rw, lb, ub;
+};
+
+template <typename T> struct LiftArgs {
+  int B, n, L, hidden, nlayers;  // nlayers = hidden layers d (2 or 3)
+  const T* X;                    // (n x B)
+  T* Psi; long ps_l, ps_b;       // element (l,b) at l*ps_l + b*ps_b
+  // MLP: weights row-major (out x in), zero padded: W1 (Hp x n), Wh[k] (Hp x Hp), Wo (Lp x Hp)
+  const T* W1; const T* b1;
+  const T* Wh[2]; const T* bh[2];
+  const T* Wo; const T* bo;
+  int Hp, Lp;
+  // RBF
+  const T* cx; T eps; int rbf_matlab;
+};
+
+template <typename T> struct PlantArgs {
+  int B, plant, switched; T h; T* X; const T* U;
+};
+
+size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2);
+
+template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s);
+template <typename T> hipError_t launch_lift_mlp(const LiftArgs<T>& a, hipStream_t s);
+template <typename T> hipError_t launch_lift_rbf(const LiftArgs<T>& a, hipStream_t s);
+template <typename T> hipError_t launch_plant(const PlantArgs<T>& a, hipStream_t s);
+template <typename T> hipError_t launch_fill_state(T* P, long strideP, int p, T P0, T* Qb, long strideQ, int L,
+                                                   T Q0, T* K, long strideK, T* C, long strideC, int n, int B,
+                                                   hipStream_t s);
+template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s);
+template <typename T> hipError_t launch_export_model(const T* K, long strideK, const T* C, long strideC, int n, int L,
+                                                     int B, T* A_out, T* B_out, T* C_out, hipStream_t s);
+
+}  // namespace kmpc

