@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""MPC steps/s of the Koopman online-updated MPC hot path (lift -> RLS-EDMD update -> condensed QP ->
+box-QP) on MI355X, BASELINE.json configs[1]: Duffing, 20-dim MLP lift, N = 20, batch = 4096
+trajectories per GPU.
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
+           --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
+
+A "step" is one closed-loop control step of every trajectory: kmpc_step (lift of the current state,
+RLS update with the previous transition, condensed-QP build, exact box-QP solve) followed by the RK4
+plant on the device; the whole loop is enqueued from C++ (kmpc_rollout), inputs are resident in HBM.
+Multi-GPU: trajectories are independent, every rank owns its own 4096 (weak scaling), no collective on
+the step path; the timed region is bracketed by barrier + synchronize and the MAX over ranks is used.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (step_kernel): algorithmic bytes
+(SURVEY.md 8d formula, kmpc_algorithmic_bytes_per_step) x trajectories per launch / its average
+duration measured with HIP events on the launch stream.  `cpu_baseline` times the NumPy oracle run the
+way the reference runs (per-trajectory Python loop, SciPy L-BFGS-B on the shooting cost,
+duffing.py:857-859) on a bounded sample of the same workload, one core.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "koopman-online-updated-mpc_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
+
+
+def cpu_baseline(weights, A0, B0, C0, x0s, L, N, budget_s):
+    """The reference's path on the host, one core: per-trajectory loop, lift -> L-BFGS-B solve -> plant ->
+    RLS (duffing.py:823-1012 order) through the oracle.  Bounded: stops after `budget_s` seconds."""
+    from oracle import koopman_oracle as ko
+
+    lift = lambda x: ko.mlp_lift(weights, x)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    steps_per_traj = 8
+    out = {}
+    for solver in ("lbfgsb", "exact"):
+        t0 = time.perf_counter()
+        done = 0
+        lim = budget_s if solver == "lbfgsb" else budget_s / 3.0
+        for t in range(x0s.shape[1]):
+            ctl = ko.OracleController(lift, L, 2, N, -2.0, 2.0, A0, B0, C0, solver=solver)
+            x = x0s[:, t].copy()
+            for k in range(steps_per_traj):
+                u, _, _ = ctl.step(x, r)
+                x = ko.plant_step("duffing", x, u)
+                done += 1
+            if time.perf_counter() - t0 > lim:
+                break
+        dt = time.perf_counter() - t0
+        out[solver] = (done / dt, done, dt)
+    return out, steps_per_traj
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
+    ap.add_argument("--L", type=int, default=20)
+    ap.add_argument("--N", type=int, default=20)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d "
+                     "(WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=dev)
+
+    from koopmpc import KoopmanMPC, max_over_ranks
+    from koopmpc.synth import initial_states, offline_edmd, random_mlp_weights
+
+    L, N, B = args.L, args.N, args.batch
+    dtype = torch.float64 if args.dtype == "f64" else torch.float32
+    weights = random_mlp_weights(2, 100, 3, L, seed=2024)
+    mpc = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev)
+    A0, B0, C0 = offline_edmd(lambda X: mpc.Encoder(X))  # one-off, identical on every rank
+    mpc.set_model(A0, B0, C0)
+    x0 = initial_states(B, seed=101 + rank)
+    X = torch.tensor(x0, dtype=dtype, device=dev).contiguous()
+    r = torch.tensor(np.tile(np.array([[1.0], [0.0]]), (1, N)), dtype=dtype, device=dev)
+
+    def sync_all():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    # ---- warm-up (untimed), then EXACTLY --steps timed steps
+    mpc.rollout("duffing", X, r, args.warmup, step0=0)
+    sync_all()
+    t0 = time.perf_counter()
+    mpc.rollout("duffing", X, r, args.steps, step0=args.warmup)
+    torch.cuda.synchronize(dev)
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize(dev)
+    dt = max_over_ranks(time.perf_counter() - t0, device=dev)
+    worst_status = int(mpc.status.max().item())
+    newton_per_step = float(mpc.iters.double().mean().item()) / max(1, args.steps)
+    newton_max = int(mpc.iters.max().item())
+
+    # ---- per-kernel durations for the roofline (same workload continued, HIP events on the launch stream)
+    prof_steps = min(args.steps, 1000)
+    mpc.profile(True)
+    mpc.rollout("duffing", X, r, prof_steps, step0=args.warmup + args.steps)
+    torch.cuda.synchronize(dev)
+    pr = mpc.profile_read()
+    mpc.profile(False)
+    step_ms = pr["step_ms"] / max(1, pr["count"])
+    lift_ms = pr["lift_ms"] / max(1, pr["count"])
+    bytes_per_traj = mpc.algorithmic_bytes_per_step()
+    achieved = bytes_per_traj * B / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+    x_ok = bool(torch.isfinite(X).all().item())
+
+    if dist is not None:
+        flag = torch.tensor([worst_status, 0 if x_ok else 1], device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+        worst_status, x_ok = int(flag[0].item()), int(flag[1].item()) == 0
+
+    if rank == 0:
+        total = B * world
+        out = {
+            "metric": "MPC steps/s (lift+EDMD-update+QP, N=%d, %d-dim lift)" % (N, L),
+            "value": total * args.steps / dt,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE cfg2: Duffing closed loop, %d-dim MLP lift (2-100-100-100-%d, random init seed 2024), "
+                            "horizon N=%d, box +-2, %d trajectories per GPU x %d GPU(s), per-trajectory RLS, "
+                            "RK4 plant on device, parameter switch at step 102" % (L, L, N, B, world),
+                "global_batch": total,
+                "parallelism": "trajectory-sharded x%d, no collective on the step path" % world,
+                "qp": "exact box-QP (projected Newton), cold start; mean Newton solves/step %.2f, worst trajectory total %d"
+                      % (newton_per_step, newton_max),
+                "worst_qp_status": worst_status,
+                "finite": x_ok,
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "step_kernel (RLS + condense + QP), %d blocks x %d threads" % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64)),
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "algorithmic_bytes_per_trajectory_step": bytes_per_traj,
+                "avg_kernel_ms": step_ms,
+                "avg_lift_kernel_ms": lift_ms,
+            },
+        }
+        if world == 1 and args.cpu_seconds > 0:
+            res, spt = cpu_baseline(weights, A0, B0, C0, x0, L, N, args.cpu_seconds)
+            v, done, secs = res["lbfgsb"]
+            ve, donee, secse = res["exact"]
+            out["cpu_baseline"] = {
+                "value": v,
+                "unit": "steps/s",
+                "cores": 1,
+                "kind": "port",
+                "sample": "first %d trajectories x %d closed-loop steps of the same workload (%d trajectory-steps, %.1f s), "
+                          "NumPy oracle with SciPy L-BFGS-B exactly as duffing.py:857-859; host has %d cores"
+                          % (done // spt, spt, done, secs, os.cpu_count()),
+                "exact_qp_variant_value": ve,
+            }
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

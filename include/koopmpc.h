@@ -130,6 +130,16 @@ int kmpc_step(kmpc_handle* h, const void* X_dev, const void* ref_dev, int ref_pe
 int kmpc_plant_step(kmpc_handle* h, int plant, void* X_dev, const void* U_dev, double hstep,
                     int switched, int B, void* stream);
 
+/* `steps` iterations of the reference loop body (duffing.py:823-1012) without returning to the host:
+ * for i = step0 .. step0+steps-1: kmpc_step(X) -> u_i; X <- plant(X, u_i) with the switched
+ * parameters once i >= switch_step (the reference switches at the end of iteration 101, i.e.
+ * switch_step = 102; pass a negative value for "never").  Optional outputs: U_log_dev (steps x B),
+ * X_log_dev (steps x n x B, the state AFTER each plant step), status_dev[B] (worst QP status of
+ * each trajectory over the call), iters_dev[B] (its total number of Newton solves).            */
+int kmpc_rollout(kmpc_handle* h, int plant, void* X_dev, const void* ref_dev, int ref_per_traj,
+                 int steps, int step0, int switch_step, double hstep, void* U_log_dev, void* X_log_dev,
+                 int32_t* status_dev, int32_t* iters_dev, void* stream);
+
 /* ---- state hand-over / checkpoint ------------------------------------------------------ */
 /* bytes of the persistent state blob (P, K, bar_Q, C, psi_prev, u_prev, flags)              */
 int64_t kmpc_state_bytes(const kmpc_handle* h);

@@ -31,6 +31,8 @@ struct kmpc_handle {
   virtual int step(const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it,
                    hipStream_t s) = 0;
   virtual int plant_step(int plant, void* X, const void* U, double h, int sw, int B, hipStream_t s) = 0;
+  virtual int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
+                      void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) = 0;
   virtual int64_t state_bytes() const = 0;
   virtual int state_export(void* blob, int64_t bytes) = 0;
   virtual int state_import(const void* blob, int64_t bytes) = 0;
@@ -132,7 +134,7 @@ struct Impl : kmpc_handle {
   ~Impl() override {
     for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev,
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
-                      (void*)dbo, (void*)dcx, (void*)dTmp})
+                      (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -315,6 +317,7 @@ struct Impl : kmpc_handle {
     a.u_prev = dUprev; a.x_now = (const T*)X;
     a.ref = (const T*)ref; a.ref_per_traj = rpt;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
+    a.accumulate = accumulate ? 1 : 0;
     HIPCHK(launch_step<T>(a, threads, s));
     if (rec) {
       HIPCHK(hipEventRecord(e2, s));
@@ -332,6 +335,29 @@ struct Impl : kmpc_handle {
     PlantArgs<T> a{};
     a.B = Bc; a.plant = plant; a.switched = sw; a.h = (T)h; a.X = (T*)X; a.U = (const T*)U;
     HIPCHK(launch_plant<T>(a, s));
+    return 0;
+  }
+
+  T* dU0 = nullptr;  // rollout scratch [B]
+  bool accumulate = false;
+  int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
+              void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) override {
+    if (!X || !ref || steps < 0) FAIL(-3, "kmpc_rollout: bad arguments");
+    if (!dU0) HIPCHK(hipMalloc(&dU0, sizeof(T) * (size_t)B));
+    if (st) HIPCHK(hipMemsetAsync(st, 0, sizeof(int32_t) * (size_t)B, s));
+    if (it) HIPCHK(hipMemsetAsync(it, 0, sizeof(int32_t) * (size_t)B, s));
+    for (int i = 0; i < steps; ++i) {
+      const int gi = step0 + i;
+      T* u = Ulog ? (T*)Ulog + (size_t)i * B : dU0;
+      accumulate = true;
+      int rc = step(X, ref, rpt, u, nullptr, st, it, s);
+      accumulate = false;
+      if (rc) return rc;
+      rc = plant_step(plant, X, u, hs, (switch_step >= 0 && gi >= switch_step) ? 1 : 0, B, s);
+      if (rc) return rc;
+      if (Xlog) HIPCHK(hipMemcpyAsync((T*)Xlog + (size_t)i * n * B, X, sizeof(T) * (size_t)n * B,
+                                      hipMemcpyDeviceToDevice, s));
+    }
     return 0;
   }
 
@@ -440,6 +466,7 @@ int kmpc_condense(kmpc_handle* h, const void* psi, const void* ref, int rpt, voi
 int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, void* s) { NN(h); return h->qp_solve(H, f, U, st, it, B, (hipStream_t)s); }
 int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
 int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NN(h); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
+int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NN(h); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
 int64_t kmpc_state_bytes(const kmpc_handle* h) { return h ? h->state_bytes() : -1; }
 int kmpc_state_export(kmpc_handle* h, void* blob, int64_t bytes) { NN(h); return h->state_export(blob, bytes); }
 int kmpc_state_import(kmpc_handle* h, const void* blob, int64_t bytes) { NN(h); return h->state_import(blob, bytes); }

@@ -20,6 +20,7 @@ struct StepArgs {
   int first_update;  // RLS starts from K_A = 0, bar_X = 0 (duffing.py:927-928, 944-945)
   int max_iter;
   int ref_per_traj;
+  int accumulate;    // status[b] = max(status[b], s), iters[b] += it (rollouts)
   int r1, r2;        // LDS region sizes in elements (host-computed, see step_lds_elems)
   // persistent state
   T* P;   long strideP;   // [B][p*p]   inv_K_G

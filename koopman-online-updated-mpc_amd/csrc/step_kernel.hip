@@ -118,7 +118,6 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   T* const qrhs = qHxa + N;
   int* const flg = reinterpret_cast<int*>(qrhs + N);  // N ints
 
-  const bool need_model = (a.phases & (PH_RLS | PH_CONDENSE)) != 0;
 
   // =====================================================================================
   // phase 1: recursive least squares (gain form; algebraically K_A inv_K_G of the reference)
@@ -224,7 +223,6 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     for (int i = tid; i < L; i += TPB) sy[i] = a.psi_now[i * a.pn_sl + b * a.pn_sb];
     __syncthreads();
   }
-  (void)need_model;
 
   // =====================================================================================
   // phase 2: condensed QP  H = Qw Phi'Phi + Rw I,  f = 2 Qw Phi'(Gamma psi - r)
@@ -448,8 +446,8 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     if (tid == 0) {
       if (a.U0) a.U0[b] = qx[0];
       if (a.u_store) a.u_store[b] = qx[0];
-      if (a.status) a.status[b] = status;
-      if (a.iters) a.iters[b] = it;
+      if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
+      if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
     }
   }
 }

@@ -48,6 +48,7 @@ SIGNATURES = {
     "kmpc_qp_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "kmpc_step": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_plant_step": (_I, [_VP, _I, _VP, _VP, _D, _I, _I, _VP]),
+    "kmpc_rollout": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_state_bytes": (_I64, [_VP]),
     "kmpc_state_export": (_I, [_VP, _VP, _I64]),
     "kmpc_state_import": (_I, [_VP, _VP, _I64]),
@@ -64,6 +65,11 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: libkoopmpc.so and torch must share ONE HIP runtime (torch's bundled
+    # libamdhip64 has the same SONAME; whichever is loaded first serves both), otherwise the
+    # device pointers torch hands out are not valid for our launches.
+    import torch  # noqa: F401
+
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             "koopmpc: %s is missing. Build the HIP library first (python __graft_entry__.py, or "

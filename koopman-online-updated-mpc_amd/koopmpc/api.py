@@ -222,6 +222,24 @@ class KoopmanMPC:
                                            X.shape[1], self._stream()), "kmpc_plant_step")
         return X
 
+    def rollout(self, kind, X, r, steps, step0=0, switch_step=102, h=0.05, log=False):
+        """`steps` iterations of the reference loop body (duffing.py:823-1012) enqueued from C++:
+        u_i = step(X); X <- plant(X, u_i), switched parameters from iteration `switch_step` on
+        (the reference flips them at the end of iteration 101).  X (n,B) device tensor, updated in place.
+        self.status / self.iters receive each trajectory's worst QP status and total Newton solves.
+        Returns (U_log (steps,B), X_log (steps,n,B)) when log=True."""
+        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP}[kind]
+        assert X.is_cuda and X.dtype == self.dtype and X.is_contiguous() and tuple(X.shape) == (self.n, self.B)
+        rr, per = self._ref(r)
+        Ul = torch.empty(steps, self.B, dtype=self.dtype, device=self.device) if log else None
+        Xl = torch.empty(steps, self.n, self.B, dtype=self.dtype, device=self.device) if log else None
+        self._chk(self.lib.kmpc_rollout(self.h, plant, self._p(X), self._p(rr), per, int(steps), int(step0),
+                                        int(switch_step), float(h), self._p(Ul) if log else None,
+                                        self._p(Xl) if log else None, self._p(self.status), self._p(self.iters),
+                                        self._stream()), "kmpc_rollout")
+        self._keep = (rr,)  # keep the reference tensor alive until the stream has consumed it
+        return (Ul, Xl) if log else None
+
     # ------------------------------------------------------------------ checkpoint
     def state_dict(self):
         nb = self.lib.kmpc_state_bytes(self.h)

@@ -338,19 +338,27 @@ class OracleController:
     """
 
     def __init__(self, lift, L, n, N, lb, ub, A0, B0, C0, P0=1e4, barQ0=100.0, Qw=100.0, Rw=1e-4,
-                 output="Cx", solver="exact"):
+                 output="Cx", solver="exact", rls="reference"):
         self.lift, self.L, self.n, self.N = lift, L, n, N
         self.lb, self.ub, self.Qw, self.Rw = lb, ub, Qw, Rw
         self.A, self.B, self.C = np.array(A0, float), np.array(B0, float).reshape(L, 1), np.array(C0, float)
         self.rls = RlsStateRef(L, 1, n, P0, barQ0)
-        self.output, self.solver = output, solver
+        self.output, self.solver, self.rls_form = output, solver, rls
+        # gain-form state (same estimator, evaluated without the K_A * inv_K_G product)
+        self.gK, self.gP = np.zeros((L, L + 1)), P0 * np.eye(L + 1)
+        self.gC, self.gQ = np.zeros((n, L)), barQ0 * np.eye(L)
         self.prev = None
 
     def step(self, x, r):
         psi = self.lift(np.reshape(x, (-1, 1))).reshape(-1)
         if self.prev is not None:
             ppsi, pu = self.prev
-            self.A, self.B, self.C = rls_update_reference(self.rls, ppsi, pu, psi, x)
+            if self.rls_form == "reference":
+                self.A, self.B, self.C = rls_update_reference(self.rls, ppsi, pu, psi, x)
+            else:
+                self.gK, self.gP = rls_update_gain(self.gK, self.gP, np.concatenate([ppsi, [pu]]), psi)
+                self.gC, self.gQ = rls_update_gain(self.gC, self.gQ, ppsi, np.reshape(x, -1))
+                self.A, self.B, self.C = self.gK[:, :-1].copy(), self.gK[:, -1:].copy(), self.gC.copy()
         Co = None if self.output == "lift" else self.C
         if self.solver == "exact":
             _, _, H, f, _ = condense(self.A, self.B, Co, psi, r, self.N, self.Qw, self.Rw)

@@ -1,0 +1,155 @@
+"""CPU-side checks: the C-ABI library loads and exports every symbol include/koopmpc.h declares,
+the product fails loudly without a GPU (no CPU path), and the multi-GPU host logic (batch
+sharding + max-over-ranks timing) works over gloo with world_size 2.  No compute kernels run."""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PKG = os.path.join(ROOT, "koopman-online-updated-mpc_amd")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from koopmpc import _ffi
+
+    if not os.path.exists(_ffi.LIB_PATH):
+        subprocess.check_call(["make", "-C", PKG, "-j4"])
+    return _ffi.load()
+
+
+def _declared_symbols():
+    src = open(os.path.join(ROOT, "include", "koopmpc.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(kmpc_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from koopmpc import _ffi
+
+    names = _declared_symbols()
+    assert len(names) >= 20
+    assert sorted(_ffi.SIGNATURES) == names  # the ctypes table binds exactly the header's API
+    for n in names:
+        assert getattr(lib, n) is not None
+    assert lib.kmpc_version() >= 100
+
+
+def test_config_struct_layout_matches_header():
+    from koopmpc import _ffi
+
+    src = open(os.path.join(ROOT, "include", "koopmpc.h")).read()
+    body = re.search(r"typedef struct kmpc_config \{(.*?)\} kmpc_config;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        typ, names = decl.split(None, 1)
+        for nm in names.split(","):
+            fields.append((nm.strip(), typ))
+    got = [(n if n != "lam" else "lambda", {ctypes.c_int32: "int32_t", ctypes.c_double: "double"}[t]) for n, t in _ffi.KmpcConfig._fields_]
+    assert got == fields
+
+
+def test_no_gpu_means_loud_failure(lib):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: the failure path is not reachable")
+    from koopmpc import _ffi
+
+    cfg = _ffi.KmpcConfig(n=2, m=1, L=8, N=10, hidden=100, layers=3, batch=4, dtype=1, lam=1.0, P0=1e4, barQ0=100.0,
+                          Qw=100.0, Rw=1e-4, lb=-2.0, ub=2.0, rbf_eps=1e-4)
+    h = ctypes.c_void_p()
+    rc = lib.kmpc_create(ctypes.byref(cfg), ctypes.byref(h))
+    assert rc != 0 and not h.value
+    assert b"no HIP device" in lib.kmpc_last_error(None)
+    from koopmpc import KoopmanMPC
+
+    with pytest.raises(RuntimeError):
+        KoopmanMPC(n=2, L=8, N=10, batch=4)
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(PKG):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M) or "koopman_oracle" in txt:
+                    bad.append(f)
+    assert not bad, bad
+
+
+def test_shard_range_partitions_the_batch():
+    from koopmpc import shard_range
+
+    for total in (1, 7, 4096, 262144, 65537):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            for (a, b), (c, d) in zip(spans, spans[1:]):
+                assert b == c
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {pkg!r})
+import torch, torch.distributed as dist
+from koopmpc import shard_range, max_over_ranks
+dist.init_process_group("gloo", init_method="tcp://127.0.0.1:{port}", rank=int(sys.argv[1]), world_size=2)
+rank = dist.get_rank()
+lo, hi = shard_range(4097, rank, 2)
+# every rank owns a disjoint contiguous slice: gather the spans and check the cover
+spans = [None, None]
+dist.all_gather_object(spans, (lo, hi))
+assert spans[0][0] == 0 and spans[0][1] == spans[1][0] and spans[1][1] == 4097, spans
+t = max_over_ranks(1.0 + rank)        # bench.py's timing rule: max over ranks
+assert t == 2.0, t
+# whole-job value = units of all ranks / max time
+units = torch.tensor([float(hi - lo)], dtype=torch.float64)
+dist.all_reduce(units)
+assert units.item() == 4097.0
+dist.barrier()
+dist.destroy_process_group()
+print("rank", rank, "ok")
+"""
+
+
+def test_two_rank_gloo_sharding_and_timing(tmp_path):
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER.format(pkg=PKG, port=port))
+    procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for r in range(2)]
+    outs = [p.communicate(timeout=240)[0].decode() for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o
+
+
+def test_synth_workload_is_deterministic():
+    from koopmpc.synth import initial_states, random_mlp_weights
+
+    a = random_mlp_weights(2, 100, 3, 20)
+    b = random_mlp_weights(2, 100, 3, 20)
+    assert all(np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) for x, y in zip(a, b))
+    assert [w.shape for w, _ in a] == [(100, 2), (100, 100), (100, 100), (20, 100)]
+    assert np.abs(a[1][0]).max() <= 0.1 + 1e-12
+    x = initial_states(4096)
+    assert x.shape == (2, 4096) and np.abs(x).max() <= 2.0

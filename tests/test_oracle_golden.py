@@ -104,6 +104,35 @@ def test_gain_form_equals_reference_form_up_to_its_own_rounding_floor(duff):
     assert worst < 2e-7
 
 
+@pytest.mark.parametrize("name,P0,lifted,bnd", [("duffing_loop.npz", 1e4, False, 2.0), ("vanderpol_loop.npz", 1e5, True, 6.0)])
+def test_reference_form_reassociation_floor(name, P0, lifted, bnd):
+    """How reproducible is the reference's OWN arithmetic?  Evaluate the same K_A / inv_K_G recursion with
+    the rank-one term associated as (Pz)(Pz)'/d instead of (P z z' P)/d (duffing.py:931-932; identical in
+    exact arithmetic): [A B] moves by ~5e-8 (inv_K_G0 = 1e4 I) / ~4e-5 (1e5 I) relative and the exact QP
+    minimiser by ~1e-6 / ~1e-3 (printed).  No implementation other than a bit-identical one can be closer to the
+    reference than this; the HIP path (gain form) is checked against these floors."""
+    g = _load(name)
+    st = ko.RlsStateRef(8, 1, 2, P0, P0)
+    KA, P = np.zeros((8, 9)), P0 * np.eye(9)
+    dK, dU = 0.0, 0.0
+    for k in range(len(g["loop_i"]) - 1):
+        A, B, Cm = ko.rls_update_reference(st, g["loop_xlift"][k], g["loop_u_loc"][k], g["loop_ylift"][k], g["loop_x_loc"][k])
+        z = np.concatenate([g["loop_xlift"][k].ravel(), g["loop_u_loc"][k].ravel()])
+        KA = KA + np.outer(g["loop_ylift"][k].ravel(), z)
+        Pz = P @ z
+        P = P - np.outer(Pz, Pz) / (1.0 + z @ Pz)
+        K2 = KA @ P
+        dK = max(dK, np.abs(K2 - st.K).max() / np.abs(st.K).max())
+        psi, r = g["loop_ylift"][k], g["loop_r"][k + 1]
+        Co = None if lifted else g["loop_C_prev"][k]
+        _, _, H, f, _ = ko.condense(A, B, Co, psi, r, 10)
+        _, _, H2, f2, _ = ko.condense(K2[:, :8], K2[:, 8:], Co, psi, r, 10)
+        dU = max(dU, np.abs(ko.qp_exact(H, f, -bnd, bnd)[0] - ko.qp_exact(H2, f2, -bnd, bnd)[0]).max())
+    print("%s: re-association moves K by %.1e (rel), U* by %.1e" % (name, dK, dU))
+    assert 1e-9 < dK < 1e-9 * P0   # measured 5.0e-8 (1e4) / 4.2e-5 (1e5)
+    assert dU < 1e-7 * P0
+
+
 # ------------------------------------------------------------------ cost / condensed QP
 def _model(g, k):
     return g["loop_Ap"][k], g["loop_Bp"][k], g["loop_Cp"][k], g["loop_xlift"][k], g["loop_r"][k]
