@@ -24,7 +24,7 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int vec_elems(int n, int L, int q, int N) {
   const int p = L + 1;
   const int setA = 2 * p + 6 * L + n + 2 * N * q;  // sz sPz | sy sE sV(2) sW(2) | sx | sG sEr
-  const int setB = 8 * N;                          // qx qxa qg qp qHx qHxa qrhs flags
+  const int setB = 4 * N;                          // qx qxa qg qHx
   return imax(setA, setB) + N /*sf*/ + 16 /*reduction scratch*/;
 }
 
@@ -57,10 +57,33 @@ template <> struct Tol<float> {
 template <typename T> __device__ __forceinline__ T tabs(T v) { return v < T(0) ? -v : v; }
 template <typename T> __device__ __forceinline__ T tclip(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// ---- wave-wide sum on DPP (no LDS crossbar): Hillis-Steele prefix inside each 16-lane row with
+// row_shr 1/2/4/8 (bound_ctrl zero-fills), then the four row totals are read from lanes 15/31/47/63.
+__device__ __forceinline__ int dpp_shr(int v, int ctrl) {
+  switch (ctrl) {
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+  }
+}
+__device__ __forceinline__ double dpp_shr(double v, int ctrl) {
+  return __hiloint2double(dpp_shr(__double2hiint(v), ctrl), dpp_shr(__double2loint(v), ctrl));
+}
+__device__ __forceinline__ float dpp_shr(float v, int ctrl) { return __int_as_float(dpp_shr(__float_as_int(v), ctrl)); }
+__device__ __forceinline__ double lane_bcast(double v, int lane) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
+                          __builtin_amdgcn_readlane(__double2loint(v), lane));
+}
+__device__ __forceinline__ float lane_bcast(float v, int lane) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
 template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  v += dpp_shr(v, 1);
+  v += dpp_shr(v, 2);
+  v += dpp_shr(v, 4);
+  v += dpp_shr(v, 8);
+  return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
 }
 
 // sum over the whole block; every thread gets the result.  `red` holds >= 8 elements.
@@ -77,16 +100,251 @@ template <typename T, int TPB> __device__ __forceinline__ T block_sum(T v, T* re
   return s;
 }
 
+// two sums at once (their shuffle chains interleave); results returned in place
+template <typename T, int TPB> __device__ __forceinline__ void block_sum2(T& v0, T& v1, T* red) {
+  v0 += dpp_shr(v0, 1); v1 += dpp_shr(v1, 1);
+  v0 += dpp_shr(v0, 2); v1 += dpp_shr(v1, 2);
+  v0 += dpp_shr(v0, 4); v1 += dpp_shr(v1, 4);
+  v0 += dpp_shr(v0, 8); v1 += dpp_shr(v1, 8);
+  v0 = (lane_bcast(v0, 15) + lane_bcast(v0, 31)) + (lane_bcast(v0, 47) + lane_bcast(v0, 63));
+  v1 = (lane_bcast(v1, 15) + lane_bcast(v1, 31)) + (lane_bcast(v1, 47) + lane_bcast(v1, 63));
+  if (TPB == 64) return;
+  const int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) { red[w] = v0; red[4 + w] = v1; }
+  __syncthreads();
+  T s0 = T(0), s1 = T(0);
+#pragma unroll
+  for (int i = 0; i < TPB / 64; ++i) { s0 += red[i]; s1 += red[4 + i]; }
+  v0 = s0; v1 = s1;
+}
+
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
-template <typename T, int TPB>
+
+// ---------------------------------------------------------------------------------------
+// Register-tableau box QP for compile-time N <= 32, one wave per trajectory.
+//
+// The 64 lanes form an 8 x 8 grid (ti = lane>>3, tj = lane&7).  Lane (ti, tj) keeps the blocks
+// Tm[r][c] = T(ti+8r, tj+8c) and Hm[r][c] = H(ti+8r, tj+8c) of the swept tableau and of H in
+// REGISTERS for the whole solve; variable i is owned by lane (i&7, i>>3).  A sweep on variable k
+// needs column k for the lane's rows and row k for its columns: two register fetches across
+// lanes (ds_bpermute, no LDS storage, no barrier), then RM*RM fused multiply-adds
+// T_ij -= T_ik T_kj / d, with T_kj <- s T_kj / d, T_ik <- s T_ik / d, T_kk <- -1/d on the lanes that hold
+// row / column k (s = +1 sweep in, -1 sweep out).
+// Mat-vecs (Newton direction with T, line-search products with H) are partial sums over the
+// lane's columns followed by an 8-lane DPP all-reduce.
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ int dpp_q(int v, int sel) {
+  switch (sel) {
+    case 0: return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
+    default: return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); // row_half_mirror
+  }
+}
+__device__ __forceinline__ double dpp_q(double v, int sel) {
+  return __hiloint2double(dpp_q(__double2hiint(v), sel), dpp_q(__double2loint(v), sel));
+}
+__device__ __forceinline__ float dpp_q(float v, int sel) { return __int_as_float(dpp_q(__float_as_int(v), sel)); }
+template <typename T> __device__ __forceinline__ T allreduce8(T v) {
+  v += dpp_q(v, 0);
+  v += dpp_q(v, 1);
+  v += dpp_q(v, 2);
+  return v;
+}
+
+template <typename T, int N_, int KR>
+__device__ __forceinline__ void sweep_regs(T (&Tm)[(N_ + 7) / 8][(N_ + 7) / 8], int kt, bool rev, T d, int ti, int tj) {
+  constexpr int RM = (N_ + 7) / 8;
+  const T dinv = T(1) / d;
+  const T sd = rev ? -dinv : dinv;
+  const bool rowk = (ti == kt), colk = (tj == kt);  // this lane holds row k / column k in block KR
+  T ct[RM], rt[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) ct[r] = __shfl(Tm[r][KR], ti * 8 + kt, 64);  // T(ti+8r, k)
+#pragma unroll
+  for (int c = 0; c < RM; ++c) rt[c] = __shfl(Tm[KR][c], kt * 8 + tj, 64);  // T(k, tj+8c)
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int c = 0; c < RM; ++c) {
+      T v = Tm[r][c] - ct[r] * (rt[c] * dinv);       // T_ij - T_ik T_kj / d
+      if (r == KR && rowk) v = rt[c] * sd;           // row k:    s T_kj / d
+      if (c == KR && colk) v = ct[r] * sd;           // column k: s T_ik / d
+      if (r == KR && c == KR && rowk && colk) v = -dinv;
+      Tm[r][c] = v;
+    }
+}
+
+template <typename T, int N_>
+__device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, int b, T* red) {
+  constexpr int RM = (N_ + 7) / 8;
+  const int tid = threadIdx.x, ti = tid >> 3, tj = tid & 7;
+  const int myvar = ti + 8 * tj;
+  const bool own = (tj < RM) && (myvar < N_);
+  const T lb = a.lb, ub = a.ub;
+  const T tol = (T)Tol<T>::kkt();
+  const T eact = (T)Tol<T>::act() * (ub - lb);
+  const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
+  const T c0 = tclip(T(0), lb, ub);
+
+  T Tm[RM][RM], Hm[RM][RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int c = 0; c < RM; ++c) {
+      const int i = ti + 8 * r, j = tj + 8 * c;
+      const T h = (i < N_ && j < N_) ? sH[i * N_ + j] : T(0);
+      Hm[r][c] = h;
+      Tm[r][c] = T(2) * h;
+    }
+  const T fi = own ? sf[myvar] : T(0);
+  // row sums of H and |H| for the owner's variable: partial over my columns, 8-lane all-reduce,
+  // the owner of variable ti + 8*tj picks block row r = tj
+  T rs = T(0), ra = T(0);
+  {
+    T ps[RM], pa[RM];
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      T s0 = T(0), s1 = T(0);
+#pragma unroll
+      for (int c = 0; c < RM; ++c) { s0 += Hm[r][c]; s1 += tabs(Hm[r][c]); }
+      ps[r] = allreduce8(s0);
+      pa[r] = allreduce8(s1);
+    }
+#pragma unroll
+    for (int r = 0; r < RM; ++r) if (tj == r) { rs = ps[r]; ra = pa[r]; }
+  }
+  const T gs = tabs(fi) + T(2) * ra * xmaxb;
+  T x = own ? c0 : T(0);
+  T hx = own ? c0 * rs : T(0);
+  T p0 = own ? x * (hx + fi) : T(0);
+  T J0 = wave_sum(p0);
+  const unsigned long long ownmask = __ballot(own);
+  unsigned long long Smask = 0ull;  // lane-space mask of the variables swept into T
+  int it = 0, status = 1, refresh = 0;
+
+  while (true) {
+    T g = T(0);
+    bool bad = false, inI = false;
+    if (own) {
+      g = T(2) * hx + fi;
+      const T res = tabs(x - tclip(x - g, lb, ub));
+      const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
+      bad = !((res <= tol * gs) || (res <= tol * xs));
+      inI = ((x <= lb + eact) && (g > T(0))) || ((x >= ub - eact) && (g < T(0)));
+    }
+    const unsigned long long Bmask = __ballot(bad);
+    const unsigned long long Imask = __ballot(inI);
+    if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
+    if (Bmask == 0ull) { status = 0; break; }
+    if (it >= a.max_iter || refresh > 4) { status = 1; break; }
+    unsigned long long Fmask = ~Imask & ownmask;
+
+    bool broke = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      unsigned long long diff = Smask ^ Fmask;
+      while (diff) {
+        const int kl = __ffsll((long long)diff) - 1;  // owner lane of the variable: (k&7)*8 + (k>>3)
+        diff &= diff - 1ull;
+        const int kt = kl >> 3, kr = kl & 7;
+        const bool rev = (Smask >> kl) & 1ull;
+        T d = T(0);
+#pragma unroll
+        for (int r = 0; r < RM; ++r) if (kr == r) d = lane_bcast(Tm[r][r], kt * 9);
+        if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
+          broke = true;
+          if (pass == 1) Fmask &= ~(1ull << kl);
+          continue;
+        }
+        switch (kr) {
+          case 0: sweep_regs<T, N_, 0>(Tm, kt, rev, d, ti, tj); break;
+          case 1: if constexpr (RM > 1) sweep_regs<T, N_, 1>(Tm, kt, rev, d, ti, tj); break;
+          case 2: if constexpr (RM > 2) sweep_regs<T, N_, 2>(Tm, kt, rev, d, ti, tj); break;
+          default: if constexpr (RM > 3) sweep_regs<T, N_, 3>(Tm, kt, rev, d, ti, tj); break;
+        }
+        Smask ^= (1ull << kl);
+      }
+      if (!broke || pass == 1) break;
+      ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hm[r][c];
+      Smask = 0ull;
+    }
+    Fmask = Smask;
+
+    // Newton direction on F: p_i = sum_{j in F} T_ij g_j ; straight to the bound on I
+    const bool isF = own && ((Fmask >> tid) & 1ull);
+    const T gm = isF ? g : T(0);
+    T pdir = T(0);
+    {
+      T gc[RM];
+#pragma unroll
+      for (int c = 0; c < RM; ++c) gc[c] = __shfl(gm, tj * 8 + c, 64);  // owner of variable tj + 8c
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        T s0 = T(0);
+#pragma unroll
+        for (int c = 0; c < RM; ++c) s0 += Tm[r][c] * gc[c];
+        s0 = allreduce8(s0);
+        if (tj == r) pdir = s0;
+      }
+    }
+    if (!isF) pdir = own ? ((g > T(0) ? lb : (g < T(0) ? ub : x)) - x) : T(0);
+
+    // projected Armijo search on the true cost
+    T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
+    while (true) {
+      xa = own ? tclip(x + alpha * pdir, lb, ub) : T(0);
+      T xc[RM];
+#pragma unroll
+      for (int c = 0; c < RM; ++c) xc[c] = __shfl(xa, tj * 8 + c, 64);
+#pragma unroll
+      for (int r = 0; r < RM; ++r) {
+        T s0 = T(0);
+#pragma unroll
+        for (int c = 0; c < RM; ++c) s0 += Hm[r][c] * xc[c];
+        s0 = allreduce8(s0);
+        if (tj == r) hxa = s0;
+      }
+      T pJa = own ? xa * (hxa + fi) : T(0);
+      T pdec = own ? (isF ? alpha * (-g * pdir) : g * (x - xa)) : T(0);
+      block_sum2<T, 64>(pJa, pdec, red);
+      Ja = pJa;
+      const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
+      if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
+      alpha *= T(0.25);
+    }
+    x = xa;
+    hx = hxa;
+    J0 = Ja;
+    ++it;
+  }
+
+  const int B = a.B;
+  if (own) {
+    if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
+  }
+  if (tid == 0) {  // lane 0 owns variable 0
+    if (a.U0) a.U0[b] = x;
+    if (a.u_store) a.u_store[b] = x;
+    if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
+    if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+  }
+}
+
+// L_, N_, Q_ != 0: dimensions fixed at compile time (every inner loop unrolls, index math folds);
+// 0: taken from the arguments at run time (generic fallback, same source).
+template <typename T, int TPB, int L_, int N_, int Q_>
 __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   T* const sm = reinterpret_cast<T*>(smem_raw);
   const int tid = threadIdx.x;
   const int b = blockIdx.x;
-  const int n = a.n, L = a.L, p = a.L + 1, q = a.q, N = a.N, B = a.B;
+  const int n = a.n, L = L_ ? L_ : a.L, p = L + 1, q = Q_ ? Q_ : a.q, N = N_ ? N_ : a.N, B = a.B;
 
   T* const sX = sm;            // P / bar_Q / H
   T* const sY = sX + a.r1;     // K, C / elimination matrix
@@ -95,9 +353,9 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   T* const sH = sX;
   T* const sM = sY;
   T* const vec = sY + a.r2;
-  T* const sf = vec;           // N   (lives condense -> QP)
-  T* const red = sf + N;       // 16
-  T* const va = red + 16;      // aliased vector sets
+  T* const red = vec;          // 16  reduction scratch (+ the 64-bit set mask at red[8])
+  T* const sf = red + 16;      // N   (lives condense -> QP)
+  T* const va = sf + N;        // aliased vector sets
   // set A (RLS + condense)
   T* const sz = va;            // p
   T* const sPz = sz + p;       // p
@@ -112,11 +370,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   T* const qx = va;
   T* const qxa = qx + N;
   T* const qg = qxa + N;
-  T* const qp = qg + N;
-  T* const qHx = qp + N;
-  T* const qHxa = qHx + N;
-  T* const qrhs = qHxa + N;
-  int* const flg = reinterpret_cast<int*>(qrhs + N);  // N ints
+  T* const qHx = qg + N;
 
 
   // =====================================================================================
@@ -142,6 +396,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     // Pz (P symmetric: column walk is conflict-free in LDS)
     for (int i = tid; i < p; i += TPB) {
       T acc = T(0);
+#pragma unroll
       for (int j = 0; j < p; ++j) acc += sX[j * p + i] * sz[j];
       sPz[i] = acc;
     }
@@ -161,6 +416,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     // innovation  y - K z
     for (int r = tid; r < L; r += TPB) {
       T acc = sy[r];
+#pragma unroll
       for (int j = 0; j < p; ++j) acc -= sK[r * p + j] * sz[j];
       sE[r] = acc;
     }
@@ -187,6 +443,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       __syncthreads();
       for (int i = tid; i < L; i += TPB) {
         T acc = T(0);
+#pragma unroll
         for (int j = 0; j < L; ++j) acc += sX[j * L + i] * sz[j];
         sPz[i] = acc;
       }
@@ -234,76 +491,137 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       sV[i] = sK[i * p + L];  // v_0 = B
       sW[i] = sy[i];          // w_0 = psi(x_k)
     }
+    for (int e = tid; e < q * N; e += TPB) {  // sEr[k][r] starts as -r[r][k]
+      const int k = e / q, r = e - k * q;
+      sEr[e] = -ref[r * N + k];
+    }
     __syncthreads();
     // v_{j+1} = A v_j, w_{j+1} = A w_j;  g_j = Co v_j;  e_j = Co w_j - r_{j-1}
-    int cur = 0;
-    const int ntask = 2 * L + 2 * q;
-    for (int j = 0; j <= N; ++j) {
-      const T* v = sV + cur * L;
-      const T* w = sW + cur * L;
-      T* vn = sV + (cur ^ 1) * L;
-      T* wn = sW + (cur ^ 1) * L;
-      for (int t = tid; t < ntask; t += TPB) {
-        if (t < L) {
-          if (j < N) {
-            T acc = T(0);
-            for (int l = 0; l < L; ++l) acc += sK[t * p + l] * v[l];
-            vn[t] = acc;
+    if constexpr (L_ > 0 && TPB == 64 && (L_ + Q_ <= 32)) {
+      // Static path: lanes 0-31 run the v-chain, lanes 32-63 the w-chain.  Lane t of a half keeps row t
+      // of the stacked matrix [A; Co] in REGISTERS for the whole recursion; per step it only reads
+      // the current vector (broadcast LDS reads) -- the matrix is never re-read from LDS.
+      const int half = tid >> 5, t = tid & 31;
+      const int nco = cx ? q : 0;
+      const bool isA = t < L, isC = (t >= L) && (t < L + nco);
+      T row[L_];
+#pragma unroll
+      for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(t - L) * L + l] : T(0));
+      if (!cx && half == 0 && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
+      int cur = 0;
+      for (int j = 0; j <= N; ++j) {
+        const T* vec = (half ? sW : sV) + cur * L;
+        T acc0 = T(0), acc1 = T(0);
+#pragma unroll
+        for (int l = 0; l + 1 < L_; l += 2) {
+          acc0 += row[l] * vec[l];
+          acc1 += row[l + 1] * vec[l + 1];
+        }
+        if (L_ & 1) acc0 += row[L_ - 1] * vec[L_ - 1];
+        const T acc = acc0 + acc1;
+        if (half == 0) {
+          if (isA && j < N) {
+            sV[(cur ^ 1) * L + t] = acc;                      // v_{j+1}
+            if (!cx && j + 1 < N) sG[(j + 1) * q + t] = acc;  // g_{j+1} = v_{j+1}
           }
-        } else if (t < 2 * L) {
-          if (j < N) {
-            const int r = t - L;
-            T acc = T(0);
-            for (int l = 0; l < L; ++l) acc += sK[r * p + l] * w[l];
-            wn[r] = acc;
-          }
-        } else if (t < 2 * L + q) {
-          if (j < N) {
-            const int r = t - 2 * L;
-            T g;
-            if (cx) {
-              g = T(0);
-              for (int l = 0; l < L; ++l) g += sC[r * L + l] * v[l];
-            } else {
-              g = v[r];
-            }
-            sG[j * q + r] = g;
-          }
+          if (isC && j < N) sG[j * q + (t - L)] = acc;        // g_j = Co v_j
         } else {
-          if (j >= 1) {
-            const int r = t - 2 * L - q;
-            T y;
-            if (cx) {
-              y = T(0);
-              for (int l = 0; l < L; ++l) y += sC[r * L + l] * w[l];
-            } else {
-              y = w[r];
+          if (isA && j < N) {
+            sW[(cur ^ 1) * L + t] = acc;                      // w_{j+1}
+            if (!cx) sEr[j * q + t] += acc;                   // e_{j+1} = w_{j+1} - r_j
+          }
+          if (isC && j >= 1) sEr[(j - 1) * q + (t - L)] += acc;  // e_j = Co w_j - r_{j-1}
+        }
+        __syncthreads();
+        cur ^= 1;
+      }
+    } else {
+    int cur = 0;
+      const int ntask = 2 * L + 2 * q;
+      for (int j = 0; j <= N; ++j) {
+        const T* v = sV + cur * L;
+        const T* w = sW + cur * L;
+        T* vn = sV + (cur ^ 1) * L;
+        T* wn = sW + (cur ^ 1) * L;
+        for (int t = tid; t < ntask; t += TPB) {
+          if (t < L) {
+            if (j < N) {
+              T acc = T(0);
+#pragma unroll
+              for (int l = 0; l < L; ++l) acc += sK[t * p + l] * v[l];
+              vn[t] = acc;
             }
-            sEr[(j - 1) * q + r] = y - ref[r * N + (j - 1)];
+          } else if (t < 2 * L) {
+            if (j < N) {
+              const int r = t - L;
+              T acc = T(0);
+#pragma unroll
+              for (int l = 0; l < L; ++l) acc += sK[r * p + l] * w[l];
+              wn[r] = acc;
+            }
+          } else if (t < 2 * L + q) {
+            if (j < N) {
+              const int r = t - 2 * L;
+              T g;
+              if (cx) {
+                g = T(0);
+#pragma unroll
+                for (int l = 0; l < L; ++l) g += sC[r * L + l] * v[l];
+              } else {
+                g = v[r];
+              }
+              sG[j * q + r] = g;
+            }
+          } else {
+            if (j >= 1) {
+              const int r = t - 2 * L - q;
+              T y;
+              if (cx) {
+                y = T(0);
+#pragma unroll
+                for (int l = 0; l < L; ++l) y += sC[r * L + l] * w[l];
+              } else {
+                y = w[r];
+              }
+              sEr[(j - 1) * q + r] += y;
+            }
           }
         }
+        __syncthreads();
+        cur ^= 1;
       }
-      __syncthreads();
-      cur ^= 1;
     }
     // H[a][b] = Qw * S(b-a, N-1-b) (+Rw on the diagonal),  S(d,t) = sum_{s<=t} g_{s+d}.g_s
     for (int d = tid; d < N; d += TPB) {
       T acc = T(0);
-      for (int t = 0; t + d < N; ++t) {
-        T s = T(0);
-        for (int r = 0; r < q; ++r) s += sG[(t + d) * q + r] * sG[t * q + r];
-        acc += s;
-        const int bb = N - 1 - t, aa = bb - d;
-        const T hv = a.Qw * acc + (d == 0 ? a.Rw : T(0));
-        sH[aa * N + bb] = hv;
-        sH[bb * N + aa] = hv;
+#pragma unroll
+      for (int t = 0; t < N; ++t) {
+        if (t + d < N) {
+          T s = T(0);
+#pragma unroll
+          for (int r = 0; r < q; ++r) s += sG[(t + d) * q + r] * sG[t * q + r];
+          acc += s;
+          const int bb = N - 1 - t, aa = bb - d;
+          const T hv = a.Qw * acc + (d == 0 ? a.Rw : T(0));
+          sH[aa * N + bb] = hv;
+          sH[bb * N + aa] = hv;
+        }
       }
     }
-    for (int aa = tid; aa < N; aa += TPB) {
-      T acc = T(0);
-      for (int t = 0; t + aa < N; ++t)
-        for (int r = 0; r < q; ++r) acc += sG[t * q + r] * sEr[(t + aa) * q + r];
-      sf[aa] = T(2) * a.Qw * acc;
+    // f on lanes 32.. so that it overlaps the H diagonals of lanes 0..N-1 when the wave has room
+    {
+      const int f0 = (TPB == 64 && N <= 32) ? 32 : 0;
+      for (int aa = tid - f0; aa < N; aa += TPB) {
+        if (aa < 0) continue;
+        T acc = T(0);
+#pragma unroll
+        for (int t = 0; t < N; ++t)
+          if (t + aa < N) {
+#pragma unroll
+            for (int r = 0; r < q; ++r) acc += sG[t * q + r] * sEr[(t + aa) * q + r];
+          }
+        sf[aa] = T(2) * a.Qw * acc;
+      }
     }
     __syncthreads();
     if (a.H_out) {
@@ -323,125 +641,204 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   }
 
   // =====================================================================================
-  // phase 3: box QP  min u'Hu + f'u, lb <= u <= ub  -- projected Newton (Bertsekas 1982):
-  // Newton step on the free set via a masked symmetric elimination, projected Armijo arc.
-  // Terminates on the componentwise KKT test; the answer is the exact solve on the final
-  // active set (cold start at clip(0) as the reference, duffing.py:634-635).
+  // phase 3: box QP  min u'Hu + f'u, lb <= u <= ub  -- projected Newton (Bertsekas 1982) on a
+  // SWEPT tableau: T = sweep_F(2H) is kept in LDS, T_FF = -(2 H_FF)^-1, so the Newton step on the
+  // free set F is one masked mat-vec and a change of the active set costs one O(N^2) symmetric
+  // sweep per variable that enters or leaves F (no refactorisation).  Projected Armijo arc on the
+  // true cost; termination on the componentwise KKT test evaluated with H itself, so rounding
+  // in T only costs an extra (cheap) iteration.  Cold start at clip(0) as the reference
+  // (duffing.py:634-635); the minimiser is unique, so the start only affects the work.
   // =====================================================================================
-  if (a.phases & PH_QP) {
+  if constexpr (N_ > 0 && N_ <= 32 && TPB == 64) {
+    if (a.phases & PH_QP) qp_regs<T, N_>(sH, sf, a, b, red);
+  } else if (a.phases & PH_QP) {
     const T lb = a.lb, ub = a.ub;
     const T tol = (T)Tol<T>::kkt();
     const T eact = (T)Tol<T>::act() * (ub - lb);
-    for (int i = tid; i < N; i += TPB) {
-      qx[i] = tclip(T(0), lb, ub);
-    }
-    __syncthreads();
-    for (int i = tid; i < N; i += TPB) {
-      T acc = T(0);
-      for (int j = 0; j < N; ++j) acc += sH[j * N + i] * qx[j];
-      qHx[i] = acc;
-    }
-    __syncthreads();
-
-    int it = 0;
-    int status = 1;
+    const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
+    const T c0 = tclip(T(0), lb, ub);
     const int ti = (TPB == 64) ? (tid >> 3) : (tid >> 4);
     const int tj = (TPB == 64) ? (tid & 7) : (tid & 15);
-    const int tstep = (TPB == 64) ? 8 : 16;
+    const int ts = (TPB == 64) ? 8 : 16;
+    const bool mine = tid < N;  // thread i < N owns variable i (N <= 64 <= TPB)
+    const unsigned long long allmask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+    unsigned long long* const smask = reinterpret_cast<unsigned long long*>(red + 8);
+
+    // static path: thread i keeps column i of H in registers for the line-search mat-vecs
+    constexpr int NH = N_ > 0 ? N_ : 1;
+    T hcol[NH];
+    if constexpr (N_ > 0) {
+#pragma unroll
+      for (int j = 0; j < N_; ++j) hcol[j] = mine ? sH[j * N + tid] : T(0);
+    }
+    T gs = T(1);
+    if (mine) {
+      T rs = T(0), ra = T(0);
+#pragma unroll
+      for (int j = 0; j < N; ++j) {
+        T h;
+        if constexpr (N_ > 0) h = hcol[j]; else h = sH[j * N + tid];
+        rs += h;
+        ra += tabs(h);
+      }
+      gs = tabs(sf[tid]) + T(2) * ra * xmaxb;  // magnitude of the terms of the gradient
+      qx[tid] = c0;
+      qHx[tid] = c0 * rs;
+    }
+    for (int i = ti; i < N; i += ts)
+      for (int j = tj; j < N; j += ts) sM[i * N + j] = T(2) * sH[i * N + j];
+    __syncthreads();
+
+    unsigned long long Smask = 0ull;  // variables currently swept into T
+    int it = 0, status = 1, refresh = 0;
+    constexpr int TS = (TPB == 64) ? 8 : 16;   // 2-D thread tile of the sweeps
+    constexpr int RMAX = N_ > 0 ? (N_ + TS - 1) / TS : 64 / TS;  // rows / columns per thread
+
+    // cost at the start  J = x'(Hx + f)
+    T x = mine ? qx[tid] : T(0);
+    T hx = mine ? qHx[tid] : T(0);
+    T J0 = block_sum<T, TPB>(mine ? x * (hx + sf[tid]) : T(0), red);
 
     while (true) {
-      // gradient, cost, componentwise KKT residual
-      T pJ = T(0), pbad = T(0);
-      for (int i = tid; i < N; i += TPB) {
-        const T x = qx[i];
-        const T g = T(2) * qHx[i] + sf[i];
-        qg[i] = g;
-        pJ += x * (qHx[i] + sf[i]);
-        T gs = tabs(sf[i]);
-        for (int j = 0; j < N; ++j) gs += T(2) * tabs(sH[j * N + i]) * tabs(qx[j]);
+      // ---- gradient, KKT residual, bound set (all per-variable, no reduction needed)
+      T g = T(0);
+      bool bad = false, inI = false;
+      if (mine) {
+        g = T(2) * hx + sf[tid];
         const T res = tabs(x - tclip(x - g, lb, ub));
         const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
-        const bool ok = (res <= tol * gs) || (res <= tol * xs);
-        pbad += ok ? T(0) : T(1);
+        bad = !((res <= tol * gs) || (res <= tol * xs));
+        inI = ((x <= lb + eact) && (g > T(0))) || ((x >= ub - eact) && (g < T(0)));
       }
-      const T J0 = block_sum<T, TPB>(pJ, red);
-      const T nbad = block_sum<T, TPB>(pbad, red);
+      unsigned long long Bmask = __ballot(bad);
+      unsigned long long Imask = __ballot(inI);  // wave 0 holds every variable (N <= 64)
+      if (TPB > 64) {
+        __syncthreads();
+        if (tid == 0) { smask[0] = Imask; smask[1] = Bmask; }
+        __syncthreads();
+        Imask = smask[0];
+        Bmask = smask[1];
+      }
       if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
-      if (nbad == T(0)) { status = 0; break; }
-      if (it >= a.max_iter) { status = 1; break; }
+      if (Bmask == 0ull) { status = 0; break; }
+      if (it >= a.max_iter || refresh > 4) { status = 1; break; }
+      unsigned long long Fmask = ~Imask & allmask;
 
-      // bound set I and right-hand side
-      for (int i = tid; i < N; i += TPB) {
-        const T x = qx[i], g = qg[i];
-        const int inI = ((x <= lb + eact) && (g > T(0))) || ((x >= ub - eact) && (g < T(0)));
-        flg[i] = inI;
-        qrhs[i] = inI ? T(0) : -g;
-      }
-      __syncthreads();
-      // masked matrix (upper triangle incl. diagonal): 2H on free x free, identity elsewhere
-      for (int i = ti; i < N; i += tstep)
-        for (int j = tj; j < N; j += tstep)
-          if (j >= i) {
-            const bool fr = !flg[i] && !flg[j];
-            sM[i * N + j] = fr ? T(2) * sH[i * N + j] : (i == j ? T(1) : T(0));
+      // ---- bring T to the new free set: one symmetric sweep per changed variable
+      bool broke = false;
+      for (int pass = 0; pass < 2; ++pass) {
+        unsigned long long diff = Smask ^ Fmask;
+        while (diff) {
+          const int k = __ffsll((long long)diff) - 1;
+          diff &= diff - 1ull;
+          const bool rev = (Smask >> k) & 1ull;
+          const T piv = sM[k * N + k];
+          if (!((rev ? -piv : piv) > T(0))) {  // numerical breakdown of the tableau
+            broke = true;
+            if (pass == 1) Fmask &= ~(1ull << k);  // clean rebuild: keep this variable fixed this iteration
+            continue;
           }
-      __syncthreads();
-      // symmetric Gaussian elimination without pivoting (SPD), carrying the rhs
-      for (int k = 0; k < N - 1; ++k) {
-        const T inv = T(1) / sM[k * N + k];
-        for (int i = k + 1 + ti; i < N; i += tstep) {
-          const T mi = sM[k * N + i] * inv;
-          for (int j = k + 1 + tj; j < N; j += tstep)
-            if (j >= i) sM[i * N + j] -= mi * sM[k * N + j];
+          const T dinv = T(1) / piv;
+          T rj[RMAX];  // this thread's columns of pivot row k
+#pragma unroll
+          for (int c = 0; c < RMAX; ++c) {
+            const int j = tj + c * TS;
+            rj[c] = (j < N && j != k) ? sM[k * N + j] : T(0);
+          }
+#pragma unroll
+          for (int r = 0; r < RMAX; ++r) {
+            const int i = ti + r * TS;
+            if (i < N && i != k) {
+              const T ci = sM[k * N + i] * dinv;
+#pragma unroll
+              for (int c = 0; c < RMAX; ++c) {
+                const int j = tj + c * TS;
+                if (j < N && j != k) sM[i * N + j] -= ci * rj[c];
+              }
+            }
+          }
+          __syncthreads();
+          if (mine) {
+            if (tid == k) {
+              sM[k * N + k] = -dinv;
+            } else {
+              const T v = sM[k * N + tid] * (rev ? -dinv : dinv);
+              sM[k * N + tid] = v;
+              sM[tid * N + k] = v;
+            }
+          }
+          __syncthreads();
+          Smask ^= (1ull << k);
         }
-        const T rk = qrhs[k];
-        for (int i = k + 1 + tid; i < N; i += TPB) qrhs[i] -= sM[k * N + i] * inv * rk;
+        if (!broke || pass == 1) break;
+        // rebuild T = 2H and sweep the free set in from scratch
+        ++refresh;
+        for (int i = ti; i < N; i += TS)
+          for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
         __syncthreads();
+        Smask = 0ull;
       }
-      // back substitution  U p = rhs
-      for (int k = N - 1; k >= 0; --k) {
-        const T pk = qrhs[k] / sM[k * N + k];
-        for (int i = tid; i < k; i += TPB) qrhs[i] -= sM[i * N + k] * pk;
-        if (tid == 0) qp[k] = pk;
-        __syncthreads();
-      }
-      // bound-set variables go to the bound the gradient pushes them to
-      for (int i = tid; i < N; i += TPB)
-        if (flg[i]) qp[i] = (qg[i] > T(0) ? lb : ub) - qx[i];
-      __syncthreads();
+      Fmask = Smask;  // what is actually swept (a variable whose pivot broke down stays fixed)
 
-      // projected Armijo search
-      T alpha = T(1);
+      // ---- direction: Newton on F (T_FF = -(2H_FF)^-1) as a mat-vec with the masked gradient,
+      //      straight to the bound on I
+      const bool isF = mine && ((Fmask >> tid) & 1ull);
+      if (mine) qg[tid] = isF ? g : T(0);
+      __syncthreads();
+      T pdir = T(0);
+      if (mine) {
+        if (isF) {
+#pragma unroll
+          for (int j = 0; j < N; ++j) pdir += sM[j * N + tid] * qg[j];
+        } else {
+          pdir = (g > T(0) ? lb : (g < T(0) ? ub : x)) - x;
+        }
+      }
+
+      // ---- projected Armijo search on the true cost (one fused two-value reduction per trial)
+      T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
       while (true) {
-        for (int i = tid; i < N; i += TPB) qxa[i] = tclip(qx[i] + alpha * qp[i], lb, ub);
+        if (mine) {
+          xa = tclip(x + alpha * pdir, lb, ub);
+          qxa[tid] = xa;
+        }
         __syncthreads();
         T pJa = T(0), pdec = T(0);
-        for (int i = tid; i < N; i += TPB) {
-          T acc = T(0);
-          for (int j = 0; j < N; ++j) acc += sH[j * N + i] * qxa[j];
-          qHxa[i] = acc;
-          const T xa = qxa[i];
-          pJa += xa * (acc + sf[i]);
-          pdec += flg[i] ? qg[i] * (qx[i] - xa) : alpha * (-qg[i] * qp[i]);
+        if (mine) {
+          hxa = T(0);
+          if constexpr (N_ > 0) {
+            T h1 = T(0);
+#pragma unroll
+            for (int j = 0; j + 1 < N_; j += 2) {
+              hxa += hcol[j] * qxa[j];
+              h1 += hcol[j + 1] * qxa[j + 1];
+            }
+            if (N_ & 1) hxa += hcol[N_ - 1] * qxa[N_ - 1];
+            hxa += h1;
+          } else {
+#pragma unroll
+            for (int j = 0; j < N; ++j) hxa += sH[j * N + tid] * qxa[j];
+          }
+          pJa = xa * (hxa + sf[tid]);
+          pdec = isF ? alpha * (-g * pdir) : g * (x - xa);
         }
-        const T Ja = block_sum<T, TPB>(pJa, red);
-        const T dec = block_sum<T, TPB>(pdec, red);
+        block_sum2<T, TPB>(pJa, pdec, red);
+        Ja = pJa;
         const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
-        if ((J0 - Ja >= T(1e-4) * dec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
+        if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
         alpha *= T(0.25);
         __syncthreads();
       }
-      __syncthreads();
-      for (int i = tid; i < N; i += TPB) {
-        qx[i] = qxa[i];
-        qHx[i] = qHxa[i];
-      }
-      __syncthreads();
+      x = xa;
+      hx = hxa;
+      J0 = Ja;
       ++it;
     }
+    if (mine) qx[tid] = x;
+    __syncthreads();
 
-    for (int i = tid; i < N; i += TPB) {
-      if (a.Useq) a.Useq[(size_t)i * B + b] = qx[i];
+    if (mine) {
+      if (a.Useq) a.Useq[(size_t)tid * B + b] = qx[tid];
     }
     if (tid == 0) {
       if (a.U0) a.U0[b] = qx[0];
@@ -455,25 +852,30 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
 // ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
-template <typename T, int TPB> static hipError_t launch_impl(const StepArgs<T>& a, hipStream_t s) {
+template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_impl(const StepArgs<T>& a, hipStream_t s) {
   StepArgs<T> k = a;
   const size_t lds = step_lds_bytes(a.n, a.L, a.q, a.N, sizeof(T), &k.r1, &k.r2);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, TPB>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, TPB, L_, N_, Q_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  hipLaunchKernelGGL((step_kernel<T, TPB>), dim3(a.B), dim3(TPB), lds, s, k);
+  hipLaunchKernelGGL((step_kernel<T, TPB, L_, N_, Q_>), dim3(a.B), dim3(TPB), lds, s, k);
   return hipGetLastError();
 }
 
 template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
-  if (threads == 256) return launch_impl<T, 256>(a, s);
-  return launch_impl<T, 64>(a, s);
+  if (threads == 256) return launch_impl<T, 256, 0, 0, 0>(a, s);
+  // compile-time specialisations: BASELINE cfg1/cfg2 (L=20, N=20, y = Cx) and the reference's own
+  // dimensions (L=8, N=10; y = Cx duffing.py, y = lifted state vanderpol.py)
+  if (a.L == 20 && a.N == 20 && a.q == 2) return launch_impl<T, 64, 20, 20, 2>(a, s);
+  if (a.L == 8 && a.N == 10 && a.q == 2) return launch_impl<T, 64, 8, 10, 2>(a, s);
+  if (a.L == 8 && a.N == 10 && a.q == 8) return launch_impl<T, 64, 8, 10, 8>(a, s);
+  return launch_impl<T, 64, 0, 0, 0>(a, s);
 }
 
 template hipError_t launch_step<float>(const StepArgs<float>&, int, hipStream_t);

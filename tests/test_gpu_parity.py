@@ -123,8 +123,9 @@ def test_rls_replay_of_reference_loop(torch_mod, KM, gfile, P0, Q0):
         A_, B_, C_ = A_.cpu().numpy(), B_.cpu().numpy(), C_.cpu().numpy()
         for b in range(B):
             Kb = np.concatenate([A_[b], B_[b]], axis=1)
-            assert np.abs(Kb - K).max() <= 1e-10 * np.abs(K).max(), k
-            assert np.abs(C_[b] - Cg).max() <= 1e-10 * max(1e-3, np.abs(Cg).max()), k
+            # same estimator, same form: only summation order differs (error scales with the init magnitude)
+            assert np.abs(Kb - K).max() <= 1e-13 * max(P0, Q0) * np.abs(K).max(), k
+            assert np.abs(C_[b] - Cg).max() <= 1e-13 * max(P0, Q0) * max(1e-3, np.abs(Cg).max()), k
             # against the reference's own numbers: inside its re-association floor (grows with P0)
             floorK = max(floorK, np.abs(Kb - g["loop_K_ext"][k]).max() / np.abs(K).max())
             floorC = max(floorC, np.abs(C_[b] - g["loop_C_prev"][k]).max() / max(1e-3, np.abs(Cg).max()))
