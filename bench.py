@@ -176,6 +176,15 @@ def main():
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         worst_status, x_ok = int(flag[0].item()), int(flag[1].item()) == 0
 
+    # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
+    # own-pattern calibration): collected offline with tools/one_phase.py, committed in profiles/
+    traffic, traffic_note = None, "not collected for this configuration"
+    tp = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    if os.path.exists(tp) and (L, N, B, args.dtype) == (20, 20, 4096, "f64"):
+        tj = json.load(open(tp))
+        traffic = tj["traffic_bytes_per_launch"]
+        traffic_note = "bytes per launch, rocprofv3 PMC passes recorded in profiles/r1_traffic.json (FETCH x %.3f own-pattern calibration + WRITE)" % tj["fetch_calibration"]
+
     if rank == 0:
         total = B * world
         out = {
@@ -209,7 +218,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_note": traffic_note,
                 "algorithmic_bytes_per_trajectory_step": bytes_per_traj,
                 "avg_kernel_ms": step_ms,
                 "avg_lift_kernel_ms": lift_ms,
