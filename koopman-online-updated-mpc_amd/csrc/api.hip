@@ -116,7 +116,7 @@ struct Impl : kmpc_handle {
       if (c.hidden < 1 || c.hidden > 128) FAIL(-2, "hidden must be in 1..128");
       Hp = c.hidden <= 112 ? 112 : 128;
       Lp = ((L + 15) / 16) * 16;
-      HIPCHK(hipMalloc(&dW1, sizeof(T) * Hp * n));
+      HIPCHK(hipMalloc(&dW1, sizeof(T) * Hp * 4));
       HIPCHK(hipMalloc(&db1, sizeof(T) * Hp));
       for (int k = 0; k < c.layers - 1; ++k) {
         HIPCHK(hipMalloc(&dWh[k], sizeof(T) * Hp * Hp));
@@ -157,7 +157,7 @@ struct Impl : kmpc_handle {
     if (rows != out_dim || cols != in_dim) FAIL(-3, "encoder layer shape does not match the configuration");
     int rc;
     if (layer == 0) {
-      if ((rc = upload_padded(dW1, W, rows, cols, Hp, n))) return rc;
+      if ((rc = upload_padded(dW1, W, rows, cols, Hp, 4))) return rc;
       if ((rc = upload_padded(db1, b, 1, rows, 1, Hp))) return rc;
     } else if (layer == nl - 1) {
       if ((rc = upload_padded(dWo, W, rows, cols, Lp, Hp))) return rc;

@@ -49,8 +49,8 @@ __global__ __launch_bounds__(LIFT_TPB, 1) void lift_mlp_kernel(const LiftArgs<T>
   const int Hp = 4 * KS;
   T* const sAct0 = sm;                 // KS*64  B-fragments of the current activations
   T* const sAct1 = sAct0 + KS * 64;    // KS*64
-  T* const sW1 = sAct1 + KS * 64;      // Hp*n
-  T* const sb1 = sW1 + Hp * a.n;       // Hp
+  T* const sW1 = sAct1 + KS * 64;      // Hp*4 (input columns zero-padded to 4)
+  T* const sb1 = sW1 + Hp * 4;         // Hp
   T* const sbh = sb1 + Hp;             // NHH*Hp
   T* const sbo = sbh + NHH * Hp;       // Lp
 
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(LIFT_TPB, 1) void lift_mlp_kernel(const LiftArgs<T>
   const int mtiles_o = a.Lp / 16;
 
   // ---- stage the small shared operands
-  for (int e = tid; e < Hp * n; e += LIFT_TPB) sW1[e] = a.W1[e];
+  for (int e = tid; e < Hp * 4; e += LIFT_TPB) sW1[e] = a.W1[e];
   for (int e = tid; e < Hp; e += LIFT_TPB) sb1[e] = a.b1[e];
   for (int k = 0; k < NHH; ++k)
     for (int e = tid; e < Hp; e += LIFT_TPB) sbh[k * Hp + e] = a.bh[k][e];
@@ -96,15 +96,16 @@ __global__ __launch_bounds__(LIFT_TPB, 1) void lift_mlp_kernel(const LiftArgs<T>
     const int b = bt * 16 + col;
     const bool live = b < B;
     // ---- layer 1 (K = n, VALU): every wave builds the full B-fragment set in registers
-    T xin[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) xin[i] = (i < n && live) ? a.X[(size_t)i * B + b] : T(0);
+    const T x0 = (live && n > 0) ? a.X[b] : T(0);
+    const T x1 = (live && n > 1) ? a.X[(size_t)B + b] : T(0);
+    const T x2 = (live && n > 2) ? a.X[(size_t)2 * B + b] : T(0);
+    const T x3 = (live && n > 3) ? a.X[(size_t)3 * B + b] : T(0);
     T act[KS];
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const int k = 4 * ks + kq;
-      T v = sb1[k];
-      for (int i = 0; i < n; ++i) v += sW1[k * n + i] * xin[i];
+      const T* wr = sW1 + 4 * k;  // zero-padded columns: no branch on n
+      const T v = sb1[k] + wr[0] * x0 + wr[1] * x1 + wr[2] * x2 + wr[3] * x3;
       act[ks] = v > T(0) ? v : T(0);
     }
     // ---- hidden -> hidden layers on MFMA
@@ -115,13 +116,17 @@ __global__ __launch_bounds__(LIFT_TPB, 1) void lift_mlp_kernel(const LiftArgs<T>
       for (int t = 0; t < MT; ++t) {
         const int tile = wave + LIFT_WAVES * t;
         if (tile < mtiles_h) {
-          acc_t acc = {T(0), T(0), T(0), T(0)};
+          // K split over four independent accumulator chains (the f64 MFMA's dependent latency is
+          // several times its issue interval)
+          acc_t ac[4];
 #pragma unroll
-          for (int ks = 0; ks < KS; ++ks) acc = Mma<T>::mma(wh[k][t][ks], act[ks], acc);
+          for (int c = 0; c < 4; ++c) ac[c] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) ac[ks & 3] = Mma<T>::mma(wh[k][t][ks], act[ks], ac[ks & 3]);
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * tile + Mma<T>::row(lane, r);  // hidden unit index
-            T v = acc[r] + sbh[k * Hp + row];
+            T v = ((ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r])) + sbh[k * Hp + row];
             v = v > T(0) ? v : T(0);
             // becomes element k' = row of the next layer's B operand: K-step row/4, lane (row%4)*16 + col
             sAct[(row >> 2) * 64 + ((row & 3) << 4) + col] = v;
@@ -134,13 +139,16 @@ __global__ __launch_bounds__(LIFT_TPB, 1) void lift_mlp_kernel(const LiftArgs<T>
     }
     // ---- output layer
     if (wave < mtiles_o) {
-      acc_t acc = {T(0), T(0), T(0), T(0)};
+      acc_t ac[4];
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks) acc = Mma<T>::mma(wo[ks], act[ks], acc);
+      for (int c = 0; c < 4; ++c) ac[c] = acc_t{T(0), T(0), T(0), T(0)};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) ac[ks & 3] = Mma<T>::mma(wo[ks], act[ks], ac[ks & 3]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = 16 * wave + Mma<T>::row(lane, r);
-        if (row < L && live) a.Psi[(size_t)row * a.ps_l + (size_t)b * a.ps_b] = acc[r] + sbo[row];
+        if (row < L && live)
+          a.Psi[(size_t)row * a.ps_l + (size_t)b * a.ps_b] = ((ac[0][r] + ac[1][r]) + (ac[2][r] + ac[3][r])) + sbo[row];
       }
     }
     // the next tile's first LDS write (sAct0) is ordered behind this tile's barriers: with
@@ -196,7 +204,7 @@ template <typename T> __global__ __launch_bounds__(256) void lift_rbf_kernel(con
 // ---------------------------------------------------------------------------------------
 template <typename T, int KS, int MT, int NHH> static hipError_t launch_mlp_impl(const LiftArgs<T>& a, hipStream_t s) {
   const int Hp = 4 * KS;
-  const size_t lds = (size_t)(2 * KS * 64 + Hp * a.n + Hp + NHH * Hp + a.Lp) * sizeof(T);
+  const size_t lds = (size_t)(2 * KS * 64 + Hp * 4 + Hp + NHH * Hp + a.Lp) * sizeof(T);
   const int ntiles = (a.B + 15) / 16;
   int grid = ntiles < 1024 ? ntiles : 1024;
   hipLaunchKernelGGL((lift_mlp_kernel<T, KS, MT, NHH>), dim3(grid), dim3(LIFT_TPB), lds, s, a);

@@ -511,14 +511,29 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       int cur = 0;
       for (int j = 0; j <= N; ++j) {
         const T* vec = (half ? sW : sV) + cur * L;
-        T acc0 = T(0), acc1 = T(0);
+        // independent products + a pairwise tree: a dependent f64 FMA costs ~40 cycles on gfx950
+        // (measured, tools/ubench/valu_f64.hip), so the reduction depth matters more than the op count
+        T pr[L_];
+        if constexpr ((L_ & 1) == 0) {
+          // 16-byte broadcast reads (ds_read_b128: half the LDS cycles of the ds_read2_b64 the compiler
+          // picks when it cannot prove the alignment); all LDS offsets are even in the static layout
+          typedef T T2 __attribute__((ext_vector_type(2)));
+          const T2* v2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(vec, 2 * sizeof(T)));
 #pragma unroll
-        for (int l = 0; l + 1 < L_; l += 2) {
-          acc0 += row[l] * vec[l];
-          acc1 += row[l + 1] * vec[l + 1];
+          for (int l = 0; l < L_ / 2; ++l) {
+            const T2 x2 = v2[l];
+            pr[2 * l] = row[2 * l] * x2.x;
+            pr[2 * l + 1] = row[2 * l + 1] * x2.y;
+          }
+        } else {
+#pragma unroll
+          for (int l = 0; l < L_; ++l) pr[l] = row[l] * vec[l];
         }
-        if (L_ & 1) acc0 += row[L_ - 1] * vec[L_ - 1];
-        const T acc = acc0 + acc1;
+#pragma unroll
+        for (int w2 = 1; w2 < L_; w2 *= 2)
+#pragma unroll
+          for (int l = 0; l + w2 < L_; l += 2 * w2) pr[l] += pr[l + w2];
+        const T acc = pr[0];
         if (half == 0) {
           if (isA && j < N) {
             sV[(cur ^ 1) * L + t] = acc;                      // v_{j+1}
