@@ -230,10 +230,13 @@ __device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs
     bool bad = false, inI = false;
     if (own) {
       g = T(2) * hx + fi;
-      const T res = tabs(x - tclip(x - g, lb, ub));
+      const bool atl = x <= lb + eact, atu = x >= ub - eact;
+      inI = (atl && (g > T(0))) || (atu && (g < T(0)));
+      // KKT violation in gradient units: |g| inside the box, the wrong-signed part of g on a bound
+      const T viol = inI ? T(0) : tabs(g);
+      const T res = tabs(x - tclip(x - g, lb, ub));  // what a projected gradient step would still move
       const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
-      bad = !((res <= tol * gs) || (res <= tol * xs));
-      inI = ((x <= lb + eact) && (g > T(0))) || ((x >= ub - eact) && (g < T(0)));
+      bad = !((viol <= tol * gs) || (res <= tol * xs));
     }
     const unsigned long long Bmask = __ballot(bad);
     const unsigned long long Imask = __ballot(inI);
@@ -720,10 +723,12 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       bool bad = false, inI = false;
       if (mine) {
         g = T(2) * hx + sf[tid];
+        const bool atl = x <= lb + eact, atu = x >= ub - eact;
+        inI = (atl && (g > T(0))) || (atu && (g < T(0)));
+        const T viol = inI ? T(0) : tabs(g);  // KKT violation in gradient units
         const T res = tabs(x - tclip(x - g, lb, ub));
         const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
-        bad = !((res <= tol * gs) || (res <= tol * xs));
-        inI = ((x <= lb + eact) && (g > T(0))) || ((x >= ub - eact) && (g < T(0)));
+        bad = !((viol <= tol * gs) || (res <= tol * xs));
       }
       unsigned long long Bmask = __ballot(bad);
       unsigned long long Imask = __ballot(inI);  // wave 0 holds every variable (N <= 64)
@@ -890,6 +895,10 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
   if (a.L == 20 && a.N == 20 && a.q == 2) return launch_impl<T, 64, 20, 20, 2>(a, s);
   if (a.L == 8 && a.N == 10 && a.q == 2) return launch_impl<T, 64, 8, 10, 2>(a, s);
   if (a.L == 8 && a.N == 10 && a.q == 8) return launch_impl<T, 64, 8, 10, 8>(a, s);
+  // BASELINE cfg3: Van der Pol tracking, 8 RBF / MLP observables, N = 30, y = lifted state
+  if (a.L == 8 && a.N == 30 && a.q == 8) return launch_impl<T, 64, 8, 30, 8>(a, s);
+  if (a.L == 8 && a.N == 30 && a.q == 2) return launch_impl<T, 64, 8, 30, 2>(a, s);
+  if (a.L == 20 && a.N == 30 && a.q == 2) return launch_impl<T, 64, 20, 30, 2>(a, s);
   return launch_impl<T, 64, 0, 0, 0>(a, s);
 }
 

@@ -211,7 +211,7 @@ def condense(A, B, Co, psi, r, N, Qw=100.0, Rw=1e-4, PN=None):
 # ----------------------------------------------------------------------------------------
 
 
-def qp_exact(H, f, lb, ub, tol=1e-12, max_iter=None):
+def qp_exact(H, f, lb, ub, tol=1e-11, max_iter=None):
     """Exact minimiser of u'Hu + f'u over the box lb <= u <= ub (H SPD): primal active set.
 
     This is the parity TARGET for the MPC solve: the unique minimiser of the reference's own
@@ -228,20 +228,22 @@ def qp_exact(H, f, lb, ub, tol=1e-12, max_iter=None):
     act[x <= lb] = -1
     act[x >= ub] = 1
     max_iter = max_iter or 20 * n + 20
-    scale = max(1.0, float(np.max(np.abs(f))), float(np.max(np.abs(H))))
+    gscale = np.abs(f) + 2.0 * (np.abs(H) @ np.maximum(np.abs(lb), np.abs(ub)))  # magnitude of the gradient's terms
+    at_min = False  # x is the minimiser on the current working set (a full step was just taken)
     for it in range(max_iter):
         F = act == 0
         grad = 2.0 * (H @ x) + f
         p = np.zeros(n)
-        if F.any():
+        if F.any() and not at_min:
             p[F] = np.linalg.solve(2.0 * H[np.ix_(F, F)], -grad[F])
-        if np.max(np.abs(p)) <= tol * max(1.0, np.max(np.abs(x))):
+        if at_min or np.max(np.abs(p)) <= 1e-9 * max(1.0, np.max(np.abs(x))):
             # stationary on the working set: check multipliers
-            viol = np.where(act == -1, -grad, np.where(act == 1, grad, 0.0))  # > 0 means wrong sign
-            j = int(np.argmax(viol))
-            if viol[j] <= tol * scale:
+            viol = np.where(act == -1, -grad, np.where(act == 1, grad, 0.0)) / np.maximum(gscale, 1e-300)
+            j = int(np.argmax(viol))  # > 0 means wrong sign
+            if viol[j] <= tol:
                 return x, it
             act[j] = 0
+            at_min = False
             continue
         alpha, blk = 1.0, -1
         for i in np.nonzero(F)[0]:
@@ -254,6 +256,7 @@ def qp_exact(H, f, lb, ub, tol=1e-12, max_iter=None):
                 if a < alpha:
                     alpha, blk = a, i
         x = x + alpha * p
+        at_min = blk < 0
         if blk >= 0:
             if p[blk] < 0:
                 x[blk] = lb[blk]

@@ -314,6 +314,49 @@ def test_closed_loop_step_on_reference_states(torch_mod, KM, gfile, wfile, outpu
     assert w_log < 5e-3
 
 
+@pytest.mark.parametrize("plant,lift,L,N,output,layers,B,threads,bnd", [
+    ("duffing", "mlp", 20, 20, "Cx", 3, 6, 0, 2.0),     # BASELINE cfg1/cfg2 dimensions (static kernel)
+    ("vdp", "rbf", 8, 30, "lift", 3, 6, 0, 6.0),        # cfg3: Van der Pol tracking in the lifted space, RBF lift
+    ("duffing", "mlp", 32, 40, "Cx", 2, 4, 0, 2.0),     # cfg4-like sizes, two hidden layers, generic 64-thread path
+    ("duffing", "mlp", 64, 50, "Cx", 3, 3, 256, 2.0),   # cfg5 dimensions, four waves per trajectory
+    ("duffing", "mlp", 20, 20, "Cx", 3, 5, 256, 2.0),   # same problem on the generic 256-thread path
+])
+def test_closed_loop_vs_oracle_scaled_dims(torch_mod, KM, plant, lift, L, N, output, layers, B, threads, bnd):
+    """kmpc_step vs the oracle controller (same estimator, gain form; exact QP) at the BASELINE dimensions with
+    synthetic weights: distinct trajectories, closed loop through the oracle's plant, u_k within 1e-6."""
+    from koopmpc.synth import duffing_rk4, initial_states, offline_edmd, random_mlp_weights, vdp_rk4
+
+    rng = np.random.RandomState(L * N)
+    if lift == "mlp":
+        w = random_mlp_weights(2, 100, layers, L, seed=5)
+        mpc = KM(n=2, L=L, N=N, batch=B, weights=w, layers=layers, output=output, lb=-bnd, ub=bnd, threads=threads)
+        lift_fn = lambda x: ko.mlp_lift(w, x)
+    else:
+        cx = 4 * rng.rand(L, 2) - 2
+        mpc = KM(n=2, L=L, N=N, batch=B, lift="rbf", centres=cx, output=output, lb=-bnd, ub=bnd, threads=threads)
+        lift_fn = lambda x: ko.rbf_lift(x, cx)
+    A0, B0, C0 = offline_edmd(lambda X: mpc.Encoder(X), plant=duffing_rk4 if plant == "duffing" else vdp_rk4)
+    mpc.set_model(A0, B0, C0)
+    if output == "lift":
+        r = np.tile(lift_fn(np.array([[1.0], [0.0]])), (1, N))   # vanderpol.py:668-675
+    else:
+        r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    ctls = [ko.OracleController(lift_fn, L, 2, N, -bnd, bnd, A0, B0, C0, output=output, rls="gain") for _ in range(B)]
+    X = initial_states(B, seed=3)
+    worst = 0.0
+    for k in range(10):
+        u = mpc.step(X, r).cpu().numpy()
+        Useq = mpc.Useq.cpu().numpy()
+        assert (mpc.status.cpu().numpy() == 0).all(), k
+        for b in range(B):
+            uo, Uo, _ = ctls[b].step(X[:, b], r)
+            worst = max(worst, abs(u[b] - uo), np.abs(Useq[:, b] - Uo).max())
+            ctls[b].prev = (ctls[b].prev[0], float(u[b]))  # both sides regress on the input that was applied
+            X[:, b] = ko.plant_step(plant, X[:, b], float(u[b]))
+    print("scaled dims %s L=%d N=%d threads=%d: max |U_gpu - U_oracle| = %.2e" % (plant, L, N, threads, worst))
+    assert worst < 1e-6
+
+
 def _set_uprev(mpc, sd, uk):
     """Replace the stored u_{k} of every trajectory in a state blob (tail of the blob) and load it back."""
     blob = sd["blob"].copy()
