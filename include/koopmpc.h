@@ -124,6 +124,24 @@ int kmpc_qp_solve(kmpc_handle* h, const void* H_dev, const void* f_dev, void* U_
 int kmpc_step(kmpc_handle* h, const void* X_dev, const void* ref_dev, int ref_per_traj,
               void* U0_dev, void* Useq_dev, int32_t* status_dev, int32_t* iters_dev, void* stream);
 
+/* ---- shared-model mode (BASELINE cfg4): ONE [A B], C for all trajectories ---------------
+ * The batch's transitions are pooled in Gram form, V = [Xlift; U], W = [Ylift; X]: G = V V', W V'
+ * (Koopman_update.m:94-98), [A B] = (Ylift V')(G + I/P0)^-1, C = (X Xlift')(G_LL + I/barQ0)^-1 -- B rank-one
+ * RLS updates of a shared inv_K_G (duffing.py:927-953) are exactly G <- G + sum_b z_b z_b'.  With the batch
+ * sharded over GPUs the only exchange of the path is the sum of `delta_gram` over ranks between the two
+ * stages (ncclAllReduce / torch.distributed.all_reduce on the caller's side; (p+L+n)*p float64 values).   */
+int64_t kmpc_gram_elems(const kmpc_handle* h);
+/* stage 1: lift x_k; delta_gram_dev (float64, overwritten) = Gram sums of THIS rank's transitions
+ * (psi_{k-1}, u_{k-1}) -> (psi_k, x_k), rows [Z Z' (p x p); Ylift Z' (L x p); X Z' (n x p)]; zeros on the
+ * first call (no transition yet).  The contraction runs on v_mfma_f64_16x16x4_f64.                        */
+int kmpc_shared_local_gram(kmpc_handle* h, const void* X_dev, double* delta_gram_dev, void* stream);
+/* stage 2: G <- lambda G + delta_gram (already summed over ranks); model from G; condensed QP of the shared
+ * model (H, F, f0 with f_b = F psi_b + f0); box QP of every trajectory.  ref_dev (q x N) is shared.        */
+int kmpc_shared_solve(kmpc_handle* h, const double* delta_gram_dev, const void* ref_dev, void* U0_dev,
+                      void* Useq_dev, int32_t* status_dev, int32_t* iters_dev, void* stream);
+/* the shared model: A_dev (L x L), B_dev (L), C_dev (n x L) in the handle dtype                           */
+int kmpc_shared_get_model(kmpc_handle* h, void* A_dev, void* B_dev, void* C_dev, void* stream);
+
 /* ---- adjacent to the path: the plant on the device ---------------- */
 /* X <- RK4(f, X, U, h) in place: duffing.py:250-261 / vanderpol_RBF.py:113; `switched`
  * selects the parameters after step 100 (duffing.py:991-992, vanderpol.py:923-931).         */

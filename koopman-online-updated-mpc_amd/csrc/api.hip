@@ -33,6 +33,11 @@ struct kmpc_handle {
   virtual int plant_step(int plant, void* X, const void* U, double h, int sw, int B, hipStream_t s) = 0;
   virtual int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
                       void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) = 0;
+  virtual int64_t gram_elems() const = 0;
+  virtual int shared_local_gram(const void* X, double* delta, hipStream_t s) = 0;
+  virtual int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
+                           hipStream_t s) = 0;
+  virtual int shared_get_model(void* A, void* B, void* C, hipStream_t s) = 0;
   virtual int64_t state_bytes() const = 0;
   virtual int state_export(void* blob, int64_t bytes) = 0;
   virtual int state_import(const void* blob, int64_t bytes) = 0;
@@ -134,7 +139,8 @@ struct Impl : kmpc_handle {
   ~Impl() override {
     for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev,
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
-                      (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0})
+                      (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
+                      (void*)dHs, (void*)dFs, (void*)df0s})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -194,11 +200,17 @@ struct Impl : kmpc_handle {
       HIPCHK(hipMemcpy(dTmp + L * p, c.data(), c.size() * sizeof(T), hipMemcpyHostToDevice));
       HIPCHK(launch_broadcast<T>(dC, sC, dTmp + L * p, n * L, B, nullptr));
     }
+    if (dKs) {
+      HIPCHK(hipMemcpy(dKs, dK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice));
+      HIPCHK(hipMemcpy(dCs, dC, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice));
+    }
     HIPCHK(hipDeviceSynchronize());
     return 0;
   }
 
   int reset(hipStream_t s) override {
+    if (dGram) HIPCHK(hipMemsetAsync(dGram, 0, sizeof(double) * (size_t)gram_elems(), s));
+    shared_has_samples = false;
     HIPCHK(launch_fill_state<T>(dP, sP, p, (T)cfg.P0, dQ, sQ, L, (T)cfg.barQ0, nullptr, sK, nullptr, sC, n, B, s));
     have_prev = false;
     rls_fresh = true;
@@ -361,6 +373,81 @@ struct Impl : kmpc_handle {
     return 0;
   }
 
+  // ---- shared-model mode -----------------------------------------------------------------------------
+  double *dGram = nullptr, *dPartial = nullptr;
+  T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr;
+  bool shared_has_samples = false;
+  static constexpr int GRAM_BLOCKS = 256;
+  int64_t gram_elems() const override { return (int64_t)(p + L + n) * p; }
+  int shared_alloc() {
+    if (dGram) return 0;
+    const int R = p + L + n, MT = (R + 15) / 16, NT = (p + 15) / 16;
+    HIPCHK(hipMalloc(&dGram, sizeof(double) * (size_t)R * p));
+    HIPCHK(hipMemset(dGram, 0, sizeof(double) * (size_t)R * p));
+    HIPCHK(hipMalloc(&dPartial, sizeof(double) * (size_t)GRAM_BLOCKS * MT * 16 * NT * 16));
+    HIPCHK(hipMalloc(&dKs, sizeof(T) * (size_t)L * p));
+    HIPCHK(hipMalloc(&dCs, sizeof(T) * (size_t)n * L));
+    HIPCHK(hipMalloc(&dHs, sizeof(T) * (size_t)N * N));
+    HIPCHK(hipMalloc(&dFs, sizeof(T) * (size_t)N * L));
+    HIPCHK(hipMalloc(&df0s, sizeof(T) * (size_t)N));
+    // until samples exist the shared model is the offline one (trajectory 0's copy, duffing.py:811-813)
+    HIPCHK(hipMemcpy(dKs, dK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice));
+    HIPCHK(hipMemcpy(dCs, dC, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice));
+    return 0;
+  }
+  int shared_local_gram(const void* X, double* delta, hipStream_t s) override {
+    if (!X || !delta) FAIL(-3, "kmpc_shared_local_gram: null pointer");
+    int rc = shared_alloc();
+    if (rc) return rc;
+    T* psi_now = dPsi[cur];
+    T* psi_prev = dPsi[cur ^ 1];
+    rc = lift_to((const T*)X, psi_now, 1, L, B, s);
+    if (rc) return rc;
+    if (!have_prev) {
+      HIPCHK(hipMemsetAsync(delta, 0, sizeof(double) * (size_t)gram_elems(), s));
+      return 0;
+    }
+    GramArgs<T> g{};
+    g.B = B; g.n = n; g.L = L; g.max_blocks = GRAM_BLOCKS;
+    g.psi_prev = psi_prev; g.pp_sl = 1; g.pp_sb = L;
+    g.psi_now = psi_now; g.pn_sl = 1; g.pn_sb = L;
+    g.u_prev = dUprev; g.x_now = (const T*)X; g.partial = dPartial;
+    HIPCHK(hipMemsetAsync(delta, 0, sizeof(double) * (size_t)gram_elems(), s));
+    HIPCHK(launch_gram<T>(g, 0.0, delta, s));
+    return 0;
+  }
+  int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
+                   hipStream_t s) override {
+    if (!delta || !ref || !U0) FAIL(-3, "kmpc_shared_solve: null pointer");
+    int rc = shared_alloc();
+    if (rc) return rc;
+    if (have_prev) {
+      HIPCHK(launch_axpby(dGram, delta, cfg.lambda, (int)gram_elems(), s));
+      HIPCHK(launch_shared_solve<T>(dGram, L, n, 1.0 / cfg.P0, 1.0 / cfg.barQ0,
+                                    cfg.output_kind == KMPC_OUT_CX ? 1 : 0, dKs, dCs, s));
+      shared_has_samples = true;
+    }
+    HIPCHK(launch_shared_condense<T>(dKs, dCs, (const T*)ref, L, n, q, N,
+                                     cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX, cfg.Qw, cfg.Rw, dHs, dFs,
+                                     df0s, s));
+    StepArgs<T> a = base_args(B);
+    a.phases = PH_QP;
+    a.H_in = dHs; a.h_shared = 1; a.F_in = dFs; a.f0_in = df0s;
+    a.psi_now = dPsi[cur]; a.pn_sl = 1; a.pn_sb = L;
+    a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
+    HIPCHK(launch_step<T>(a, threads, s));
+    have_prev = true;
+    cur ^= 1;
+    return 0;
+  }
+  int shared_get_model(void* A, void* Bm, void* C, hipStream_t s) override {
+    int rc = shared_alloc();
+    if (rc) return rc;
+    HIPCHK(launch_export_model<T>(dKs, (long)L * p, cfg.output_kind == KMPC_OUT_CX ? dCs : nullptr, (long)n * L, n, L,
+                                  1, (T*)A, (T*)Bm, (T*)C, s));
+    return 0;
+  }
+
   // ---- state blob: header | P | K | Q | C | psi_prev | u_prev
   struct BlobHeader { int32_t magic, dtype, n, L, N, B, have_prev, rls_fresh; };
   int64_t state_bytes() const override {
@@ -467,6 +554,10 @@ int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t
 int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
 int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NN(h); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
 int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NN(h); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
+int64_t kmpc_gram_elems(const kmpc_handle* h) { return h ? h->gram_elems() : -1; }
+int kmpc_shared_local_gram(kmpc_handle* h, const void* X, double* delta, void* s) { NN(h); return h->shared_local_gram(X, delta, (hipStream_t)s); }
+int kmpc_shared_solve(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->shared_solve(delta, ref, U0, Useq, st, it, (hipStream_t)s); }
+int kmpc_shared_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->shared_get_model(A, B, C, (hipStream_t)s); }
 int64_t kmpc_state_bytes(const kmpc_handle* h) { return h ? h->state_bytes() : -1; }
 int kmpc_state_export(kmpc_handle* h, void* blob, int64_t bytes) { NN(h); return h->state_export(blob, bytes); }
 int kmpc_state_import(kmpc_handle* h, const void* blob, int64_t bytes) { NN(h); return h->state_import(blob, bytes); }

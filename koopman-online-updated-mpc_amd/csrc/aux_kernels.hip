@@ -106,6 +106,15 @@ template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* 
   return hipGetLastError();
 }
 
+// g <- a * g + d   (Gram accumulation with forgetting)
+__global__ __launch_bounds__(256) void axpby_kernel(double* g, const double* d, double a, int count) {
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < count; e += gridDim.x * blockDim.x) g[e] = a * g[e] + d[e];
+}
+hipError_t launch_axpby(double* g, const double* d, double a, int count, hipStream_t s) {
+  hipLaunchKernelGGL(axpby_kernel, dim3((count + 255) / 256), dim3(256), 0, s, g, d, a, count);
+  return hipGetLastError();
+}
+
 #define INST(T)                                                                                                      \
   template hipError_t launch_plant<T>(const PlantArgs<T>&, hipStream_t);                                             \
   template hipError_t launch_fill_state<T>(T*, long, int, T, T*, long, int, T, T*, long, T*, long, int, int,        \

@@ -36,6 +36,8 @@ struct StepArgs {
   const T* ref;      // (q x N) or [B][q][N]
   T* H_out; T* f_out;        // optional exports  [B][N*N], [B][N]
   const T* H_in; const T* f_in;  // QP-only mode inputs
+  int h_shared;                  // H_in is ONE matrix for the whole batch (shared-model mode)
+  const T* F_in; const T* f0_in; // shared-model mode: f_b = F psi_b + f0 (F: N x L), psi from psi_now
   // QP
   T* Useq;           // (N x B) or null
   T* U0;             // [B] or null
@@ -57,6 +59,15 @@ template <typename T> struct LiftArgs {
   const T* cx; T eps; int rbf_matlab;
 };
 
+// K7: Gram sums of one step's transitions (rows [psi_prev; u_prev; psi_now; x_now] against [psi_prev; u_prev])
+template <typename T> struct GramArgs {
+  int B, n, L, max_blocks;
+  const T* psi_prev; long pp_sl, pp_sb;
+  const T* psi_now;  long pn_sl, pn_sb;
+  const T* u_prev; const T* x_now;
+  double* partial;   // [max_blocks][Rp][Cp] scratch
+};
+
 template <typename T> struct PlantArgs {
   int B, plant, switched; T h; T* X; const T* U;
 };
@@ -70,6 +81,13 @@ template <typename T> hipError_t launch_plant(const PlantArgs<T>& a, hipStream_t
 template <typename T> hipError_t launch_fill_state(T* P, long strideP, int p, T P0, T* Qb, long strideQ, int L,
                                                    T Q0, T* K, long strideK, T* C, long strideC, int n, int B,
                                                    hipStream_t s);
+hipError_t launch_axpby(double* g, const double* d, double a, int count, hipStream_t s);
+template <typename T> hipError_t launch_gram(const GramArgs<T>& a, double forget, double* gram, hipStream_t s);
+template <typename T> hipError_t launch_shared_solve(const double* gram, int L, int n, double dP, double dQ, int use_C,
+                                                     T* Kout, T* Cout, hipStream_t s);
+template <typename T> hipError_t launch_shared_condense(const T* K, const T* C, const T* ref, int L, int n, int q, int N,
+                                                        int out_kind, double Qw, double Rw, T* Hout, T* Fout, T* f0out,
+                                                        hipStream_t s);
 template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s);
 template <typename T> hipError_t launch_export_model(const T* K, long strideK, const T* C, long strideC, int n, int L,
                                                      int B, T* A_out, T* B_out, T* C_out, hipStream_t s);

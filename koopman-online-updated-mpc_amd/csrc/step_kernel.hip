@@ -651,10 +651,21 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       for (int e = tid; e < N; e += TPB) fg[e] = sf[e];
     }
   } else if (a.phases & PH_QP) {
-    const T* Hg = a.H_in + (size_t)b * N * N;
-    const T* fg = a.f_in + (size_t)b * N;
+    const T* Hg = a.H_in + (a.h_shared ? (size_t)0 : (size_t)b * N * N);
     for (int e = tid; e < N * N; e += TPB) sH[e] = Hg[e];
-    for (int e = tid; e < N; e += TPB) sf[e] = fg[e];
+    if (a.F_in) {
+      // shared-model mode: f_b = F psi_b + f0 (the per-trajectory part of the condensed QP)
+      for (int i = tid; i < L; i += TPB) sy[i] = a.psi_now[i * a.pn_sl + b * a.pn_sb];
+      __syncthreads();
+      for (int e = tid; e < N; e += TPB) {
+        T acc = a.f0_in[e];
+        for (int l = 0; l < L; ++l) acc += a.F_in[e * L + l] * sy[l];
+        sf[e] = acc;
+      }
+    } else {
+      const T* fg = a.f_in + (size_t)b * N;
+      for (int e = tid; e < N; e += TPB) sf[e] = fg[e];
+    }
     __syncthreads();
   }
 

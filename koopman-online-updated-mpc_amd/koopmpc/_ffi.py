@@ -47,6 +47,10 @@ SIGNATURES = {
     "kmpc_condense": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP]),
     "kmpc_qp_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "kmpc_step": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
+    "kmpc_gram_elems": (_I64, [_VP]),
+    "kmpc_shared_local_gram": (_I, [_VP, _VP, _VP, _VP]),
+    "kmpc_shared_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "kmpc_shared_get_model": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "kmpc_plant_step": (_I, [_VP, _I, _VP, _VP, _D, _I, _I, _VP]),
     "kmpc_rollout": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_state_bytes": (_I64, [_VP]),

@@ -212,6 +212,49 @@ class KoopmanMPC:
                                      self._p(self.status), self._p(self.iters), self._stream()), "kmpc_step")
         return self.U0
 
+    # ------------------------------------------------------------------ shared-model mode
+    def shared_local_gram(self, x):
+        """Stage 1 of a shared-model step: lift x_k and return this rank's Gram sums of the transitions
+        (psi_{k-1}, u_{k-1}) -> (psi_k, x_k): float64 tensor ((p+L+n), p) = [Z Z'; Ylift Z'; X Z']
+        (Koopman_update.m:94-98).  Zeros on the first call."""
+        X = self._dev(x, (self.n, self.B))
+        p = self.L + 1
+        if getattr(self, "_delta", None) is None:
+            self._delta = torch.zeros(p + self.L + self.n, p, dtype=torch.float64, device=self.device)
+        self._chk(self.lib.kmpc_shared_local_gram(self.h, self._p(X), self._p(self._delta), self._stream()),
+                  "kmpc_shared_local_gram")
+        return self._delta
+
+    def shared_solve(self, delta_gram, r):
+        """Stage 2: G <- lambda G + delta_gram (summed over ranks by the caller), shared [A B], C from G,
+        condensed QP of the shared model, box QP of every trajectory.  Returns u_k (B,)."""
+        rr, per = self._ref(r)
+        if per:
+            raise ValueError("shared-model mode takes one reference (q, N) for the whole batch")
+        d = delta_gram.to(device=self.device, dtype=torch.float64).contiguous()
+        self._chk(self.lib.kmpc_shared_solve(self.h, self._p(d), self._p(rr), self._p(self.U0), self._p(self.Useq),
+                                             self._p(self.status), self._p(self.iters), self._stream()),
+                  "kmpc_shared_solve")
+        return self.U0
+
+    def shared_step(self, x, r):
+        """One control step with ONE model for all trajectories of all ranks: local Gram sums (MFMA) ->
+        all-reduce over the process group (RCCL on GPUs; the only collective of the path) -> model, QP."""
+        import torch.distributed as dist
+
+        delta = self.shared_local_gram(x)
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+        return self.shared_solve(delta, r)
+
+    def shared_model(self):
+        A = torch.empty(self.L, self.L, dtype=self.dtype, device=self.device)
+        Bm = torch.empty(self.L, 1, dtype=self.dtype, device=self.device)
+        Cm = torch.empty(self.n, self.L, dtype=self.dtype, device=self.device) if self.output == "Cx" else None
+        self._chk(self.lib.kmpc_shared_get_model(self.h, self._p(A), self._p(Bm), self._p(Cm) if Cm is not None else None,
+                                                 self._stream()), "kmpc_shared_get_model")
+        return A, Bm, Cm
+
     # ------------------------------------------------------------------ plant (adjacent)
     def plant_step(self, kind, X, U, h=0.05, switched=False):
         """X <- f_update(0, X, U) in place on the device (duffing.py:256-261)."""

@@ -146,6 +146,35 @@ def rls_update_gain(K, P, z, y, lam=1.0):
     return Kn, Pn
 
 
+class SharedEdmd:
+    """Shared-model EDMD in Gram form (Koopman_update.m:94-101): V = [Xlift; U], W = [Ylift; X],
+    G = V V', [A B] = (Ylift V')(G + I/P0)^-1, C = (X Xlift')(G_LL + I/barQ0)^-1.  The ridge terms are
+    the reference's RLS initialisations (duffing.py:929-930, 946): for one trajectory this IS the
+    recursion of rls_update_reference (matrix inversion lemma), for B trajectories it pools them."""
+
+    def __init__(self, L, n, P0=1e4, barQ0=100.0, lam=1.0):
+        p = L + 1
+        self.L, self.n, self.p, self.P0, self.barQ0, self.lam = L, n, p, P0, barQ0, lam
+        self.G = np.zeros((p, p)); self.YZ = np.zeros((L, p)); self.XZ = np.zeros((n, p))
+
+    @staticmethod
+    def gram(Psi, U, PsiN, XN):
+        """Gram sums of a batch of transitions: Psi, PsiN (L,B), U (B,), XN (n,B) -> (G, YZ, XZ)."""
+        Z = np.concatenate([Psi, np.reshape(U, (1, -1))], axis=0)
+        return Z @ Z.T, PsiN @ Z.T, XN @ Z.T
+
+    def add(self, G, YZ, XZ):
+        self.G = self.lam * self.G + G
+        self.YZ = self.lam * self.YZ + YZ
+        self.XZ = self.lam * self.XZ + XZ
+
+    def model(self):
+        L, p = self.L, self.p
+        K = np.linalg.solve(self.G + np.eye(p) / self.P0, self.YZ.T).T
+        C = np.linalg.solve(self.G[:L, :L] + np.eye(L) / self.barQ0, self.XZ[:, :L].T).T
+        return K[:, :L].copy(), K[:, L:].copy(), C
+
+
 # ----------------------------------------------------------------------------------------
 # a5  shooting cost == a7 condensed QP
 # ----------------------------------------------------------------------------------------

@@ -357,6 +357,98 @@ def test_closed_loop_vs_oracle_scaled_dims(torch_mod, KM, plant, lift, L, N, out
     assert worst < 1e-6
 
 
+# ------------------------------------------------------------------ shared-model mode
+@pytest.mark.parametrize("L,B", [(20, 1), (20, 130), (32, 257), (64, 70), (8, 4096)])
+def test_gram_kernel_mfma(torch_mod, KM, L, B):
+    """K7: Gram sums on v_mfma_f64_16x16x4_f64 vs NumPy, ragged batches, two consecutive steps."""
+    rng = np.random.RandomState(L + B)
+    mpc = KM(n=2, L=L, N=10, batch=B, lift="rbf", centres=4 * rng.rand(L, 2) - 2)
+    mpc.set_model(np.zeros((L, L)), np.zeros(L), np.zeros((2, L)))
+    r = np.zeros((2, 10))
+    X0 = 4 * rng.rand(2, B) - 2
+    d0 = mpc.shared_local_gram(X0).cpu().numpy()
+    assert np.all(d0 == 0.0)  # no transition yet
+    u0 = mpc.shared_solve(mpc._delta, r).cpu().numpy().copy()
+    X1 = 4 * rng.rand(2, B) - 2
+    d1 = mpc.shared_local_gram(X1).cpu().numpy()
+    cx = mpc_centres = None
+    psi0 = mpc.Encoder(X0)
+    psi1 = mpc.Encoder(X1)
+    G, YZ, XZ = ko.SharedEdmd.gram(psi0, u0, psi1, X1)
+    want = np.concatenate([G, YZ, XZ], axis=0)
+    assert d1.shape == want.shape
+    assert np.abs(d1 - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+
+
+@pytest.mark.parametrize("L,N,B,layers", [(20, 20, 37, 3), (32, 40, 12, 2), (8, 10, 1, 3)])
+def test_shared_model_closed_loop_vs_oracle(torch_mod, KM, L, N, B, layers):
+    """Shared-model step (Gram -> model -> shared condense -> per-trajectory QP) vs the NumPy oracle
+    (SharedEdmd + condense + qp_exact) in closed loop; the model to 1e-7, the controls to 1e-6."""
+    from koopmpc.synth import initial_states, offline_edmd, random_mlp_weights
+
+    w = random_mlp_weights(2, 100, layers, L, seed=7)
+    mpc = KM(n=2, L=L, N=N, batch=B, weights=w, layers=layers)
+    lift = lambda x: ko.mlp_lift(w, x)
+    A0, B0, C0 = offline_edmd(lambda X: mpc.Encoder(X))
+    mpc.set_model(A0, B0, C0)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    sh = ko.SharedEdmd(L, 2)
+    A, Bm, C = A0, B0, C0
+    X = initial_states(B, seed=11)
+    prev = None
+    worst_u, worst_m = 0.0, 0.0
+    for k in range(8):
+        u = mpc.shared_step(X, r).cpu().numpy()
+        assert int(mpc.status.max().item()) == 0
+        Psi = lift(X)
+        if prev is not None:
+            sh.add(*ko.SharedEdmd.gram(prev[0], prev[1], Psi, X))
+            A, Bm, C = sh.model()
+            Ag, Bg, Cg = [t.cpu().numpy() for t in mpc.shared_model()]
+            scale = max(np.abs(A).max(), np.abs(Bm).max())
+            worst_m = max(worst_m, np.abs(Ag - A).max() / scale, np.abs(Bg - Bm).max() / scale,
+                          np.abs(Cg - C).max() / max(1e-3, np.abs(C).max()))
+        _, _, H, _, _ = ko.condense(A, Bm, C, Psi[:, 0], r, N)
+        Useq = mpc.Useq.cpu().numpy()
+        for b in range(B):
+            _, _, _, f, _ = ko.condense(A, Bm, C, Psi[:, b], r, N)
+            Uo, _ = ko.qp_exact(H, f, -2.0, 2.0)
+            worst_u = max(worst_u, np.abs(Useq[:, b] - Uo).max())
+        prev = (Psi, u.copy())
+        X = ko.plant_step("duffing", X, u)
+    print("shared mode L=%d N=%d B=%d: model %.2e, controls %.2e" % (L, N, B, worst_m, worst_u))
+    assert worst_m < 1e-7 and worst_u < 1e-6
+
+
+def test_shared_model_two_shards_equal_one_batch(torch_mod, KM):
+    """The batch split over two handles (two 'ranks' on one GPU) with the Gram sums added by hand -- the job
+    ncclAllReduce does between the two stages -- gives the same shared model and controls as one handle."""
+    torch = torch_mod
+    from koopmpc.synth import initial_states, offline_edmd, random_mlp_weights
+
+    L, N, B = 20, 20, 96
+    w = random_mlp_weights(2, 100, 3, L, seed=7)
+    full = KM(n=2, L=L, N=N, batch=B, weights=w)
+    h0 = KM(n=2, L=L, N=N, batch=40, weights=w)
+    h1 = KM(n=2, L=L, N=N, batch=B - 40, weights=w)
+    A0, B0, C0 = offline_edmd(lambda X: full.Encoder(X))
+    for m in (full, h0, h1):
+        m.set_model(A0, B0, C0)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X = torch.tensor(initial_states(B, seed=5), dtype=torch.float64, device="cuda:0")
+    for k in range(6):
+        uf = full.shared_step(X, r).clone()
+        d = h0.shared_local_gram(X[:, :40].contiguous()) + h1.shared_local_gram(X[:, 40:].contiguous())  # "all-reduce"
+        u0 = h0.shared_solve(d, r).clone()
+        u1 = h1.shared_solve(d, r).clone()
+        us = torch.cat([u0, u1])
+        assert float((uf - us).abs().max()) < 1e-9
+        Af, Bf, Cf = full.shared_model()
+        As, Bs, Cs = h1.shared_model()
+        assert float((Af - As).abs().max()) <= 1e-10 * float(Af.abs().max())
+        X = full.plant_step("duffing", X.clone(), uf)
+
+
 def _set_uprev(mpc, sd, uk):
     """Replace the stored u_{k} of every trajectory in a state blob (tail of the blob) and load it back."""
     blob = sd["blob"].copy()

@@ -121,6 +121,21 @@ assert t == 2.0, t
 units = torch.tensor([float(hi - lo)], dtype=torch.float64)
 dist.all_reduce(units)
 assert units.item() == 4097.0
+# shared-model mode: the ONLY collective of the path is the sum of the per-rank Gram blocks
+# (KoopmanMPC.shared_step does dist.all_reduce(delta) between its two stages).  Same arithmetic on the
+# oracle: per-shard Gram sums, all-reduced, equal the Gram sums of the whole batch.
+sys.path.insert(0, {root!r})
+import numpy as np
+from oracle import koopman_oracle as ko
+rng = np.random.RandomState(0)
+L, Bt = 6, 101
+Psi, U, PsiN, XN = rng.randn(L, Bt), rng.randn(Bt), rng.randn(L, Bt), rng.randn(2, Bt)
+lo, hi = shard_range(Bt, rank, 2)
+G, YZ, XZ = ko.SharedEdmd.gram(Psi[:, lo:hi], U[lo:hi], PsiN[:, lo:hi], XN[:, lo:hi])
+delta = torch.tensor(np.concatenate([G, YZ, XZ], axis=0))
+dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+Gf, YZf, XZf = ko.SharedEdmd.gram(Psi, U, PsiN, XN)
+assert np.allclose(delta.numpy(), np.concatenate([Gf, YZf, XZf], axis=0), rtol=1e-12, atol=1e-12)
 dist.barrier()
 dist.destroy_process_group()
 print("rank", rank, "ok")
@@ -135,7 +150,7 @@ def test_two_rank_gloo_sharding_and_timing(tmp_path):
     port = s.getsockname()[1]
     s.close()
     script = tmp_path / "w.py"
-    script.write_text(_WORKER.format(pkg=PKG, port=port))
+    script.write_text(_WORKER.format(pkg=PKG, port=port, root=ROOT))
     procs = [subprocess.Popen([sys.executable, str(script), str(r)], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
              for r in range(2)]
     outs = [p.communicate(timeout=240)[0].decode() for p in procs]

@@ -133,6 +133,19 @@ def test_reference_form_reassociation_floor(name, P0, lifted, bnd):
     assert dU < 1e-7 * P0
 
 
+def test_shared_edmd_is_the_reference_rls_for_one_trajectory(duff):
+    """Gram-form shared model (Koopman_update.m:94-101 with the RLS initialisations as ridge) pooled over ONE
+    trajectory reproduces the reference's recursive K_ext / C_prev (inside the K_A*inv_K_G floor)."""
+    g = duff
+    sh = ko.SharedEdmd(8, 2)
+    for k in range(130):
+        sh.add(*ko.SharedEdmd.gram(g["loop_xlift"][k], g["loop_u_loc"][k].ravel(), g["loop_ylift"][k], g["loop_x_loc"][k]))
+        A, B, C = sh.model()
+        K = np.concatenate([A, B], axis=1)
+        assert np.abs(K - g["loop_K_ext"][k]).max() <= 2e-7 * np.abs(K).max()
+        assert np.abs(C - g["loop_C_prev"][k]).max() <= 1e-9 * max(1e-3, np.abs(C).max())
+
+
 # ------------------------------------------------------------------ cost / condensed QP
 def _model(g, k):
     return g["loop_Ap"][k], g["loop_Bp"][k], g["loop_Cp"][k], g["loop_xlift"][k], g["loop_r"][k]
