@@ -41,7 +41,7 @@ enum {
   KMPC_OUT_CX = 0,   /* y = C x, C adapted by RLS (duffing.py:553, 943-953); q = n        */
   KMPC_OUT_LIFT = 1  /* y = lifted state (vanderpol.py:456-459); q = L, C not used        */
 };
-enum { KMPC_PLANT_DUFFING = 0, KMPC_PLANT_VDP = 1 };
+enum { KMPC_PLANT_DUFFING = 0, KMPC_PLANT_VDP = 1, KMPC_PLANT_TANK = 2 /* Tank_System.m:9-10, 194-195, 211 */ };
 
 /* kmpc_step / kmpc_run phases (bit mask) */
 enum { KMPC_PH_RLS = 1, KMPC_PH_CONDENSE = 2, KMPC_PH_QP = 4 };
@@ -59,12 +59,20 @@ typedef struct kmpc_config {
   int32_t batch;       /* B: trajectories resident on this GPU                             */
   int32_t qp_max_iter; /* Newton-solve cap per QP (0 -> 8N + 40)                           */
   int32_t threads;     /* threads per trajectory block: 0 auto, 64 or 256                  */
+  int32_t delta_u;     /* 1: decision variable is the input increment, MPC state [psi; u_prev],
+                          A~ = [A B; 0 I], B~ = [B; I], C~ = [C 0] (Tank_System.m:110-113, 265-268, 290);
+                          the step returns u_k = u_{k-1} + dU*(1) (Tank_System.m:192)          */
+  int32_t out_row0;    /* KMPC_OUT_CX: outputs are rows out_row0 .. out_row0+out_rows-1 of C x   */
+  int32_t out_rows;    /*   (Cy = [0 1] -> out_row0 = 1, out_rows = 1, Tank_System.m:113); 0 -> all n rows */
+  int32_t c_skip_first;/* 1: the first C update only downdates bar_Q (Tank_System.m:252-254)     */
   double lambda;       /* RLS forgetting factor (1.0; Koopman_update.m:258)                */
   double P0;           /* inv_K_G init scale (1e4 duffing.py:929-930; 1e5 vanderpol.py:874)*/
   double barQ0;        /* bar_Q init scale (100 duffing.py:946)                            */
   double Qw, Rw;       /* stage weights (100, 1e-4: duffing.py:580)                        */
   double lb, ub;       /* input box (+-2 duffing.py:636; +-6 vanderpol.py:542-544)         */
   double rbf_eps;      /* 1e-4 (vanderpol_RBF.py:22)                                       */
+  double umin, umax;   /* delta_u: absolute input range folded into the first increment's box
+                          (A_cons, b_cons of Tank_System.m:182-188)                           */
 } kmpc_config;
 
 /* ---- life cycle -------------------------------------------------------------------- */

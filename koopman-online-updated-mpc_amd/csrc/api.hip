@@ -89,7 +89,9 @@ struct Impl : kmpc_handle {
   int init(const kmpc_config& c) {
     cfg = c;
     n = c.n; m = c.m; L = c.L; N = c.N; B = c.batch; p = L + 1;
-    q = (c.output_kind == KMPC_OUT_LIFT) ? L : n;
+    q = (c.output_kind == KMPC_OUT_LIFT) ? L : (c.out_rows > 0 ? c.out_rows : n);
+    if (c.output_kind != KMPC_OUT_LIFT && (c.out_row0 < 0 || c.out_row0 + q > n)) FAIL(-2, "out_row0/out_rows outside C");
+    if (c.delta_u && !(c.umax > c.umin)) FAIL(-2, "delta_u needs umin < umax");
     if (m != 1) FAIL(-2, "m must be 1 (the reference takes B_hat = K[:, Nlift], duffing.py:170-171)");
     if (n < 1 || n > 4) FAIL(-2, "n must be in 1..4");
     if (L < 1 || L > 64) FAIL(-2, "L must be in 1..64");
@@ -257,6 +259,11 @@ struct Impl : kmpc_handle {
     a.max_iter = cfg.qp_max_iter > 0 ? cfg.qp_max_iter : 8 * N + 40;
     a.P = dP; a.strideP = sP; a.K = dK; a.strideK = sK; a.Qb = dQ; a.strideQ = sQ; a.C = dC; a.strideC = sC;
     a.lam = (T)cfg.lambda; a.Qw = (T)cfg.Qw; a.Rw = (T)cfg.Rw; a.lb = (T)cfg.lb; a.ub = (T)cfg.ub;
+    a.du_mode = cfg.delta_u ? 1 : 0;
+    a.cy0 = cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0;
+    a.c_skip_first = cfg.c_skip_first ? 1 : 0;
+    a.umin = (T)cfg.umin; a.umax = (T)cfg.umax;
+    a.u_prev = dUprev;  // delta-u reads the absolute previous input in every phase
     return a;
   }
 
@@ -294,6 +301,7 @@ struct Impl : kmpc_handle {
 
   int qp_solve(const void* H, const void* f, void* U, int32_t* st, int32_t* it, int Bc, hipStream_t s) override {
     if (Bc < 0 || !H || !f || !U) FAIL(-3, "kmpc_qp_solve: bad arguments");
+    if (cfg.delta_u && Bc != B) FAIL(-3, "kmpc_qp_solve: with delta_u the batch must equal the handle's (per-trajectory u_prev)");
     StepArgs<T> a = base_args(Bc);
     a.phases = PH_QP;
     a.H_in = (const T*)H; a.f_in = (const T*)f;
@@ -343,7 +351,7 @@ struct Impl : kmpc_handle {
 
   int plant_step(int plant, void* X, const void* U, double h, int sw, int Bc, hipStream_t s) override {
     if (n != 2) FAIL(-3, "plants are two-state systems");
-    if (plant != KMPC_PLANT_DUFFING && plant != KMPC_PLANT_VDP) FAIL(-3, "unknown plant");
+    if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
     PlantArgs<T> a{};
     a.B = Bc; a.plant = plant; a.switched = sw; a.h = (T)h; a.X = (T*)X; a.U = (const T*)U;
     HIPCHK(launch_plant<T>(a, s));
@@ -397,6 +405,7 @@ struct Impl : kmpc_handle {
   }
   int shared_local_gram(const void* X, double* delta, hipStream_t s) override {
     if (!X || !delta) FAIL(-3, "kmpc_shared_local_gram: null pointer");
+    if (cfg.delta_u || cfg.out_rows > 0) FAIL(-3, "shared-model mode does not implement the delta-u / Cy-row options yet");
     int rc = shared_alloc();
     if (rc) return rc;
     T* psi_now = dPsi[cur];

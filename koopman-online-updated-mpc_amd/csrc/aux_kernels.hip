@@ -23,6 +23,16 @@ template <typename T> __global__ __launch_bounds__(256) void plant_kernel(const 
   const int B = a.B;
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
     const T x1 = a.X[b], x2 = a.X[(size_t)B + b], u = a.U[b], h = a.h;
+    if (a.plant == 2) {
+      // cascaded tanks, a discrete map: Tank_System.m:9-10 (nominal), :194-195 (after step 100), clip at 0 :211
+      const T s1 = sqrt(x1 > T(0) ? x1 : T(0)), s2 = sqrt(x2 > T(0) ? x2 : T(0));
+      T y1, y2;
+      if (a.switched) { y1 = x1 - T(0.53) * s1 + T(0.3) * u; y2 = x2 + T(0.1) * s1 - T(0.35) * s2; }
+      else            { y1 = x1 - T(0.5) * s1 + T(0.4) * u;  y2 = x2 + T(0.2) * s1 - T(0.3) * s2; }
+      a.X[b] = y1 > T(0) ? y1 : T(0);
+      a.X[(size_t)B + b] = y2 > T(0) ? y2 : T(0);
+      continue;
+    }
     T k1a, k1b, k2a, k2b, k3a, k3b, k4a, k4b;
     plant_f(a.plant, a.switched, x1, x2, u, k1a, k1b);
     plant_f(a.plant, a.switched, x1 + T(0.5) * h * k1a, x2 + T(0.5) * h * k1b, u, k2a, k2b);

@@ -21,6 +21,10 @@ struct StepArgs {
   int max_iter;
   int ref_per_traj;
   int accumulate;    // status[b] = max(status[b], s), iters[b] += it (rollouts)
+  int du_mode;       // Tank_System.m:110-113: decision variable is the input increment, state [psi; u_prev]
+  int cy0;           // first row of C used as output (Cy selects rows cy0 .. cy0+q-1; Tank_System.m:113)
+  int c_skip_first;  // Tank_System.m:252-254: the first C update only touches bar_Q
+  T umin, umax;      // absolute input range, folded into the first increment's box (Tank_System.m:182-188)
   int r1, r2;        // LDS region sizes in elements (host-computed, see step_lds_elems)
   // persistent state
   T* P;   long strideP;   // [B][p*p]   inv_K_G

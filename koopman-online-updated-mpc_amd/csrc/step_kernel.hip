@@ -183,10 +183,17 @@ __device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs
   const int tid = threadIdx.x, ti = tid >> 3, tj = tid & 7;
   const int myvar = ti + 8 * tj;
   const bool own = (tj < RM) && (myvar < N_);
-  const T lb = a.lb, ub = a.ub;
+  // per-variable box: in the delta-u form the first increment also keeps the absolute input inside
+  // [umin, umax]:  lb_1 = max(lb, umin - u_prev), ub_1 = min(ub, umax - u_prev)   (Tank_System.m:182-188)
+  const T uprev = a.du_mode ? a.u_prev[b] : T(0);
+  T lb = a.lb, ub = a.ub;
   const T tol = (T)Tol<T>::kkt();
   const T eact = (T)Tol<T>::act() * (ub - lb);
   const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
+  if (a.du_mode && tid == 0) {
+    lb = (a.umin - uprev) > lb ? (a.umin - uprev) : lb;
+    ub = (a.umax - uprev) < ub ? (a.umax - uprev) : ub;
+  }
   const T c0 = tclip(T(0), lb, ub);
 
   T Tm[RM][RM], Hm[RM][RM];
@@ -218,7 +225,22 @@ __device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs
   }
   const T gs = tabs(fi) + T(2) * ra * xmaxb;
   T x = own ? c0 : T(0);
-  T hx = own ? c0 * rs : T(0);
+  T hx = T(0);  // H x at the start (x need not be uniform: the first variable's box may differ)
+  {
+    T xc[RM];
+#pragma unroll
+    for (int c = 0; c < RM; ++c) xc[c] = __shfl(x, tj * 8 + c, 64);
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      T s0 = T(0);
+#pragma unroll
+      for (int c = 0; c < RM; ++c) s0 += Hm[r][c] * xc[c];
+      s0 = allreduce8(s0);
+      if (tj == r) hx = s0;
+    }
+    if (!own) hx = T(0);
+  }
+  (void)rs;
   T p0 = own ? x * (hx + fi) : T(0);
   T J0 = wave_sum(p0);
   const unsigned long long ownmask = __ballot(own);
@@ -332,8 +354,9 @@ __device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs
     if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
   }
   if (tid == 0) {  // lane 0 owns variable 0
-    if (a.U0) a.U0[b] = x;
-    if (a.u_store) a.u_store[b] = x;
+    const T uout = a.du_mode ? uprev + x : x;  // U0 = U0 + dU*(1)   (Tank_System.m:192)
+    if (a.U0) a.U0[b] = uout;
+    if (a.u_store) a.u_store[b] = uout;
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
     if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
   }
@@ -467,7 +490,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       }
       for (int e = tid; e < n * L; e += TPB) {
         const int r = e / L, j = e - r * L;
-        const T v = sC[e] + sE[r] * (sPz[j] * dcinv);
+        const T v = (a.c_skip_first && a.first_update) ? T(0) : sC[e] + sE[r] * (sPz[j] * dcinv);
         sC[e] = v;
         Cg[e] = v;
       }
@@ -509,7 +532,10 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       const bool isA = t < L, isC = (t >= L) && (t < L + nco);
       T row[L_];
 #pragma unroll
-      for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(t - L) * L + l] : T(0));
+      for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(a.cy0 + t - L) * L + l] : T(0));
+      // delta-u form (Tank_System.m:110-113): the augmented state [x; u_prev] propagates as
+      // x+ = A x + B s with s = 1 on the v-chain (B~ = [B; 1]) and s = u_prev on the w-chain
+      const T bs = (a.du_mode && isA) ? sK[t * p + L] * (half ? a.u_prev[b] : T(1)) : T(0);
       if (!cx && half == 0 && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
       int cur = 0;
       for (int j = 0; j <= N; ++j) {
@@ -536,7 +562,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
         for (int w2 = 1; w2 < L_; w2 *= 2)
 #pragma unroll
           for (int l = 0; l + w2 < L_; l += 2 * w2) pr[l] += pr[l + w2];
-        const T acc = pr[0];
+        const T acc = pr[0] + (isA ? bs : T(0));
         if (half == 0) {
           if (isA && j < N) {
             sV[(cur ^ 1) * L + t] = acc;                      // v_{j+1}
@@ -567,7 +593,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
               T acc = T(0);
 #pragma unroll
               for (int l = 0; l < L; ++l) acc += sK[t * p + l] * v[l];
-              vn[t] = acc;
+              vn[t] = a.du_mode ? acc + sK[t * p + L] : acc;  // delta-u: x+ = A x + B s, s = 1
             }
           } else if (t < 2 * L) {
             if (j < N) {
@@ -575,7 +601,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
               T acc = T(0);
 #pragma unroll
               for (int l = 0; l < L; ++l) acc += sK[r * p + l] * w[l];
-              wn[r] = acc;
+              wn[r] = a.du_mode ? acc + sK[r * p + L] * a.u_prev[b] : acc;  // s = u_prev
             }
           } else if (t < 2 * L + q) {
             if (j < N) {
@@ -584,7 +610,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
               if (cx) {
                 g = T(0);
 #pragma unroll
-                for (int l = 0; l < L; ++l) g += sC[r * L + l] * v[l];
+                for (int l = 0; l < L; ++l) g += sC[(a.cy0 + r) * L + l] * v[l];
               } else {
                 g = v[r];
               }
@@ -597,7 +623,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
               if (cx) {
                 y = T(0);
 #pragma unroll
-                for (int l = 0; l < L; ++l) y += sC[r * L + l] * w[l];
+                for (int l = 0; l < L; ++l) y += sC[(a.cy0 + r) * L + l] * w[l];
               } else {
                 y = w[r];
               }
@@ -681,10 +707,15 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   if constexpr (N_ > 0 && N_ <= 32 && TPB == 64) {
     if (a.phases & PH_QP) qp_regs<T, N_>(sH, sf, a, b, red);
   } else if (a.phases & PH_QP) {
-    const T lb = a.lb, ub = a.ub;
+    const T uprev = a.du_mode ? a.u_prev[b] : T(0);
+    T lb = a.lb, ub = a.ub;
     const T tol = (T)Tol<T>::kkt();
     const T eact = (T)Tol<T>::act() * (ub - lb);
     const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
+    if (a.du_mode && tid == 0) {  // first increment: absolute input range folded in (Tank_System.m:182-188)
+      lb = (a.umin - uprev) > lb ? (a.umin - uprev) : lb;
+      ub = (a.umax - uprev) < ub ? (a.umax - uprev) : ub;
+    }
     const T c0 = tclip(T(0), lb, ub);
     const int ti = (TPB == 64) ? (tid >> 3) : (tid >> 4);
     const int tj = (TPB == 64) ? (tid & 7) : (tid & 15);
@@ -712,10 +743,16 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       }
       gs = tabs(sf[tid]) + T(2) * ra * xmaxb;  // magnitude of the terms of the gradient
       qx[tid] = c0;
-      qHx[tid] = c0 * rs;
+      (void)rs;
     }
     for (int i = ti; i < N; i += ts)
       for (int j = tj; j < N; j += ts) sM[i * N + j] = T(2) * sH[i * N + j];
+    __syncthreads();
+    if (mine) {  // H x at the start (x need not be uniform: the first variable's box may differ)
+      T acc = T(0);
+      for (int j = 0; j < N; ++j) acc += sH[j * N + tid] * qx[j];
+      qHx[tid] = acc;
+    }
     __syncthreads();
 
     unsigned long long Smask = 0ull;  // variables currently swept into T
@@ -872,8 +909,9 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       if (a.Useq) a.Useq[(size_t)tid * B + b] = qx[tid];
     }
     if (tid == 0) {
-      if (a.U0) a.U0[b] = qx[0];
-      if (a.u_store) a.u_store[b] = qx[0];
+      const T uout = a.du_mode ? uprev + qx[0] : qx[0];
+      if (a.U0) a.U0[b] = uout;
+      if (a.u_store) a.u_store[b] = uout;
       if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
       if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
     }
@@ -907,6 +945,7 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
   if (a.L == 8 && a.N == 10 && a.q == 2) return launch_impl<T, 64, 8, 10, 2>(a, s);
   if (a.L == 8 && a.N == 10 && a.q == 8) return launch_impl<T, 64, 8, 10, 8>(a, s);
   // BASELINE cfg3: Van der Pol tracking, 8 RBF / MLP observables, N = 30, y = lifted state
+  if (a.L == 10 && a.N == 20 && a.q == 1) return launch_impl<T, 64, 10, 20, 1>(a, s);  // Tank_System.m dimensions
   if (a.L == 8 && a.N == 30 && a.q == 8) return launch_impl<T, 64, 8, 30, 8>(a, s);
   if (a.L == 8 && a.N == 30 && a.q == 2) return launch_impl<T, 64, 8, 30, 2>(a, s);
   if (a.L == 20 && a.N == 30 && a.q == 2) return launch_impl<T, 64, 20, 30, 2>(a, s);

@@ -14,7 +14,7 @@ LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "libkoopmpc.so")
 KMPC_F32, KMPC_F64 = 0, 1
 KMPC_LIFT_MLP, KMPC_LIFT_RBF_PY, KMPC_LIFT_RBF_MATLAB = 0, 1, 2
 KMPC_OUT_CX, KMPC_OUT_LIFT = 0, 1
-KMPC_PLANT_DUFFING, KMPC_PLANT_VDP = 0, 1
+KMPC_PLANT_DUFFING, KMPC_PLANT_VDP, KMPC_PLANT_TANK = 0, 1, 2
 
 
 class KmpcConfig(C.Structure):
@@ -23,9 +23,10 @@ class KmpcConfig(C.Structure):
         ("hidden", C.c_int32), ("layers", C.c_int32), ("lift_kind", C.c_int32),
         ("output_kind", C.c_int32), ("dtype", C.c_int32), ("batch", C.c_int32),
         ("qp_max_iter", C.c_int32), ("threads", C.c_int32),
+        ("delta_u", C.c_int32), ("out_row0", C.c_int32), ("out_rows", C.c_int32), ("c_skip_first", C.c_int32),
         ("lam", C.c_double), ("P0", C.c_double), ("barQ0", C.c_double),
         ("Qw", C.c_double), ("Rw", C.c_double), ("lb", C.c_double), ("ub", C.c_double),
-        ("rbf_eps", C.c_double),
+        ("rbf_eps", C.c_double), ("umin", C.c_double), ("umax", C.c_double),
     ]
 
 

@@ -39,7 +39,8 @@ class KoopmanMPC:
 
     def __init__(self, n=2, L=8, N=10, batch=1, lift="mlp", weights=None, centres=None, hidden=100, layers=3,
                  output="Cx", dtype=torch.float64, lam=1.0, P0=1e4, barQ0=100.0, Qw=100.0, Rw=1e-4, lb=-2.0,
-                 ub=2.0, rbf_eps=1e-4, qp_max_iter=0, threads=0, device=None):
+                 ub=2.0, rbf_eps=1e-4, qp_max_iter=0, threads=0, device=None, delta_u=False, out_row0=0, out_rows=0,
+                 c_skip_first=False, umin=-8.0, umax=8.0):
         if not torch.cuda.is_available():
             raise RuntimeError("koopmpc needs a HIP device (MI355X); there is no CPU path")
         self.lib = _ffi.load()
@@ -49,7 +50,7 @@ class KoopmanMPC:
             raise ValueError("dtype must be torch.float64 or torch.float32")
         self.dtype = dtype
         self.n, self.L, self.N, self.B = int(n), int(L), int(N), int(batch)
-        self.q = self.L if output == "lift" else self.n
+        self.q = self.L if output == "lift" else (int(out_rows) if out_rows else self.n)
         self.output = output
         lift_kind = {"mlp": _ffi.KMPC_LIFT_MLP, "rbf": _ffi.KMPC_LIFT_RBF_PY, "rbf_matlab": _ffi.KMPC_LIFT_RBF_MATLAB}[lift]
         cfg = _ffi.KmpcConfig(
@@ -57,7 +58,8 @@ class KoopmanMPC:
             output_kind=_ffi.KMPC_OUT_LIFT if output == "lift" else _ffi.KMPC_OUT_CX,
             dtype=_ffi.KMPC_F64 if dtype == torch.float64 else _ffi.KMPC_F32, batch=batch,
             qp_max_iter=qp_max_iter, threads=threads, lam=lam, P0=P0, barQ0=barQ0, Qw=Qw, Rw=Rw, lb=lb, ub=ub,
-            rbf_eps=rbf_eps)
+            rbf_eps=rbf_eps, delta_u=int(bool(delta_u)), out_row0=int(out_row0), out_rows=int(out_rows),
+            c_skip_first=int(bool(c_skip_first)), umin=umin, umax=umax)
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.lib.kmpc_create(C.byref(cfg), C.byref(h))
@@ -258,7 +260,7 @@ class KoopmanMPC:
     # ------------------------------------------------------------------ plant (adjacent)
     def plant_step(self, kind, X, U, h=0.05, switched=False):
         """X <- f_update(0, X, U) in place on the device (duffing.py:256-261)."""
-        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP}[kind]
+        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP, "tank": _ffi.KMPC_PLANT_TANK}[kind]
         assert X.is_cuda and X.dtype == self.dtype and X.is_contiguous()
         Uu = self._dev(U, (X.shape[1],))
         self._chk(self.lib.kmpc_plant_step(self.h, plant, self._p(X), self._p(Uu), float(h), int(bool(switched)),
@@ -271,7 +273,7 @@ class KoopmanMPC:
         (the reference flips them at the end of iteration 101).  X (n,B) device tensor, updated in place.
         self.status / self.iters receive each trajectory's worst QP status and total Newton solves.
         Returns (U_log (steps,B), X_log (steps,n,B)) when log=True."""
-        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP}[kind]
+        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP, "tank": _ffi.KMPC_PLANT_TANK}[kind]
         assert X.is_cuda and X.dtype == self.dtype and X.is_contiguous() and tuple(X.shape) == (self.n, self.B)
         rr, per = self._ref(r)
         Ul = torch.empty(steps, self.B, dtype=self.dtype, device=self.device) if log else None

@@ -400,3 +400,53 @@ class OracleController:
                                 self.N, self.lb, self.ub, self.Qw, self.Rw)
         self.prev = (psi, float(U[0]))
         return float(U[0]), U, psi
+
+
+class OracleDeltaUController:
+    """Tank_System.m loop (:170-291), restated from the MATLAB text (no Octave here: parity unpinned).
+
+    RLS of [A B] / C on z = [psi; u] as usual (:234-263; first C update only downdates bar_Q, :252-254);
+    the MPC runs on the increment form  A~ = [A B; 0 I], B~ = [B; I], C~ = [C 0], Cy = rows
+    cy0..cy0+q-1 (:110-113, 265-268), state Lift_xu = [psi(x); U0] (:290); every increment in
+    [lb, ub] = +-0.5 and the first one also inside [umin - U0, umax - U0] (:182-188);
+    U0 <- U0 + dU*(1) (:192).  Weights Q = 10, R = 1e-3 (:117-118).  Gain-form RLS (see rls_update_gain).
+    """
+
+    def __init__(self, lift, L, n, N, A0, B0, C0, cy0=1, q=1, lb=-0.5, ub=0.5, umin=-8.0, umax=8.0, P0=1e4, barQ0=1e4,
+                 Qw=10.0, Rw=1e-3, c_skip_first=True):
+        self.lift, self.L, self.n, self.N = lift, L, n, N
+        self.cy0, self.q, self.lb, self.ub, self.umin, self.umax = cy0, q, lb, ub, umin, umax
+        self.Qw, self.Rw, self.c_skip_first = Qw, Rw, c_skip_first
+        self.A, self.B, self.C = np.array(A0, float), np.array(B0, float).reshape(L, 1), np.array(C0, float)
+        self.gK, self.gP = np.zeros((L, L + 1)), P0 * np.eye(L + 1)
+        self.gC, self.gQ = np.zeros((n, L)), barQ0 * np.eye(L)
+        self.prev, self.u, self.nupd = None, 0.0, 0
+
+    def qp(self, psi):
+        L = self.L
+        At = np.block([[self.A, self.B], [np.zeros((1, L)), np.eye(1)]])
+        Bt = np.concatenate([self.B, [[1.0]]], axis=0)
+        Ct = np.concatenate([self.C, np.zeros((self.n, 1))], axis=1)
+        Co = Ct[self.cy0: self.cy0 + self.q]
+        xt = np.concatenate([psi, [self.u]])
+        return At, Bt, Co, xt
+
+    def step(self, x, r):
+        psi = self.lift(np.reshape(x, (-1, 1))).reshape(-1)
+        if self.prev is not None:
+            ppsi, pu = self.prev
+            self.gK, self.gP = rls_update_gain(self.gK, self.gP, np.concatenate([ppsi, [pu]]), psi)
+            Cn, self.gQ = rls_update_gain(self.gC, self.gQ, ppsi, np.reshape(x, -1))
+            self.gC = np.zeros_like(self.gC) if (self.c_skip_first and self.nupd == 0) else Cn
+            self.nupd += 1
+            self.A, self.B, self.C = self.gK[:, :-1].copy(), self.gK[:, -1:].copy(), self.gC.copy()
+        At, Bt, Co, xt = self.qp(psi)
+        _, _, H, f, _ = condense(At, Bt, Co, xt, r, self.N, self.Qw, self.Rw)
+        lbv = np.full(self.N, self.lb); ubv = np.full(self.N, self.ub)
+        lbv[0] = max(self.lb, self.umin - self.u)
+        ubv[0] = min(self.ub, self.umax - self.u)
+        dU, _ = qp_exact(H, f, lbv, ubv)
+        self.u = self.u + float(dU[0])
+        self.prev = (psi, self.u)
+        return self.u, dU, psi
+
