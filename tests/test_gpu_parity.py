@@ -494,8 +494,12 @@ def test_tank_delta_u_closed_loop(torch_mod, KM, lift, threads, N):
         assert (st <= 1).all(), k
         ncap += int((st == 1).sum())
         for b in range(B):
-            uo, dUo, _ = ctls[b].step(X[:, b], r)
-            worst = max(worst, abs(u[b] - uo), np.abs(dU[:, b] - dUo).max())
+            uo, dUo, psi_b = ctls[b].step(X[:, b], r)
+            At, Bt, Co, xt = ctls[b].qp(psi_b)
+            # (xt already carries the updated u; H does not depend on it)
+            Hc = ko.condense(At, Bt, Co, xt, r, N, 10.0, 1e-3)[2]
+            if np.linalg.cond(Hc) < 1e12:  # a singular H has no unique minimiser to compare with
+                worst = max(worst, abs(u[b] - uo), np.abs(dU[:, b] - dUo).max())
             ctls[b].u = float(u[b]); ctls[b].prev = (ctls[b].prev[0], float(u[b]))
         Xg = mpc.plant_step("tank", torch.tensor(X, dtype=torch.float64, device="cuda:0"), u, switched=(k > 6)).cpu().numpy()
         Xo = ko.tank_step(X, u, switched=(k > 6))
