@@ -97,14 +97,15 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     from koopmpc import KoopmanMPC, max_over_ranks
-    from koopmpc.synth import initial_states, offline_edmd, random_mlp_weights
+    from koopmpc.synth import initial_states, offline_data, random_mlp_weights
 
     L, N, B = args.L, args.N, args.batch
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     weights = random_mlp_weights(2, 100, 3, L, seed=2024)
     mpc = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev)
-    A0, B0, C0 = offline_edmd(lambda X: mpc.Encoder(X))  # one-off, identical on every rank
-    mpc.set_model(A0, B0, C0)
+    # one-off offline EDMD fit (duffing.py:152-177) on the device: lift, MFMA Gram sums, p x p solve; identical on
+    # every rank; the fitted model is handed to every trajectory
+    A0, B0, C0 = [t.cpu().numpy() for t in mpc.offline_fit(*offline_data())]
     x0 = initial_states(B, seed=101 + rank)
     X = torch.tensor(x0, dtype=dtype, device=dev).contiguous()
     r = torch.tensor(np.tile(np.array([[1.0], [0.0]]), (1, N)), dtype=dtype, device=dev)

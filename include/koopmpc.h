@@ -150,6 +150,14 @@ int kmpc_shared_solve(kmpc_handle* h, const double* delta_gram_dev, const void* 
 /* the shared model: A_dev (L x L), B_dev (L), C_dev (n x L) in the handle dtype                           */
 int kmpc_shared_get_model(kmpc_handle* h, void* A_dev, void* B_dev, void* C_dev, void* stream);
 
+/* Offline EDMD fit on the device: K_hat = PHIY pinv([PHIX; U]), C = X pinv(PHIX)
+ * (duffing.py:152-177) evaluated in Gram form M = (W V')(V V')^-1 (Koopman_update.m:94-101): lift X and Y,
+ * Gram sums on the MFMA kernel, p x p solve with the ridge `ridge` (0 reproduces the pseudo-inverse when
+ * V V' has full rank).  X_dev, Y_dev (n x M), U_dev (M).  The fitted model becomes every trajectory's
+ * model (as kmpc_set_model) and is returned in A_dev (L x L), B_dev (L), C_dev (n x L) when non-NULL.       */
+int kmpc_offline_fit(kmpc_handle* h, const void* X_dev, const void* Y_dev, const void* U_dev, int M,
+                     double ridge, void* A_dev, void* B_dev, void* C_dev, void* stream);
+
 /* ---- adjacent to the path: the plant on the device ---------------- */
 /* X <- RK4(f, X, U, h) in place: duffing.py:250-261 / vanderpol_RBF.py:113; `switched`
  * selects the parameters after step 100 (duffing.py:991-992, vanderpol.py:923-931).         */

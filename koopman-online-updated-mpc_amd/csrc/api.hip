@@ -33,6 +33,8 @@ struct kmpc_handle {
   virtual int plant_step(int plant, void* X, const void* U, double h, int sw, int B, hipStream_t s) = 0;
   virtual int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
                       void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) = 0;
+  virtual int offline_fit(const void* X, const void* Y, const void* U, int M, double ridge, void* A, void* B, void* C,
+                          hipStream_t s) = 0;
   virtual int64_t gram_elems() const = 0;
   virtual int shared_local_gram(const void* X, double* delta, hipStream_t s) = 0;
   virtual int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
@@ -449,6 +451,41 @@ struct Impl : kmpc_handle {
     cur ^= 1;
     return 0;
   }
+  int offline_fit(const void* X, const void* Y, const void* U, int M, double ridge, void* A, void* Bm, void* C,
+                  hipStream_t s) override {
+    if (!X || !Y || !U || M < 1) FAIL(-3, "kmpc_offline_fit: bad arguments");
+    int rc = shared_alloc();
+    if (rc) return rc;
+    T *px = nullptr, *py = nullptr;
+    double* g = nullptr;
+    HIPCHK(hipMalloc(&px, sizeof(T) * (size_t)L * M));
+    HIPCHK(hipMalloc(&py, sizeof(T) * (size_t)L * M));
+    HIPCHK(hipMalloc(&g, sizeof(double) * (size_t)gram_elems()));
+    rc = lift_to((const T*)X, px, M, 1, M, s);           // panels (L x M)
+    if (!rc) rc = lift_to((const T*)Y, py, M, 1, M, s);
+    if (!rc) {
+      GramArgs<T> ga{};
+      ga.B = M; ga.n = n; ga.L = L; ga.max_blocks = GRAM_BLOCKS;
+      ga.psi_prev = px; ga.pp_sl = M; ga.pp_sb = 1;
+      ga.psi_now = py; ga.pn_sl = M; ga.pn_sb = 1;
+      ga.u_prev = (const T*)U; ga.x_now = (const T*)X;  // C pairs X with PHIX (duffing.py:177)
+      ga.partial = dPartial;
+      hipError_t e = hipMemsetAsync(g, 0, sizeof(double) * (size_t)gram_elems(), s);
+      if (e == hipSuccess) e = launch_gram<T>(ga, 0.0, g, s);
+      if (e == hipSuccess) e = launch_shared_solve<T>(g, L, n, ridge, ridge, 1, dTmp, dTmp + L * p, s);
+      if (e == hipSuccess) e = launch_broadcast<T>(dK, sK, dTmp, L * p, B, s);
+      if (e == hipSuccess && cfg.output_kind == KMPC_OUT_CX) e = launch_broadcast<T>(dC, sC, dTmp + L * p, n * L, B, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(dKs, dTmp, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess) e = hipMemcpyAsync(dCs, dTmp + L * p, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice, s);
+      if (e == hipSuccess && (A || Bm || C))
+        e = launch_export_model<T>(dTmp, (long)L * p, dTmp + L * p, (long)n * L, n, L, 1, (T*)A, (T*)Bm, (T*)C, s);
+      if (e == hipSuccess) e = hipStreamSynchronize(s);
+      if (e != hipSuccess) { err = std::string("kmpc_offline_fit: ") + hipGetErrorString(e); rc = -(int)(1000 + (int)e); }
+    }
+    (void)hipFree(px); (void)hipFree(py); (void)hipFree(g);
+    return rc;
+  }
+
   int shared_get_model(void* A, void* Bm, void* C, hipStream_t s) override {
     int rc = shared_alloc();
     if (rc) return rc;
@@ -563,6 +600,7 @@ int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t
 int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
 int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NN(h); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
 int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NN(h); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
+int kmpc_offline_fit(kmpc_handle* h, const void* X, const void* Y, const void* U, int M, double ridge, void* A, void* B, void* C, void* s) { NN(h); return h->offline_fit(X, Y, U, M, ridge, A, B, C, (hipStream_t)s); }
 int64_t kmpc_gram_elems(const kmpc_handle* h) { return h ? h->gram_elems() : -1; }
 int kmpc_shared_local_gram(kmpc_handle* h, const void* X, double* delta, void* s) { NN(h); return h->shared_local_gram(X, delta, (hipStream_t)s); }
 int kmpc_shared_solve(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->shared_solve(delta, ref, U0, Useq, st, it, (hipStream_t)s); }

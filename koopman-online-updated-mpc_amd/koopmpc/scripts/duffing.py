@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from koopmpc import KoopmanMPC
-from koopmpc.synth import initial_states, offline_edmd, random_mlp_weights
+from koopmpc.synth import initial_states, offline_data, random_mlp_weights
 
 
 def main():
@@ -36,8 +36,7 @@ def main():
         weights = random_mlp_weights(2, 100, 3, Nlift)
     B, N = a.batch, a.horizon
     mpc = KoopmanMPC(n=2, L=Nlift, N=N, batch=B, weights=weights, lb=-2.0, ub=2.0)  # bounds duffing.py:636
-    A, Bm, C = offline_edmd(lambda X: mpc.Encoder(X))                              # duffing.py:152-177
-    mpc.set_model(A, Bm, C)                                                         # duffing.py:811-813
+    mpc.offline_fit(*offline_data())            # duffing.py:152-177 (fit) and :811-813 (Aloc_d, Bloc_d, Cloc_d = A, B, C)
 
     init = np.array([-2.0, -2.0])                                                   # duffing.py:649
     x0 = np.tile(init[:, None], (1, B)) if B == 1 else initial_states(B)

@@ -38,6 +38,19 @@ def vdp_rk4(x, u, h=0.05):
     return x + (h / 6.0) * (k1 + 2 * k2 + 2 * k3 + k4)
 
 
+def offline_data(plant=duffing_rk4, n_steps=100, n_traj=100, seed=101):
+    """The reference's training set (data_generate.py:17-79): 100 trajectories x 100 RK4 steps, u, x0 ~ U[-2,2]."""
+    rng = np.random.RandomState(seed)
+    U0 = 4.0 * rng.rand(n_steps, n_traj) - 2.0
+    x = 4.0 * rng.rand(2, n_traj) - 2.0
+    Xs, Ys, Us = [], [], []
+    for i in range(n_steps):
+        xn = plant(x, U0[i])
+        Xs.append(x); Ys.append(xn); Us.append(U0[i])
+        x = xn
+    return np.concatenate(Xs, 1), np.concatenate(Ys, 1), np.concatenate(Us, 0)
+
+
 def offline_edmd(lift, plant=duffing_rk4, n_steps=100, n_traj=100, seed=101):
     """The reference's one-off fit (duffing.py:152-177, data_generate.py:17-79): 100 x 100 random-input
     samples, K = PHIY pinv([PHIX; U]), C = X pinv(PHIX).  `lift` maps (n,M) -> (L,M) (the HIP Encoder)."""

@@ -449,6 +449,31 @@ def test_shared_model_two_shards_equal_one_batch(torch_mod, KM):
         X = full.plant_step("duffing", X.clone(), uf)
 
 
+def test_offline_fit_on_device_matches_pinv(torch_mod, KM):
+    """a10: the reference's one-off EDMD fit (duffing.py:152-177, pinv) done on the device in Gram form."""
+    from koopmpc.synth import offline_data, offline_edmd, random_mlp_weights
+
+    for L, wfile in ((8, "weights_duffing.npz"), (20, None)):
+        w = ko.load_mlp_weights(_load(wfile)) if wfile else random_mlp_weights(2, 100, 3, L, seed=2)
+        mpc = KM(n=2, L=L, N=10, batch=3, weights=w)
+        X, Y, U = offline_data()
+        A, Bm, C = [t.cpu().numpy() for t in mpc.offline_fit(X, Y, U)]
+        PX, PY = ko.mlp_lift(w, X), ko.mlp_lift(w, Y)
+        K = PY @ np.linalg.pinv(np.concatenate([PX, U[None, :]], 0))
+        Cn = X @ np.linalg.pinv(PX)
+        scale = np.abs(K).max()
+        # the Gram form squares the condition number of the regressor matrix: agreement ~ cond^2 * eps
+        cond = np.linalg.cond(np.concatenate([PX, U[None, :]], 0))
+        tol = max(1e-9, 50 * cond ** 2 * 2.2e-16)
+        assert np.abs(A - K[:, :L]).max() <= tol * scale and np.abs(Bm - K[:, L:]).max() <= tol * scale, (L, cond)
+        assert np.abs(C - Cn).max() <= tol * max(1.0, np.abs(Cn).max())
+        A2, B2, C2 = [t.cpu().numpy() for t in mpc.get_model()]
+        assert np.array_equal(A2[0], A) and np.array_equal(A2[2], A)  # handed to every trajectory
+        if wfile:  # the reference's own offline model (seed 101) from the golden file
+            g = _load("duffing_loop.npz")
+            assert np.abs(A - g["A0"]).max() <= tol * scale and np.abs(C - g["C0"]).max() <= tol * np.abs(g["C0"]).max()
+
+
 # ------------------------------------------------------------------ Tank_System.m: delta-u form
 @pytest.mark.parametrize("lift,threads,N", [("rbf_matlab", 0, 20), ("mlp", 0, 20), ("rbf_matlab", 256, 20), ("rbf_matlab", 0, 18)])
 def test_tank_delta_u_closed_loop(torch_mod, KM, lift, threads, N):
