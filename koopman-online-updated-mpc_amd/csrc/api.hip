@@ -266,6 +266,7 @@ struct Impl : kmpc_handle {
     a.c_skip_first = cfg.c_skip_first ? 1 : 0;
     a.umin = (T)cfg.umin; a.umax = (T)cfg.umax;
     a.u_prev = dUprev;  // delta-u reads the absolute previous input in every phase
+    a.plant = -1;
     return a;
   }
 
@@ -340,6 +341,7 @@ struct Impl : kmpc_handle {
     a.ref = (const T*)ref; a.ref_per_traj = rpt;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
     a.accumulate = accumulate ? 1 : 0;
+    if (fuse_plant >= 0) { a.plant = fuse_plant; a.plant_switched = fuse_switched; a.plant_h = (T)fuse_h; a.X_rw = (T*)const_cast<void*>(X); }
     HIPCHK(launch_step<T>(a, threads, s));
     if (rec) {
       HIPCHK(hipEventRecord(e2, s));
@@ -362,6 +364,8 @@ struct Impl : kmpc_handle {
 
   T* dU0 = nullptr;  // rollout scratch [B]
   bool accumulate = false;
+  int fuse_plant = -1, fuse_switched = 0;  // rollouts: the step kernel advances the plant itself
+  double fuse_h = 0.05;
   int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
               void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) override {
     if (!X || !ref || steps < 0) FAIL(-3, "kmpc_rollout: bad arguments");
@@ -371,11 +375,13 @@ struct Impl : kmpc_handle {
     for (int i = 0; i < steps; ++i) {
       const int gi = step0 + i;
       T* u = Ulog ? (T*)Ulog + (size_t)i * B : dU0;
+      if (n != 2) FAIL(-3, "plants are two-state systems");
+      if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
       accumulate = true;
-      int rc = step(X, ref, rpt, u, nullptr, st, it, s);
+      fuse_plant = plant; fuse_switched = (switch_step >= 0 && gi >= switch_step) ? 1 : 0; fuse_h = hs;
+      int rc = step(X, ref, rpt, u, nullptr, st, it, s);  // lift kernel + fused RLS/condense/QP/plant kernel
       accumulate = false;
-      if (rc) return rc;
-      rc = plant_step(plant, X, u, hs, (switch_step >= 0 && gi >= switch_step) ? 1 : 0, B, s);
+      fuse_plant = -1;
       if (rc) return rc;
       if (Xlog) HIPCHK(hipMemcpyAsync((T*)Xlog + (size_t)i * n * B, X, sizeof(T) * (size_t)n * B,
                                       hipMemcpyDeviceToDevice, s));

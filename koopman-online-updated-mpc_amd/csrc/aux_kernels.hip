@@ -6,40 +6,17 @@
 //             after step 100: x1' = x2, x2' = -3 x2 - 10 x1^2 x2 - 3 x1 + u  vanderpol.py:923-931
 //   RK4, h = 0.05                                                duffing.py:256-261
 #include "kernels.h"
+#include "plant_device.h"
 
 namespace kmpc {
-
-template <typename T> __device__ __forceinline__ void plant_f(int plant, int sw, T x1, T x2, T u, T& d1, T& d2) {
-  if (plant == 0) {
-    if (sw) { d1 = x2; d2 = T(-10.0) * T(0.5) * x2 + T(2.0) * x1 - T(0.5) * x1 * x1 * x1 + u; }
-    else    { d1 = x2; d2 = T(-0.5) * x2 + x1 - x1 * x1 * x1 + u; }
-  } else {
-    if (sw) { d1 = x2; d2 = T(-3.0) * x2 - T(10.0) * x1 * x1 * x2 - T(3.0) * x1 + u; }
-    else    { d1 = T(2.0) * x2; d2 = T(2.0) * x2 - T(10.0) * x1 * x1 * x2 - T(0.8) * x1 + u; }
-  }
-}
 
 template <typename T> __global__ __launch_bounds__(256) void plant_kernel(const PlantArgs<T> a) {
   const int B = a.B;
   for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < B; b += gridDim.x * blockDim.x) {
-    const T x1 = a.X[b], x2 = a.X[(size_t)B + b], u = a.U[b], h = a.h;
-    if (a.plant == 2) {
-      // cascaded tanks, a discrete map: Tank_System.m:9-10 (nominal), :194-195 (after step 100), clip at 0 :211
-      const T s1 = sqrt(x1 > T(0) ? x1 : T(0)), s2 = sqrt(x2 > T(0) ? x2 : T(0));
-      T y1, y2;
-      if (a.switched) { y1 = x1 - T(0.53) * s1 + T(0.3) * u; y2 = x2 + T(0.1) * s1 - T(0.35) * s2; }
-      else            { y1 = x1 - T(0.5) * s1 + T(0.4) * u;  y2 = x2 + T(0.2) * s1 - T(0.3) * s2; }
-      a.X[b] = y1 > T(0) ? y1 : T(0);
-      a.X[(size_t)B + b] = y2 > T(0) ? y2 : T(0);
-      continue;
-    }
-    T k1a, k1b, k2a, k2b, k3a, k3b, k4a, k4b;
-    plant_f(a.plant, a.switched, x1, x2, u, k1a, k1b);
-    plant_f(a.plant, a.switched, x1 + T(0.5) * h * k1a, x2 + T(0.5) * h * k1b, u, k2a, k2b);
-    plant_f(a.plant, a.switched, x1 + T(0.5) * h * k2a, x2 + T(0.5) * h * k2b, u, k3a, k3b);
-    plant_f(a.plant, a.switched, x1 + h * k3a, x2 + h * k3b, u, k4a, k4b);
-    a.X[b] = x1 + (h / T(6.0)) * (k1a + T(2.0) * k2a + T(2.0) * k3a + k4a);
-    a.X[(size_t)B + b] = x2 + (h / T(6.0)) * (k1b + T(2.0) * k2b + T(2.0) * k3b + k4b);
+    T x1 = a.X[b], x2 = a.X[(size_t)B + b];
+    plant_apply<T>(a.plant, a.switched, a.h, x1, x2, a.U[b]);
+    a.X[b] = x1;
+    a.X[(size_t)B + b] = x2;
   }
 }
 

@@ -25,6 +25,8 @@ struct StepArgs {
   int cy0;           // first row of C used as output (Cy selects rows cy0 .. cy0+q-1; Tank_System.m:113)
   int c_skip_first;  // Tank_System.m:252-254: the first C update only touches bar_Q
   T umin, umax;      // absolute input range, folded into the first increment's box (Tank_System.m:182-188)
+  int plant;         // >= 0: the wave also advances its trajectory's plant with u_k (rollouts): X <- f(X, u_k)
+  int plant_switched; T plant_h; T* X_rw;
   int r1, r2;        // LDS region sizes in elements (host-computed, see step_lds_elems)
   // persistent state
   T* P;   long strideP;   // [B][p*p]   inv_K_G

@@ -13,6 +13,7 @@
 // LDS map (elements of T):  X[r1] : P -> bar_Q -> H      Y[r2] : K, C -> elimination matrix
 //                           V     : vectors (RLS/condense set aliased with the QP set)
 #include "kernels.h"
+#include "plant_device.h"
 
 namespace kmpc {
 
@@ -154,27 +155,59 @@ template <typename T> __device__ __forceinline__ T allreduce8(T v) {
   return v;
 }
 
+// fast reciprocal: hardware estimate + two Newton steps (full double / float accuracy for the
+// normalised pivots met here; an IEEE-exact division costs ~10 dependent f64 ops at ~40 cycles each)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  return r;
+}
+__device__ __forceinline__ float fast_rcp(float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
+  return r;
+}
+// register fetch from another lane with a precomputed byte address (ds_bpermute_b32)
+__device__ __forceinline__ double bperm(int addr, double v) {
+  return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)),
+                          __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
+}
+__device__ __forceinline__ float bperm(int addr, float v) {
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
+}
+
 template <typename T, int N_, int KR>
 __device__ __forceinline__ void sweep_regs(T (&Tm)[(N_ + 7) / 8][(N_ + 7) / 8], int kt, bool rev, T d, int ti, int tj) {
   constexpr int RM = (N_ + 7) / 8;
-  const T dinv = T(1) / d;
-  const T sd = rev ? -dinv : dinv;
+  const T dinv = fast_rcp(d);
+  const T s = rev ? T(-1) : T(1);
   const bool rowk = (ti == kt), colk = (tj == kt);  // this lane holds row k / column k in block KR
+  const int arow = (ti * 8 + kt) << 2, acol = (kt * 8 + tj) << 2;
   T ct[RM], rt[RM];
 #pragma unroll
-  for (int r = 0; r < RM; ++r) ct[r] = __shfl(Tm[r][KR], ti * 8 + kt, 64);  // T(ti+8r, k)
+  for (int r = 0; r < RM; ++r) ct[r] = bperm(arow, Tm[r][KR]);  // T(ti+8r, k)
 #pragma unroll
-  for (int c = 0; c < RM; ++c) rt[c] = __shfl(Tm[KR][c], kt * 8 + tj, 64);  // T(k, tj+8c)
+  for (int c = 0; c < RM; ++c) rt[c] = bperm(acol, Tm[KR][c]) * dinv;  // T(k, tj+8c) / d
+  // Uniform update v = T_ij - ct_i * rt_j.  Row and column k come out of the SAME expression by
+  // editing its inputs on the lanes that hold them (exact, no cancellation):
+  //   row k    : T := 0, ct := -s             ->  v =  s T_kj / d
+  //   column k : T := 0, rt := -s / d         ->  v =  s T_ik / d
+  //   (k, k)   : both                         ->  v = -1 / d
+  if (rowk) {
+    ct[KR] = -s;
+#pragma unroll
+    for (int c = 0; c < RM; ++c) Tm[KR][c] = T(0);
+  }
+  if (colk) {
+    rt[KR] = -s * dinv;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) Tm[r][KR] = T(0);
+  }
 #pragma unroll
   for (int r = 0; r < RM; ++r)
 #pragma unroll
-    for (int c = 0; c < RM; ++c) {
-      T v = Tm[r][c] - ct[r] * (rt[c] * dinv);       // T_ij - T_ik T_kj / d
-      if (r == KR && rowk) v = rt[c] * sd;           // row k:    s T_kj / d
-      if (c == KR && colk) v = ct[r] * sd;           // column k: s T_ik / d
-      if (r == KR && c == KR && rowk && colk) v = -dinv;
-      Tm[r][c] = v;
-    }
+    for (int c = 0; c < RM; ++c) Tm[r][c] -= ct[r] * rt[c];
 }
 
 template <typename T, int N_>
@@ -357,6 +390,12 @@ __device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs
     const T uout = a.du_mode ? uprev + x : x;  // U0 = U0 + dU*(1)   (Tank_System.m:192)
     if (a.U0) a.U0[b] = uout;
     if (a.u_store) a.u_store[b] = uout;
+    if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
+      T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
+      plant_apply<T>(a.plant, a.plant_switched, a.plant_h, x1, x2, uout);
+      a.X_rw[b] = x1;
+      a.X_rw[(size_t)B + b] = x2;
+    }
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
     if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
   }
@@ -912,6 +951,12 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       const T uout = a.du_mode ? uprev + qx[0] : qx[0];
       if (a.U0) a.U0[b] = uout;
       if (a.u_store) a.u_store[b] = uout;
+      if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
+        T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
+        plant_apply<T>(a.plant, a.plant_switched, a.plant_h, x1, x2, uout);
+        a.X_rw[b] = x1;
+        a.X_rw[(size_t)B + b] = x2;
+      }
       if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
       if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
     }

@@ -21,6 +21,11 @@ psi = mpc.Encoder(X); u = mpc.step(X, r).clone()
 Xn = mpc.plant_step("duffing", X.clone(), u); psin = mpc.Encoder(Xn)
 H, f = mpc.condense(psin, r)
 U = torch.empty(N, B, dtype=torch.float64, device=dev); st = torch.empty(B, dtype=torch.int32, device=dev); it = torch.empty_like(st)
+if os.environ.get("QP_EASY"):
+    _, _, it0 = mpc.qp_solve(H, f)
+    idx = torch.nonzero(it0 <= 1).flatten()
+    idx = idx.repeat((B + idx.numel() - 1) // idx.numel())[:B]
+    H, f = H[idx].contiguous(), f[idx].contiguous()
 torch.cuda.synchronize()
 print("MARK setup done")
 for _ in range(reps):
