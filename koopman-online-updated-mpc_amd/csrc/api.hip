@@ -250,6 +250,7 @@ struct Impl : kmpc_handle {
   }
 
   int lift(const void* X, void* Psi, int Bc, hipStream_t s) override {
+    if (Bc == 0) return 0;  // empty batch: nothing to do
     if (Bc < 0 || !X || !Psi) FAIL(-3, "kmpc_lift: bad arguments");
     return lift_to((const T*)X, (T*)Psi, Bc, 1, Bc, s);
   }
@@ -303,6 +304,7 @@ struct Impl : kmpc_handle {
   }
 
   int qp_solve(const void* H, const void* f, void* U, int32_t* st, int32_t* it, int Bc, hipStream_t s) override {
+    if (Bc == 0) return 0;  // empty batch: nothing to do
     if (Bc < 0 || !H || !f || !U) FAIL(-3, "kmpc_qp_solve: bad arguments");
     if (cfg.delta_u && Bc != B) FAIL(-3, "kmpc_qp_solve: with delta_u the batch must equal the handle's (per-trajectory u_prev)");
     StepArgs<T> a = base_args(Bc);

@@ -638,6 +638,39 @@ def test_plant_kernels(torch_mod, KM):
             assert np.abs(got - want).max() < 1e-13
 
 
+def test_edge_sizes(torch_mod, KM):
+    """Empty batches are no-ops, the maximum dimensions (L = 64, N = 64) run, a batch of one works."""
+    torch = torch_mod
+    from koopmpc.synth import random_mlp_weights
+
+    w = random_mlp_weights(2, 100, 3, 8, seed=1)
+    mpc = KM(n=2, L=8, N=10, batch=1, weights=w)
+    e = torch.empty(2, 0, dtype=torch.float64, device="cuda:0")
+    assert tuple(mpc.Encoder(e).shape) == (8, 0)           # B = 0 lift: nothing launched, nothing written
+    U, st, it = mpc.qp_solve(torch.empty(0, 10, 10, dtype=torch.float64, device="cuda:0"),
+                             torch.empty(0, 10, dtype=torch.float64, device="cuda:0"))
+    assert tuple(U.shape) == (10, 0)
+    u = mpc.step(np.array([[0.5], [-0.5]]), np.tile(np.array([[1.0], [0.0]]), (1, 10)))  # batch of one, zero model
+    assert tuple(u.shape) == (1,) and float(u.abs().max()) == 0.0 and int(mpc.status[0]) == 0
+    w64 = random_mlp_weights(2, 128, 3, 64, seed=2)
+    big = KM(n=2, L=64, N=64, batch=2, weights=w64, hidden=128)
+    rng = np.random.RandomState(0)
+    A, Bm, Cm = _rand_model(rng, 64, 2)
+    big.set_model(A, Bm, Cm)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, 64))
+    X = 4 * rng.rand(2, 2) - 2
+    for k in range(3):
+        ub = big.step(X, r).cpu().numpy()
+        assert (big.status.cpu().numpy() == 0).all() and np.all(np.abs(big.Useq.cpu().numpy()) <= 2.0)
+        psi = ko.mlp_lift(w64, X)
+        Ak, Bk, Ck = [t.cpu().numpy() for t in big.get_model()]
+        for b in range(2):
+            _, _, H, f, _ = ko.condense(Ak[b], Bk[b], Ck[b], psi[:, b], r, 64)
+            kk = ko.kkt_residual(H, f, -2, 2, big.Useq.cpu().numpy()[:, b])
+            assert kk <= 1e-6 * max(1.0, np.abs(f).max())
+        X = ko.plant_step("duffing", X, ub)
+
+
 def test_errors_are_loud(torch_mod, KM):
     from koopmpc._ffi import KmpcError
 
