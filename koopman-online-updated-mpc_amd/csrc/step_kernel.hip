@@ -579,9 +579,9 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       int cur = 0;
       for (int j = 0; j <= N; ++j) {
         const T* vec = (half ? sW : sV) + cur * L;
-        // independent products + a pairwise tree: a dependent f64 FMA costs ~40 cycles on gfx950
-        // (measured, tools/ubench/valu_f64.hip), so the reduction depth matters more than the op count
-        T pr[L_];
+        // four independent FMA chains: a dependent f64 FMA costs ~40 cycles on gfx950 (tools/ubench), but with
+        // four waves per SIMD the kernel is issue-bound, so products and adds stay fused (20 FMA + 3 adds)
+        T ac4[4] = {T(0), T(0), T(0), T(0)};
         if constexpr ((L_ & 1) == 0) {
           // 16-byte broadcast reads (ds_read_b128: half the LDS cycles of the ds_read2_b64 the compiler
           // picks when it cannot prove the alignment); all LDS offsets are even in the static layout
@@ -590,17 +590,14 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
 #pragma unroll
           for (int l = 0; l < L_ / 2; ++l) {
             const T2 x2 = v2[l];
-            pr[2 * l] = row[2 * l] * x2.x;
-            pr[2 * l + 1] = row[2 * l + 1] * x2.y;
+            ac4[(2 * l) & 3] += row[2 * l] * x2.x;
+            ac4[(2 * l + 1) & 3] += row[2 * l + 1] * x2.y;
           }
         } else {
 #pragma unroll
-          for (int l = 0; l < L_; ++l) pr[l] = row[l] * vec[l];
+          for (int l = 0; l < L_; ++l) ac4[l & 3] += row[l] * vec[l];
         }
-#pragma unroll
-        for (int w2 = 1; w2 < L_; w2 *= 2)
-#pragma unroll
-          for (int l = 0; l + w2 < L_; l += 2 * w2) pr[l] += pr[l + w2];
+        T pr[1] = {(ac4[0] + ac4[1]) + (ac4[2] + ac4[3])};
         const T acc = pr[0] + (isA ? bs : T(0));
         if (half == 0) {
           if (isA && j < N) {
