@@ -25,7 +25,7 @@ static inline int imax(int a, int b) { return a > b ? a : b; }
 static inline int vec_elems(int n, int L, int q, int N) {
   const int p = L + 1;
   const int setA = 2 * p + 6 * L + n + 2 * N * q;  // sz sPz | sy sE sV(2) sW(2) | sx | sG sEr
-  const int setB = 4 * N;                          // qx qxa qg qHx
+  const int setB = 3 * N;                          // qx qxa qg
   return imax(setA, setB) + N /*sf*/ + 16 /*reduction scratch*/;
 }
 
@@ -210,8 +210,19 @@ __device__ __forceinline__ void sweep_regs(T (&Tm)[(N_ + 7) / 8][(N_ + 7) / 8], 
     for (int c = 0; c < RM; ++c) Tm[r][c] -= ct[r] * rt[c];
 }
 
+template <typename T> __device__ __forceinline__ T wave_max_x(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
+  return v;
+}
+template <typename T> __device__ __forceinline__ T wave_min_x(T v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const T w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
+  return v;
+}
+
 template <typename T, int N_>
-__device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, int b, T* red) {
+__device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, int b, T* red, T* qx_out) {
   constexpr int RM = (N_ + 7) / 8;
   const int tid = threadIdx.x, ti = tid >> 3, tj = tid & 7;
   const int myvar = ti + 8 * tj;
@@ -298,6 +309,10 @@ __device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs
     if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
     if (Bmask == 0ull) { status = 0; break; }
     if (it >= a.max_iter || refresh > 4) { status = 1; break; }
+    // Safeguard: projected Newton can crawl (tiny Armijo steps) on ill-conditioned, almost fully saturated
+    // problems; after N+10 iterations the caller finishes the solve from the current point with the
+    // active-set method of qp_lds (rare: ~4e-5 of the QPs of the cfg3-sized closed loop).
+    if (it >= N_ + 10) { status = 3; break; }
     unsigned long long Fmask = ~Imask & ownmask;
 
     bool broke = false;
@@ -383,6 +398,10 @@ __device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs
     ++it;
   }
 
+  if (status == 3) {  // hand the current point to the active-set solver
+    if (own) qx_out[myvar] = x;
+    return true;
+  }
   const int B = a.B;
   if (own) {
     if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
@@ -400,10 +419,246 @@ __device__ __forceinline__ void qp_regs(const T* sH, const T* sf, const StepArgs
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
     if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
   }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------
+// LDS-tableau box QP (run-time N <= 64, 64 or 256 threads): the generic solver, and the safeguard the
+// register solver falls back to.  Projected Newton on the swept tableau in LDS; when it crawls
+// (N+10 iterations or 2N Armijo backtracks) or when `as_from_start` is set the loop continues as a PRIMAL
+// ACTIVE-SET method on the same tableau: Newton direction on the free set, ratio test to the first blocking
+// bound, one wrong-signed multiplier released per minimiser -- monotone and finite for a strictly convex QP.
+// ---------------------------------------------------------------------------------------
+template <typename T, int TPB>
+__device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T* qxa, T* qg, T* red,
+                                       const StepArgs<T>& a, int b, int N, bool as_from_start) {
+  const int tid = threadIdx.x, B = a.B;
+  const T uprev = a.du_mode ? a.u_prev[b] : T(0);
+  T lb = a.lb, ub = a.ub;
+  const T tol = (T)Tol<T>::kkt();
+  const T eact = (T)Tol<T>::act() * (ub - lb);
+  const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
+  if (a.du_mode && tid == 0) {  // first increment: absolute input range folded in (Tank_System.m:182-188)
+    lb = (a.umin - uprev) > lb ? (a.umin - uprev) : lb;
+    ub = (a.umax - uprev) < ub ? (a.umax - uprev) : ub;
+  }
+  const T c0 = tclip(T(0), lb, ub);
+  constexpr int TS = (TPB == 64) ? 8 : 16;  // 2-D thread tile of the sweeps
+  constexpr int RMAX = 64 / TS;             // rows / columns per thread (N <= 64)
+  const int ti = tid / TS, tj = tid % TS;
+  const bool mine = tid < N;  // thread i < N owns variable i (N <= 64 <= TPB)
+  const unsigned long long allmask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
+  unsigned long long* const smask = reinterpret_cast<unsigned long long*>(red + 8);
+  T* const sval = red + 12;  // broadcast slot for wave-0 scalars (256-thread blocks)
+
+  T gs = T(1);
+  if (mine) {
+    T ra = T(0);
+    for (int j = 0; j < N; ++j) ra += tabs(sH[j * N + tid]);
+    gs = tabs(sf[tid]) + T(2) * ra * xmaxb;  // magnitude of the terms of the gradient
+    // start: clip(0) as the reference (duffing.py:634-635), or the point the register solver handed over
+    qx[tid] = as_from_start ? tclip(qx[tid], lb, ub) : c0;
+  }
+  for (int i = ti; i < N; i += TS)
+    for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
+  __syncthreads();
+  T x = mine ? qx[tid] : T(0), hx = T(0);
+  if (mine) {  // H x at the start (x need not be uniform: the first variable's box may differ)
+    for (int j = 0; j < N; ++j) hx += sH[j * N + tid] * qx[j];
+  }
+  T J0 = block_sum<T, TPB>(mine ? x * (hx + sf[tid]) : T(0), red);
+
+  unsigned long long Smask = 0ull;  // variables currently swept into T
+  unsigned long long Wmask = 0ull;  // active-set mode: variables held at a bound
+  int it = 0, status = 1, refresh = 0;
+  bool mode_as = false, at_min = false;
+
+  // every thread gets wave 0's value of a block-uniform quantity
+  auto bcast_mask = [&](unsigned long long m) -> unsigned long long {
+    if (TPB == 64) return m;
+    __syncthreads();
+    if (tid == 0) smask[0] = m;
+    __syncthreads();
+    return smask[0];
+  };
+  auto bcast_val = [&](T v) -> T {
+    if (TPB == 64) return v;
+    __syncthreads();
+    if (tid == 0) sval[0] = v;
+    __syncthreads();
+    return sval[0];
+  };
+
+  while (true) {
+    // ---- gradient, KKT residual, natural bound set
+    T g = T(0);
+    bool bad = false, inI = false;
+    if (mine) {
+      g = T(2) * hx + sf[tid];
+      const bool atl = x <= lb + eact, atu = x >= ub - eact;
+      inI = (atl && (g > T(0))) || (atu && (g < T(0)));
+      const T viol = inI ? T(0) : tabs(g);  // KKT violation in gradient units
+      const T res = tabs(x - tclip(x - g, lb, ub));
+      const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
+      bad = !((viol <= tol * gs) || (res <= tol * xs));
+    }
+    const unsigned long long Bmask = bcast_mask(__ballot(bad));  // wave 0 holds every variable (N <= 64)
+    const unsigned long long Imask = bcast_mask(__ballot(inI));
+    if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
+    if (Bmask == 0ull) { status = 0; break; }
+    if (it >= a.max_iter || refresh > 4) { status = 1; break; }
+    if (!mode_as && (as_from_start || it >= N + 10)) {
+      mode_as = true;
+      at_min = false;
+      Wmask = Imask;
+    }
+    if (mode_as && at_min) {  // x minimises the cost on the free set: release the worst wrong-signed multiplier
+      const bool inW = (Wmask >> tid) & 1ull;
+      const T vr = (mine && inW && !inI) ? tabs(g) / gs : T(0);
+      const T vmax = bcast_val(wave_max_x(vr));
+      const unsigned long long cand = bcast_mask(__ballot(mine && vr == vmax));
+      if (vmax > tol) Wmask &= ~(1ull << (__ffsll((long long)cand) - 1));
+      at_min = false;
+    }
+    unsigned long long Fmask = (mode_as ? ~Wmask : ~Imask) & allmask;
+
+    // ---- bring T to the free set: one symmetric sweep per changed variable
+    bool broke = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      unsigned long long diff = Smask ^ Fmask;
+      while (diff) {
+        const int k = __ffsll((long long)diff) - 1;
+        diff &= diff - 1ull;
+        const bool rev = (Smask >> k) & 1ull;
+        const T piv = sM[k * N + k];
+        if (!((rev ? -piv : piv) > T(0))) {  // numerical breakdown of the tableau
+          broke = true;
+          if (pass == 1) Fmask &= ~(1ull << k);  // clean rebuild: keep this variable fixed this iteration
+          continue;
+        }
+        const T dinv = T(1) / piv;
+        T rj[RMAX];  // this thread's columns of pivot row k
+#pragma unroll
+        for (int c = 0; c < RMAX; ++c) {
+          const int j = tj + c * TS;
+          rj[c] = (j < N && j != k) ? sM[k * N + j] : T(0);
+        }
+#pragma unroll
+        for (int r = 0; r < RMAX; ++r) {
+          const int i = ti + r * TS;
+          if (i < N && i != k) {
+            const T ci = sM[k * N + i] * dinv;
+#pragma unroll
+            for (int c = 0; c < RMAX; ++c) {
+              const int j = tj + c * TS;
+              if (j < N && j != k) sM[i * N + j] -= ci * rj[c];
+            }
+          }
+        }
+        __syncthreads();
+        if (mine) {
+          if (tid == k) {
+            sM[k * N + k] = -dinv;
+          } else {
+            const T v = sM[k * N + tid] * (rev ? -dinv : dinv);
+            sM[k * N + tid] = v;
+            sM[tid * N + k] = v;
+          }
+        }
+        __syncthreads();
+        Smask ^= (1ull << k);
+      }
+      if (!broke || pass == 1) break;
+      ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
+      for (int i = ti; i < N; i += TS)
+        for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
+      __syncthreads();
+      Smask = 0ull;
+    }
+    Fmask = Smask;  // what is actually swept (a variable whose pivot broke down stays fixed)
+
+    // ---- direction: Newton on F (T_FF = -(2H_FF)^-1) as a mat-vec with the masked gradient
+    const bool isF = mine && ((Fmask >> tid) & 1ull);
+    if (mine) qg[tid] = isF ? g : T(0);
+    __syncthreads();
+    T pdir = T(0);
+    if (isF) {
+      for (int j = 0; j < N; ++j) pdir += sM[j * N + tid] * qg[j];
+    } else if (mine && !mode_as) {
+      pdir = (g > T(0) ? lb : (g < T(0) ? ub : x)) - x;  // projected Newton: straight to the bound on I
+    }
+
+    T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
+    bool one_shot = false;
+    int jb = -1;
+    if (mode_as) {
+      // ratio test: the largest step along the Newton direction that keeps the free variables inside the box
+      T al = (T)1e300;
+      if (isF && pdir < T(0) && x + pdir < lb) al = (lb - x) / pdir;
+      if (isF && pdir > T(0) && x + pdir > ub) al = (ub - x) / pdir;
+      const T amin = bcast_val(wave_min_x(al));
+      alpha = amin < T(1) ? (amin > T(0) ? amin : T(0)) : T(1);
+      if (amin < T(1)) {
+        const unsigned long long cand = bcast_mask(__ballot(mine && al == amin));
+        jb = __ffsll((long long)cand) - 1;
+        Wmask |= (1ull << jb);
+      } else {
+        at_min = true;
+      }
+      one_shot = true;
+    }
+    // ---- projected Armijo search on the true cost (active-set mode: one evaluation at the ratio-test step)
+    while (true) {
+      if (mine) {
+        xa = tclip(x + alpha * pdir, lb, ub);
+        if (tid == jb) xa = pdir < T(0) ? lb : ub;  // the blocking variable sits exactly on its bound
+        qxa[tid] = xa;
+      }
+      __syncthreads();
+      T pJa = T(0), pdec = T(0);
+      if (mine) {
+        hxa = T(0);
+        for (int j = 0; j < N; ++j) hxa += sH[j * N + tid] * qxa[j];
+        pJa = xa * (hxa + sf[tid]);
+        pdec = isF ? alpha * (-g * pdir) : g * (x - xa);
+      }
+      block_sum2<T, TPB>(pJa, pdec, red);
+      Ja = pJa;
+      const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
+      if (one_shot || (J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
+      alpha *= T(0.25);
+      __syncthreads();
+    }
+    x = xa;
+    hx = hxa;
+    J0 = Ja;
+    ++it;
+  }
+  if (mine) qx[tid] = x;
+  __syncthreads();
+
+  if (mine) {
+    if (a.Useq) a.Useq[(size_t)tid * B + b] = qx[tid];
+  }
+  if (tid == 0) {
+    const T uout = a.du_mode ? uprev + qx[0] : qx[0];
+    if (a.U0) a.U0[b] = uout;
+    if (a.u_store) a.u_store[b] = uout;
+    if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
+      T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
+      plant_apply<T>(a.plant, a.plant_switched, a.plant_h, x1, x2, uout);
+      a.X_rw[b] = x1;
+      a.X_rw[(size_t)B + b] = x2;
+    }
+    if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
+    if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+  }
 }
 
 // L_, N_, Q_ != 0: dimensions fixed at compile time (every inner loop unrolls, index math folds);
 // 0: taken from the arguments at run time (generic fallback, same source).
+// Four waves per SIMD (<= 128 VGPRs) for the small static configurations: BASELINE cfg2 puts exactly 4096
+// trajectories = 4 waves per SIMD on the chip, so one register too many costs a whole second round.
 template <typename T, int TPB, int L_, int N_, int Q_>
 __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -436,7 +691,6 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   T* const qx = va;
   T* const qxa = qx + N;
   T* const qg = qxa + N;
-  T* const qHx = qg + N;
 
 
   // =====================================================================================
@@ -783,222 +1037,15 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   // in T only costs an extra (cheap) iteration.  Cold start at clip(0) as the reference
   // (duffing.py:634-635); the minimiser is unique, so the start only affects the work.
   // =====================================================================================
-  if constexpr (N_ > 0 && N_ <= 40 && TPB == 64) {
-    if (a.phases & PH_QP) qp_regs<T, N_>(sH, sf, a, b, red);
-  } else if (a.phases & PH_QP) {
-    const T uprev = a.du_mode ? a.u_prev[b] : T(0);
-    T lb = a.lb, ub = a.ub;
-    const T tol = (T)Tol<T>::kkt();
-    const T eact = (T)Tol<T>::act() * (ub - lb);
-    const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
-    if (a.du_mode && tid == 0) {  // first increment: absolute input range folded in (Tank_System.m:182-188)
-      lb = (a.umin - uprev) > lb ? (a.umin - uprev) : lb;
-      ub = (a.umax - uprev) < ub ? (a.umax - uprev) : ub;
-    }
-    const T c0 = tclip(T(0), lb, ub);
-    const int ti = (TPB == 64) ? (tid >> 3) : (tid >> 4);
-    const int tj = (TPB == 64) ? (tid & 7) : (tid & 15);
-    const int ts = (TPB == 64) ? 8 : 16;
-    const bool mine = tid < N;  // thread i < N owns variable i (N <= 64 <= TPB)
-    const unsigned long long allmask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
-    unsigned long long* const smask = reinterpret_cast<unsigned long long*>(red + 8);
-
-    // static path: thread i keeps column i of H in registers for the line-search mat-vecs
-    constexpr int NH = N_ > 0 ? N_ : 1;
-    T hcol[NH];
-    if constexpr (N_ > 0) {
-#pragma unroll
-      for (int j = 0; j < N_; ++j) hcol[j] = mine ? sH[j * N + tid] : T(0);
-    }
-    T gs = T(1);
-    if (mine) {
-      T rs = T(0), ra = T(0);
-#pragma unroll
-      for (int j = 0; j < N; ++j) {
-        T h;
-        if constexpr (N_ > 0) h = hcol[j]; else h = sH[j * N + tid];
-        rs += h;
-        ra += tabs(h);
-      }
-      gs = tabs(sf[tid]) + T(2) * ra * xmaxb;  // magnitude of the terms of the gradient
-      qx[tid] = c0;
-      (void)rs;
-    }
-    for (int i = ti; i < N; i += ts)
-      for (int j = tj; j < N; j += ts) sM[i * N + j] = T(2) * sH[i * N + j];
-    __syncthreads();
-    if (mine) {  // H x at the start (x need not be uniform: the first variable's box may differ)
-      T acc = T(0);
-      for (int j = 0; j < N; ++j) acc += sH[j * N + tid] * qx[j];
-      qHx[tid] = acc;
-    }
-    __syncthreads();
-
-    unsigned long long Smask = 0ull;  // variables currently swept into T
-    int it = 0, status = 1, refresh = 0;
-    constexpr int TS = (TPB == 64) ? 8 : 16;   // 2-D thread tile of the sweeps
-    constexpr int RMAX = N_ > 0 ? (N_ + TS - 1) / TS : 64 / TS;  // rows / columns per thread
-
-    // cost at the start  J = x'(Hx + f)
-    T x = mine ? qx[tid] : T(0);
-    T hx = mine ? qHx[tid] : T(0);
-    T J0 = block_sum<T, TPB>(mine ? x * (hx + sf[tid]) : T(0), red);
-
-    while (true) {
-      // ---- gradient, KKT residual, bound set (all per-variable, no reduction needed)
-      T g = T(0);
-      bool bad = false, inI = false;
-      if (mine) {
-        g = T(2) * hx + sf[tid];
-        const bool atl = x <= lb + eact, atu = x >= ub - eact;
-        inI = (atl && (g > T(0))) || (atu && (g < T(0)));
-        const T viol = inI ? T(0) : tabs(g);  // KKT violation in gradient units
-        const T res = tabs(x - tclip(x - g, lb, ub));
-        const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
-        bad = !((viol <= tol * gs) || (res <= tol * xs));
-      }
-      unsigned long long Bmask = __ballot(bad);
-      unsigned long long Imask = __ballot(inI);  // wave 0 holds every variable (N <= 64)
-      if (TPB > 64) {
+  if (a.phases & PH_QP) {
+    if constexpr (N_ > 0 && N_ <= 40 && TPB == 64) {
+      // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
+      if (qp_regs<T, N_>(sH, sf, a, b, red, qx)) {
         __syncthreads();
-        if (tid == 0) { smask[0] = Imask; smask[1] = Bmask; }
-        __syncthreads();
-        Imask = smask[0];
-        Bmask = smask[1];
+        qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, b, N, true);
       }
-      if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
-      if (Bmask == 0ull) { status = 0; break; }
-      if (it >= a.max_iter || refresh > 4) { status = 1; break; }
-      unsigned long long Fmask = ~Imask & allmask;
-
-      // ---- bring T to the new free set: one symmetric sweep per changed variable
-      bool broke = false;
-      for (int pass = 0; pass < 2; ++pass) {
-        unsigned long long diff = Smask ^ Fmask;
-        while (diff) {
-          const int k = __ffsll((long long)diff) - 1;
-          diff &= diff - 1ull;
-          const bool rev = (Smask >> k) & 1ull;
-          const T piv = sM[k * N + k];
-          if (!((rev ? -piv : piv) > T(0))) {  // numerical breakdown of the tableau
-            broke = true;
-            if (pass == 1) Fmask &= ~(1ull << k);  // clean rebuild: keep this variable fixed this iteration
-            continue;
-          }
-          const T dinv = T(1) / piv;
-          T rj[RMAX];  // this thread's columns of pivot row k
-#pragma unroll
-          for (int c = 0; c < RMAX; ++c) {
-            const int j = tj + c * TS;
-            rj[c] = (j < N && j != k) ? sM[k * N + j] : T(0);
-          }
-#pragma unroll
-          for (int r = 0; r < RMAX; ++r) {
-            const int i = ti + r * TS;
-            if (i < N && i != k) {
-              const T ci = sM[k * N + i] * dinv;
-#pragma unroll
-              for (int c = 0; c < RMAX; ++c) {
-                const int j = tj + c * TS;
-                if (j < N && j != k) sM[i * N + j] -= ci * rj[c];
-              }
-            }
-          }
-          __syncthreads();
-          if (mine) {
-            if (tid == k) {
-              sM[k * N + k] = -dinv;
-            } else {
-              const T v = sM[k * N + tid] * (rev ? -dinv : dinv);
-              sM[k * N + tid] = v;
-              sM[tid * N + k] = v;
-            }
-          }
-          __syncthreads();
-          Smask ^= (1ull << k);
-        }
-        if (!broke || pass == 1) break;
-        // rebuild T = 2H and sweep the free set in from scratch
-        ++refresh;
-        for (int i = ti; i < N; i += TS)
-          for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
-        __syncthreads();
-        Smask = 0ull;
-      }
-      Fmask = Smask;  // what is actually swept (a variable whose pivot broke down stays fixed)
-
-      // ---- direction: Newton on F (T_FF = -(2H_FF)^-1) as a mat-vec with the masked gradient,
-      //      straight to the bound on I
-      const bool isF = mine && ((Fmask >> tid) & 1ull);
-      if (mine) qg[tid] = isF ? g : T(0);
-      __syncthreads();
-      T pdir = T(0);
-      if (mine) {
-        if (isF) {
-#pragma unroll
-          for (int j = 0; j < N; ++j) pdir += sM[j * N + tid] * qg[j];
-        } else {
-          pdir = (g > T(0) ? lb : (g < T(0) ? ub : x)) - x;
-        }
-      }
-
-      // ---- projected Armijo search on the true cost (one fused two-value reduction per trial)
-      T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
-      while (true) {
-        if (mine) {
-          xa = tclip(x + alpha * pdir, lb, ub);
-          qxa[tid] = xa;
-        }
-        __syncthreads();
-        T pJa = T(0), pdec = T(0);
-        if (mine) {
-          hxa = T(0);
-          if constexpr (N_ > 0) {
-            T h1 = T(0);
-#pragma unroll
-            for (int j = 0; j + 1 < N_; j += 2) {
-              hxa += hcol[j] * qxa[j];
-              h1 += hcol[j + 1] * qxa[j + 1];
-            }
-            if (N_ & 1) hxa += hcol[N_ - 1] * qxa[N_ - 1];
-            hxa += h1;
-          } else {
-#pragma unroll
-            for (int j = 0; j < N; ++j) hxa += sH[j * N + tid] * qxa[j];
-          }
-          pJa = xa * (hxa + sf[tid]);
-          pdec = isF ? alpha * (-g * pdir) : g * (x - xa);
-        }
-        block_sum2<T, TPB>(pJa, pdec, red);
-        Ja = pJa;
-        const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
-        if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
-        alpha *= T(0.25);
-        __syncthreads();
-      }
-      x = xa;
-      hx = hxa;
-      J0 = Ja;
-      ++it;
-    }
-    if (mine) qx[tid] = x;
-    __syncthreads();
-
-    if (mine) {
-      if (a.Useq) a.Useq[(size_t)tid * B + b] = qx[tid];
-    }
-    if (tid == 0) {
-      const T uout = a.du_mode ? uprev + qx[0] : qx[0];
-      if (a.U0) a.U0[b] = uout;
-      if (a.u_store) a.u_store[b] = uout;
-      if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
-        T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
-        plant_apply<T>(a.plant, a.plant_switched, a.plant_h, x1, x2, uout);
-        a.X_rw[b] = x1;
-        a.X_rw[(size_t)B + b] = x2;
-      }
-      if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
-      if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+    } else {
+      qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, b, N, false);
     }
   }
 }

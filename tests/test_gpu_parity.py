@@ -242,6 +242,23 @@ def test_qp_random_mpc_problems(torch_mod, KM, L, N, q, rho, threads):
     assert nsat > 0  # the set contains saturated solutions
 
 
+def test_qp_instances_where_projected_newton_crawls(torch_mod, KM):
+    """QPs recorded from a closed loop (L = 8, N = 30, cond(H) ~ 2e6, 27-28 of 30 inputs saturated) on which
+    plain projected Newton needs hundreds of tiny Armijo steps: the active-set safeguard must finish them
+    (status 0) at the exact minimiser, on the register solver (static N = 30) and on the LDS solver."""
+    d = _load("qp_hard_instances.npz")
+    H, f = d["H"], d["f"]
+    for threads in (0, 256):
+        mpc = KM(n=2, L=8, N=30, batch=1, lift="rbf", centres=np.zeros((8, 2)), threads=threads)
+        U, st, it = mpc.qp_solve(H, f)
+        U, st, it = U.cpu().numpy(), st.cpu().numpy(), it.cpu().numpy()
+        assert (st == 0).all(), (threads, st, it)
+        for k in range(len(H)):
+            Uo, _ = ko.qp_exact(H[k], f[k], -2.0, 2.0)
+            assert np.abs(U[:, k] - Uo).max() <= 1e-7, (threads, k)
+        assert it.max() < 8 * 30 + 40  # finished well before the cap
+
+
 def test_qp_edge_cases_and_status(torch_mod, KM):
     mpc = KM(n=2, L=8, N=2, batch=1, lift="rbf", centres=np.zeros((8, 2)))
     H = np.array([[2.0, 0.5], [0.5, 1.0]])
