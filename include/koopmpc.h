@@ -154,9 +154,13 @@ int kmpc_shared_get_model(kmpc_handle* h, void* A_dev, void* B_dev, void* C_dev,
  * (duffing.py:152-177) evaluated in Gram form M = (W V')(V V')^-1 (Koopman_update.m:94-101): lift X and Y,
  * Gram sums on the MFMA kernel, p x p solve with the ridge `ridge` (0 reproduces the pseudo-inverse when
  * V V' has full rank).  X_dev, Y_dev (n x M), U_dev (M).  The fitted model becomes every trajectory's
- * model (as kmpc_set_model) and is returned in A_dev (L x L), B_dev (L), C_dev (n x L) when non-NULL.       */
+ * model (as kmpc_set_model) and is returned in A_dev (L x L), B_dev (L), C_dev (n x L) when non-NULL.
+ * init_rls = 1 additionally starts every trajectory's online RLS FROM the offline data, as the MATLAB twin
+ * does (K_A = Ylift V', inv_K_G = pinv(V V'), Koopman_update.m:258-278): P = (V V')^-1, bar_Q =
+ * (Xlift Xlift')^-1, and the first online update refines the fitted model instead of restarting from
+ * K_A = 0 (the Python scripts' behaviour, duffing.py:927-930, which init_rls = 0 keeps).                    */
 int kmpc_offline_fit(kmpc_handle* h, const void* X_dev, const void* Y_dev, const void* U_dev, int M,
-                     double ridge, void* A_dev, void* B_dev, void* C_dev, void* stream);
+                     double ridge, int init_rls, void* A_dev, void* B_dev, void* C_dev, void* stream);
 
 /* ---- adjacent to the path: the plant on the device ---------------- */
 /* X <- RK4(f, X, U, h) in place: duffing.py:250-261 / vanderpol_RBF.py:113; `switched`

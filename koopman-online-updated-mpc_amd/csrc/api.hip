@@ -33,8 +33,8 @@ struct kmpc_handle {
   virtual int plant_step(int plant, void* X, const void* U, double h, int sw, int B, hipStream_t s) = 0;
   virtual int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
                       void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) = 0;
-  virtual int offline_fit(const void* X, const void* Y, const void* U, int M, double ridge, void* A, void* B, void* C,
-                          hipStream_t s) = 0;
+  virtual int offline_fit(const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A,
+                          void* B, void* C, hipStream_t s) = 0;
   virtual int64_t gram_elems() const = 0;
   virtual int shared_local_gram(const void* X, double* delta, hipStream_t s) = 0;
   virtual int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
@@ -459,13 +459,14 @@ struct Impl : kmpc_handle {
     cur ^= 1;
     return 0;
   }
-  int offline_fit(const void* X, const void* Y, const void* U, int M, double ridge, void* A, void* Bm, void* C,
-                  hipStream_t s) override {
+  int offline_fit(const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A, void* Bm,
+                  void* C, hipStream_t s) override {
     if (!X || !Y || !U || M < 1) FAIL(-3, "kmpc_offline_fit: bad arguments");
     int rc = shared_alloc();
     if (rc) return rc;
-    T *px = nullptr, *py = nullptr;
+    T *px = nullptr, *py = nullptr, *pinv = nullptr;
     double* g = nullptr;
+    if (init_rls) HIPCHK(hipMalloc(&pinv, sizeof(T) * (size_t)(p * p + L * L)));
     HIPCHK(hipMalloc(&px, sizeof(T) * (size_t)L * M));
     HIPCHK(hipMalloc(&py, sizeof(T) * (size_t)L * M));
     HIPCHK(hipMalloc(&g, sizeof(double) * (size_t)gram_elems()));
@@ -480,7 +481,14 @@ struct Impl : kmpc_handle {
       ga.partial = dPartial;
       hipError_t e = hipMemsetAsync(g, 0, sizeof(double) * (size_t)gram_elems(), s);
       if (e == hipSuccess) e = launch_gram<T>(ga, 0.0, g, s);
-      if (e == hipSuccess) e = launch_shared_solve<T>(g, L, n, ridge, ridge, 1, dTmp, dTmp + L * p, s);
+      if (e == hipSuccess)
+        e = launch_shared_solve<T>(g, L, n, ridge, ridge, 1, dTmp, dTmp + L * p, s, pinv, pinv ? pinv + p * p : nullptr);
+      if (e == hipSuccess && init_rls) {
+        // the online RLS continues from the offline data: K_A = Ylift V', inv_K_G = pinv(V V')
+        // (Koopman_update.m:258-278) -- in gain form: K = offline [A B], P = (V V')^-1
+        e = launch_broadcast<T>(dP, sP, pinv, p * p, B, s);
+        if (e == hipSuccess) e = launch_broadcast<T>(dQ, sQ, pinv + p * p, L * L, B, s);
+      }
       if (e == hipSuccess) e = launch_broadcast<T>(dK, sK, dTmp, L * p, B, s);
       if (e == hipSuccess && cfg.output_kind == KMPC_OUT_CX) e = launch_broadcast<T>(dC, sC, dTmp + L * p, n * L, B, s);
       if (e == hipSuccess) e = hipMemcpyAsync(dKs, dTmp, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice, s);
@@ -491,6 +499,8 @@ struct Impl : kmpc_handle {
       if (e != hipSuccess) { err = std::string("kmpc_offline_fit: ") + hipGetErrorString(e); rc = -(int)(1000 + (int)e); }
     }
     (void)hipFree(px); (void)hipFree(py); (void)hipFree(g);
+    if (pinv) (void)hipFree(pinv);
+    if (!rc && init_rls) rls_fresh = false;  // the first online update refines this model instead of restarting from K_A = 0
     return rc;
   }
 
@@ -608,7 +618,7 @@ int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t
 int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
 int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NN(h); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
 int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NN(h); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
-int kmpc_offline_fit(kmpc_handle* h, const void* X, const void* Y, const void* U, int M, double ridge, void* A, void* B, void* C, void* s) { NN(h); return h->offline_fit(X, Y, U, M, ridge, A, B, C, (hipStream_t)s); }
+int kmpc_offline_fit(kmpc_handle* h, const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A, void* B, void* C, void* s) { NN(h); return h->offline_fit(X, Y, U, M, ridge, init_rls, A, B, C, (hipStream_t)s); }
 int64_t kmpc_gram_elems(const kmpc_handle* h) { return h ? h->gram_elems() : -1; }
 int kmpc_shared_local_gram(kmpc_handle* h, const void* X, double* delta, void* s) { NN(h); return h->shared_local_gram(X, delta, (hipStream_t)s); }
 int kmpc_shared_solve(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->shared_solve(delta, ref, U0, Useq, st, it, (hipStream_t)s); }

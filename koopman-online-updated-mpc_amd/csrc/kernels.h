@@ -90,7 +90,8 @@ template <typename T> hipError_t launch_fill_state(T* P, long strideP, int p, T 
 hipError_t launch_axpby(double* g, const double* d, double a, int count, hipStream_t s);
 template <typename T> hipError_t launch_gram(const GramArgs<T>& a, double forget, double* gram, hipStream_t s);
 template <typename T> hipError_t launch_shared_solve(const double* gram, int L, int n, double dP, double dQ, int use_C,
-                                                     T* Kout, T* Cout, hipStream_t s);
+                                                     T* Kout, T* Cout, hipStream_t s, T* Pout = nullptr,
+                                                     T* Qout = nullptr);
 template <typename T> hipError_t launch_shared_condense(const T* K, const T* C, const T* ref, int L, int n, int q, int N,
                                                         int out_kind, double Qw, double Rw, T* Hout, T* Fout, T* f0out,
                                                         hipStream_t s);

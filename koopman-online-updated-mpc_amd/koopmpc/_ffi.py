@@ -48,7 +48,7 @@ SIGNATURES = {
     "kmpc_condense": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP]),
     "kmpc_qp_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "kmpc_step": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
-    "kmpc_offline_fit": (_I, [_VP, _VP, _VP, _VP, _I, _D, _VP, _VP, _VP, _VP]),
+    "kmpc_offline_fit": (_I, [_VP, _VP, _VP, _VP, _I, _D, _I, _VP, _VP, _VP, _VP]),
     "kmpc_gram_elems": (_I64, [_VP]),
     "kmpc_shared_local_gram": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_shared_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),

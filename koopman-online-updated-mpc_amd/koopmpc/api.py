@@ -121,10 +121,11 @@ class KoopmanMPC:
         cp = _dptr(Cm) if Cm is not None else None
         self._chk(self.lib.kmpc_set_model(self.h, _dptr(A), _dptr(Bv), cp), "kmpc_set_model")
 
-    def offline_fit(self, X, Y, U, ridge=0.0):
+    def offline_fit(self, X, Y, U, ridge=0.0, init_rls=False):
         """K_hat = PHIY pinv([PHIX; U]), C = X pinv(PHIX) (duffing.py:152-177) on the device in Gram form
         (Koopman_update.m:94-101): lift, MFMA Gram sums, p x p solve.  X, Y (n, M), U (M,).  The result
-        becomes every trajectory's model; returns (A, B, C) as device tensors."""
+        becomes every trajectory's model; returns (A, B, C) as device tensors.  init_rls=True also starts
+        the online RLS from the offline data as Koopman_update.m:258-278 does (inv_K_G = pinv(V V'))."""
         Xd = self._dev(X, (self.n, -1))
         M = Xd.shape[1]
         Yd = self._dev(Y, (self.n, M))
@@ -132,7 +133,7 @@ class KoopmanMPC:
         A = torch.empty(self.L, self.L, dtype=self.dtype, device=self.device)
         Bm = torch.empty(self.L, 1, dtype=self.dtype, device=self.device)
         Cm = torch.empty(self.n, self.L, dtype=self.dtype, device=self.device)
-        self._chk(self.lib.kmpc_offline_fit(self.h, self._p(Xd), self._p(Yd), self._p(Ud), M, float(ridge), self._p(A),
+        self._chk(self.lib.kmpc_offline_fit(self.h, self._p(Xd), self._p(Yd), self._p(Ud), M, float(ridge), int(bool(init_rls)), self._p(A),
                                             self._p(Bm), self._p(Cm), self._stream()), "kmpc_offline_fit")
         return A, Bm, Cm
 

@@ -491,6 +491,43 @@ def test_offline_fit_on_device_matches_pinv(torch_mod, KM):
             assert np.abs(A - g["A0"]).max() <= tol * scale and np.abs(C - g["C0"]).max() <= tol * np.abs(g["C0"]).max()
 
 
+def test_rls_continues_from_offline_gram(torch_mod, KM):
+    """MATLAB twin semantics (Koopman_update.m:258-278): the online RLS starts from K_A = Ylift V',
+    inv_K_G = pinv(V V') of the OFFLINE data, so after k online samples the model is the least-squares fit of
+    offline + online data together (checked against the oracle's Gram-form fit of the pooled data)."""
+    from koopmpc.synth import offline_data, random_mlp_weights
+
+    L, B = 8, 3
+    w = ko.load_mlp_weights(_load("weights_duffing.npz"))
+    mpc = KM(n=2, L=L, N=10, batch=B, weights=w)
+    X, Y, U = offline_data()
+    mpc.offline_fit(X, Y, U, init_rls=True)
+    PX, PY = ko.mlp_lift(w, X), ko.mlp_lift(w, Y)
+    sh = ko.SharedEdmd(L, 2, P0=1e300, barQ0=1e300)  # no ridge: pinv of full-rank Grams
+    G, YZ, _ = ko.SharedEdmd.gram(PX, U, PY, Y)
+    sh.add(G, YZ, X @ np.concatenate([PX, U[None, :]], 0).T)  # C pairs X with PHIX (duffing.py:177)
+    rng = np.random.RandomState(1)
+    x = 4 * rng.rand(2, B) - 2
+    for k in range(5):
+        u = 4 * rng.rand(B) - 2
+        xn = ko.plant_step("duffing", x, u)
+        psi, psin = ko.mlp_lift(w, x), ko.mlp_lift(w, xn)
+        A_, B_, C_ = [t.cpu().numpy() for t in mpc.Koopman_update(psi, u, psin, xn)]
+        for b in range(B):  # every trajectory refines its own copy with its own samples
+            shb = ko.SharedEdmd(L, 2, P0=1e300, barQ0=1e300)
+            shb.G, shb.YZ, shb.XZ = sh.G.copy(), sh.YZ.copy(), sh.XZ.copy()
+            if k == 0:
+                hist = [[] for _ in range(B)] if b == 0 else hist
+            hist[b].append((psi[:, b:b + 1], u[b:b + 1], psin[:, b:b + 1], xn[:, b:b + 1]))
+            for (p0, u0, p1, x1) in hist[b]:
+                shb.add(*ko.SharedEdmd.gram(p0, u0, p1, x1))
+            Ao, Bo, Co = shb.model()
+            scale = max(np.abs(Ao).max(), np.abs(Bo).max())
+            assert np.abs(A_[b] - Ao).max() <= 1e-6 * scale and np.abs(B_[b] - Bo).max() <= 1e-6 * scale, (k, b)
+            assert np.abs(C_[b] - Co).max() <= 1e-6 * max(1.0, np.abs(Co).max()), (k, b)
+        x = xn
+
+
 # ------------------------------------------------------------------ Tank_System.m: delta-u form
 @pytest.mark.parametrize("lift,threads,N", [("rbf_matlab", 0, 20), ("mlp", 0, 20), ("rbf_matlab", 256, 20), ("rbf_matlab", 0, 18)])
 def test_tank_delta_u_closed_loop(torch_mod, KM, lift, threads, N):

@@ -168,3 +168,29 @@ def test_synth_workload_is_deterministic():
     assert np.abs(a[1][0]).max() <= 0.1 + 1e-12
     x = initial_states(4096)
     assert x.shape == (2, 4096) and np.abs(x).max() <= 2.0
+
+
+def test_mat_io_roundtrip(tmp_path):
+    """.mat compatibility with the reference's weight files and log dumps (Encoder_Duffing.m:2-6, duffing.py:61-64, :1015)."""
+    import scipy.io as sio
+
+    from koopmpc import io as kio
+    from koopmpc.synth import random_mlp_weights
+
+    w = random_mlp_weights(2, 100, 3, 8)
+    f = str(tmp_path / "weights.mat")
+    kio.save_encoder_mat(f, w)
+    d = sio.loadmat(f)
+    assert d["W1"].shape == (100, 2) and d["b1"].shape == (1, 100) and d["W4"].shape == (8, 100)  # the reference's layout
+    w2 = kio.load_encoder_mat(f)
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) for a, b in zip(w, w2))
+    # the committed golden weights came from the reference's .mat: same loader semantics as the oracle's
+    g = np.load(os.path.join(ROOT, "tests", "golden", "weights_tank.npz"))
+    kio.save_encoder_mat(f, [(g["W%d" % k], g["b%d" % k]) for k in (1, 2, 3)])
+    assert len(kio.load_encoder_mat(f)) == 3
+    logX, logU = np.random.rand(7, 2, 3), np.random.rand(7, 3)
+    f2 = str(tmp_path / "DuffingPlotrealtime.mat")
+    kio.save_closed_loop_mat(f2, logX, logU, r=np.array([[1.0], [0.0]]) * np.ones((1, 10)), traj=1)
+    d = sio.loadmat(f2)
+    assert d["logXloc"].shape == (2, 7) and d["logUloc"].shape == (1, 7) and d["logR"].shape == (2, 7)
+    assert np.array_equal(d["logXloc"][:, 3], logX[3, :, 1]) and np.allclose(d["tspan"].ravel(), 0.05 * np.arange(7))
