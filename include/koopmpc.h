@@ -92,6 +92,12 @@ int kmpc_set_centres(kmpc_handle* h, const double* cx_host, int L, int n);
  * (duffing.py:811-813).  A (L x L), B (L), C (n x L; ignored for KMPC_OUT_LIFT); broadcast
  * to every trajectory.                                                                      */
 int kmpc_set_model(kmpc_handle* h, const double* A_host, const double* B_host, const double* C_host);
+
+/* Optional terminal weight: the last q x q block of Q_bar becomes PN instead of Qw*I
+ * (Q_bar(end-n+1:end, end-n+1:end) = C*P*C', Koopman_update.m:381; the LMI that produces P there is host
+ * work and out of scope).  PN: host, q x q row-major (q = output rows); shared by all trajectories; NULL
+ * restores Qw*I.  Applies to kmpc_condense / kmpc_step / kmpc_rollout and the shared-model mode.          */
+int kmpc_set_terminal_weight(kmpc_handle* h, const double* PN);
 /* re-initialise the online state: K_A = 0, inv_K_G = P0 I, bar_X = 0, bar_Q = barQ0 I and
  * forget the previous transition (duffing.py:927-930, 944-946)                              */
 int kmpc_reset(kmpc_handle* h, void* stream);

@@ -22,6 +22,7 @@ struct kmpc_handle {
   virtual int set_encoder_layer(int layer, const double* W, const double* b, int rows, int cols) = 0;
   virtual int set_centres(const double* cx, int L, int n) = 0;
   virtual int set_model(const double* A, const double* B, const double* C) = 0;
+  virtual int set_terminal_weight(const double* PN) = 0;
   virtual int reset(hipStream_t s) = 0;
   virtual int lift(const void* X, void* Psi, int B, hipStream_t s) = 0;
   virtual int rls_update(const void* psi, const void* u, const void* psin, const void* xn, int B, hipStream_t s) = 0;
@@ -144,7 +145,7 @@ struct Impl : kmpc_handle {
     for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev,
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
-                      (void*)dHs, (void*)dFs, (void*)df0s})
+                      (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -212,6 +213,17 @@ struct Impl : kmpc_handle {
     return 0;
   }
 
+  int set_terminal_weight(const double* PN) override {
+    if (!PN) { have_wterm = false; return 0; }
+    std::vector<T> w((size_t)q * q);
+    for (int r = 0; r < q; ++r)
+      for (int c2 = 0; c2 < q; ++c2) w[(size_t)r * q + c2] = (T)(PN[(size_t)r * q + c2] - (r == c2 ? cfg.Qw : 0.0));
+    if (!dWt) HIPCHK(hipMalloc(&dWt, sizeof(T) * (size_t)q * q));
+    HIPCHK(hipMemcpy(dWt, w.data(), w.size() * sizeof(T), hipMemcpyHostToDevice));
+    have_wterm = true;
+    return 0;
+  }
+
   int reset(hipStream_t s) override {
     if (dGram) HIPCHK(hipMemsetAsync(dGram, 0, sizeof(double) * (size_t)gram_elems(), s));
     shared_has_samples = false;
@@ -261,6 +273,7 @@ struct Impl : kmpc_handle {
     a.out_kind = cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX;
     a.max_iter = cfg.qp_max_iter > 0 ? cfg.qp_max_iter : 8 * N + 40;
     a.P = dP; a.strideP = sP; a.K = dK; a.strideK = sK; a.Qb = dQ; a.strideQ = sQ; a.C = dC; a.strideC = sC;
+    a.Wterm = have_wterm ? dWt : nullptr;
     a.lam = (T)cfg.lambda; a.Qw = (T)cfg.Qw; a.Rw = (T)cfg.Rw; a.lb = (T)cfg.lb; a.ub = (T)cfg.ub;
     a.du_mode = cfg.delta_u ? 1 : 0;
     a.cy0 = cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0;
@@ -394,6 +407,8 @@ struct Impl : kmpc_handle {
   // ---- shared-model mode -----------------------------------------------------------------------------
   double *dGram = nullptr, *dPartial = nullptr;
   T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr;
+  T* dWt = nullptr;  // PN - Qw I (terminal block of Q_bar)
+  bool have_wterm = false;
   bool shared_has_samples = false;
   static constexpr int GRAM_BLOCKS = 256;
   int64_t gram_elems() const override { return (int64_t)(p + L + n) * p; }
@@ -448,7 +463,7 @@ struct Impl : kmpc_handle {
     }
     HIPCHK(launch_shared_condense<T>(dKs, dCs, (const T*)ref, L, n, q, N,
                                      cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX, cfg.Qw, cfg.Rw, dHs, dFs,
-                                     df0s, s));
+                                     df0s, s, have_wterm ? dWt : nullptr));
     StepArgs<T> a = base_args(B);
     a.phases = PH_QP;
     a.H_in = dHs; a.h_shared = 1; a.F_in = dFs; a.f0_in = df0s;
@@ -609,6 +624,7 @@ const char* kmpc_last_error(const kmpc_handle* h) { return h ? h->err.c_str() : 
 int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { NN(h); return h->set_encoder_layer(layer, W, b, rows, cols); }
 int kmpc_set_centres(kmpc_handle* h, const double* cx, int L, int n) { NN(h); return h->set_centres(cx, L, n); }
 int kmpc_set_model(kmpc_handle* h, const double* A, const double* B, const double* C) { NN(h); return h->set_model(A, B, C); }
+int kmpc_set_terminal_weight(kmpc_handle* h, const double* PN) { NN(h); return h->set_terminal_weight(PN); }
 int kmpc_reset(kmpc_handle* h, void* s) { NN(h); return h->reset((hipStream_t)s); }
 int kmpc_lift(kmpc_handle* h, const void* X, void* Psi, int B, void* s) { NN(h); return h->lift(X, Psi, B, (hipStream_t)s); }
 int kmpc_rls_update(kmpc_handle* h, const void* psi, const void* u, const void* psin, const void* xn, int B, void* s) { NN(h); return h->rls_update(psi, u, psin, xn, B, (hipStream_t)s); }

@@ -49,6 +49,7 @@ struct StepArgs {
   T* U0;             // [B] or null
   T* u_store;        // [B] handle copy of u_k for the next RLS update, or null
   int32_t* status; int32_t* iters;
+  const T* Wterm;  // q x q, PN - Qw I: terminal block of Q_bar (Koopman_update.m:381), or null
   T lam, Qw, Rw, lb, ub;
 };
 
@@ -94,7 +95,7 @@ template <typename T> hipError_t launch_shared_solve(const double* gram, int L, 
                                                      T* Qout = nullptr);
 template <typename T> hipError_t launch_shared_condense(const T* K, const T* C, const T* ref, int L, int n, int q, int N,
                                                         int out_kind, double Qw, double Rw, T* Hout, T* Fout, T* f0out,
-                                                        hipStream_t s);
+                                                        hipStream_t s, const T* Wterm = nullptr);
 template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s);
 template <typename T> hipError_t launch_export_model(const T* K, long strideK, const T* C, long strideC, int n, int L,
                                                      int B, T* A_out, T* B_out, T* C_out, hipStream_t s);

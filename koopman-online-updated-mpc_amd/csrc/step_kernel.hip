@@ -1000,6 +1000,28 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
         sf[aa] = T(2) * a.Qw * acc;
       }
     }
+    if (a.Wterm) {
+      // terminal block of Q_bar is PN instead of Qw I (Koopman_update.m:381); Wterm = PN - Qw I:
+      //   H[a][b] += g_{N-1-a}' sym(W) g_{N-1-b},   f[a] += 2 g_{N-1-a}' W e_N
+      __syncthreads();
+      for (int e = tid; e < N * N; e += TPB) {
+        const int aa = e / N, bb = e - aa * N;
+        const T* ga = sG + (N - 1 - aa) * q;
+        const T* gb = sG + (N - 1 - bb) * q;
+        T acc = T(0);
+        for (int r = 0; r < q; ++r)
+          for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * (T(0.5) * (a.Wterm[r * q + s2] + a.Wterm[s2 * q + r])) * gb[s2];
+        sH[e] += acc;
+      }
+      for (int aa = tid; aa < N; aa += TPB) {
+        const T* ga = sG + (N - 1 - aa) * q;
+        const T* eN = sEr + (N - 1) * q;
+        T acc = T(0);
+        for (int r = 0; r < q; ++r)
+          for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * a.Wterm[r * q + s2] * eN[s2];
+        sf[aa] += T(2) * acc;
+      }
+    }
     __syncthreads();
     if (a.H_out) {
       T* Hg = a.H_out + (size_t)b * N * N;

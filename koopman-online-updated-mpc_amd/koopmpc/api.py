@@ -121,6 +121,17 @@ class KoopmanMPC:
         cp = _dptr(Cm) if Cm is not None else None
         self._chk(self.lib.kmpc_set_model(self.h, _dptr(A), _dptr(Bv), cp), "kmpc_set_model")
 
+    def set_terminal_weight(self, PN=None):
+        """Q_bar(end-n+1:end, end-n+1:end) = C*P*C'  (Koopman_update.m:381): PN (q, q) replaces the last
+        Qw*I block of the output weight; None restores it."""
+        if PN is None:
+            self._chk(self.lib.kmpc_set_terminal_weight(self.h, None), "kmpc_set_terminal_weight")
+            return
+        PN = np.ascontiguousarray(PN, dtype=np.float64)
+        if PN.shape != (self.q, self.q):
+            raise ValueError("PN must be (%d, %d)" % (self.q, self.q))
+        self._chk(self.lib.kmpc_set_terminal_weight(self.h, _dptr(PN)), "kmpc_set_terminal_weight")
+
     def offline_fit(self, X, Y, U, ridge=0.0, init_rls=False):
         """K_hat = PHIY pinv([PHIX; U]), C = X pinv(PHIX) (duffing.py:152-177) on the device in Gram form
         (Koopman_update.m:94-101): lift, MFMA Gram sums, p x p solve.  X, Y (n, M), U (M,).  The result

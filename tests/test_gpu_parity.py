@@ -185,6 +185,65 @@ def test_condense_matches_oracle(torch_mod, KM, L, N, output, threads):
         assert np.abs(f2[b] - fo).max() <= 1e-10 * max(1.0, np.abs(fo).max())
 
 
+@pytest.mark.parametrize("L,N,output,threads", [(20, 20, "Cx", 64), (8, 30, "lift", 64), (64, 50, "Cx", 256)])
+def test_condense_with_terminal_weight(torch_mod, KM, L, N, output, threads):
+    """Q_bar(end-n+1:end, end-n+1:end) = C*P*C' (Koopman_update.m:381): a q x q terminal block instead of Qw*I;
+    per-trajectory condense, then the same through the shared-model condense + solve."""
+    rng = np.random.RandomState(L + N)
+    B = 4
+    q = L if output == "lift" else 2
+    mpc = KM(n=2, L=L, N=N, batch=B, lift="rbf", centres=rng.rand(L, 2), output=output, threads=threads)
+    A, Bm, Cm = _rand_model(rng, L, 2)
+    mpc.set_model(A, Bm, Cm)
+    G = rng.randn(q, q)
+    PN = 300.0 * (G @ G.T / q + 0.1 * np.eye(q))
+    mpc.set_terminal_weight(PN)
+    psi = rng.randn(L, B)
+    r = rng.randn(q, N)
+    H, f = [t.cpu().numpy() for t in mpc.condense(psi, r)]
+    worst = 0.0
+    for b in range(B):
+        _, _, Ho, fo, _ = ko.condense(A, Bm, None if output == "lift" else Cm, psi[:, b], r, N, PN=PN)
+        _, _, Hplain, _, _ = ko.condense(A, Bm, None if output == "lift" else Cm, psi[:, b], r, N)
+        assert np.abs(Ho - Hplain).max() > 1e-3 * np.abs(Ho).max()  # the terminal block matters here
+        assert np.abs(H[b] - Ho).max() <= 1e-10 * np.abs(Ho).max()
+        assert np.abs(f[b] - fo).max() <= 1e-10 * max(1.0, np.abs(fo).max())
+    # end to end: the solve on these problems
+    U, st, _ = mpc.qp_solve(H, f)
+    assert int(st.max().item()) == 0
+    for b in range(B):
+        _, _, Ho, fo, _ = ko.condense(A, Bm, None if output == "lift" else Cm, psi[:, b], r, N, PN=PN)
+        Uo, _ = ko.qp_exact(Ho, fo, -2.0, 2.0)
+        worst = max(worst, np.abs(U.cpu().numpy()[:, b] - Uo).max())
+    assert worst < 1e-6, worst
+    mpc.set_terminal_weight(None)
+    H0, _ = [t.cpu().numpy() for t in mpc.condense(psi, r)]
+    _, _, Hplain, _, _ = ko.condense(A, Bm, None if output == "lift" else Cm, psi[:, 0], r, N)
+    assert np.abs(H0[0] - Hplain).max() <= 1e-10 * np.abs(Hplain).max()
+
+
+def test_shared_mode_with_terminal_weight(torch_mod, KM):
+    from koopmpc.synth import initial_states, offline_edmd, random_mlp_weights
+
+    L, N, B = 20, 20, 16
+    w = random_mlp_weights(2, 100, 3, L, seed=7)
+    mpc = KM(n=2, L=L, N=N, batch=B, weights=w)
+    A0, B0, C0 = offline_edmd(lambda X: mpc.Encoder(X))
+    mpc.set_model(A0, B0, C0)
+    PN = np.array([[900.0, 120.0], [120.0, 400.0]])
+    mpc.set_terminal_weight(PN)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X = initial_states(B, seed=3)
+    mpc.shared_step(X, r)  # first step: the offline model, no samples yet
+    assert int(mpc.status.max().item()) == 0
+    Useq = mpc.Useq.cpu().numpy()
+    Psi = ko.mlp_lift(w, X)
+    for b in range(B):
+        _, _, H, f, _ = ko.condense(A0, B0, C0, Psi[:, b], r, N, PN=PN)
+        Uo, _ = ko.qp_exact(H, f, -2.0, 2.0)
+        assert np.abs(Useq[:, b] - Uo).max() < 1e-6, b
+
+
 def test_condense_is_the_reference_cost_on_golden_models(torch_mod, KM):
     g = _load("duffing_loop.npz")
     mpc = KM(n=2, L=8, N=10, batch=1, lift="rbf", centres=np.zeros((8, 2)))
