@@ -65,6 +65,10 @@ typedef struct kmpc_config {
   int32_t out_row0;    /* KMPC_OUT_CX: outputs are rows out_row0 .. out_row0+out_rows-1 of C x   */
   int32_t out_rows;    /*   (Cy = [0 1] -> out_row0 = 1, out_rows = 1, Tank_System.m:113); 0 -> all n rows */
   int32_t c_skip_first;/* 1: the first C update only downdates bar_Q (Tank_System.m:252-254)     */
+  int32_t cold_start;  /* 0: kmpc_step / kmpc_rollout start each solve at the previous minimiser, as the
+                          reference does (pastRes_loc, duffing.py:857-865); 1: always at clip(0).  The
+                          minimiser is unique, so this only changes the work, not the answer          */
+  int32_t reserved0;   /* keeps the doubles 8-byte aligned; must be 0                              */
   double lambda;       /* RLS forgetting factor (1.0; Koopman_update.m:258)                */
   double P0;           /* inv_K_G init scale (1e4 duffing.py:929-930; 1e5 vanderpol.py:874)*/
   double barQ0;        /* bar_Q init scale (100 duffing.py:946)                            */
@@ -126,7 +130,8 @@ int kmpc_condense(kmpc_handle* h, const void* psi_dev, const void* ref_dev, int 
 
 /* Box QP  min u'Hu + f'u, lb <= u <= ub  -- replaces optimize.minimize(..., bounds=...)
  * duffing.py:857-861 and quadprog(2H, f, ...) Koopman_update.m:214.  H_dev [B][N][N],
- * f_dev [B][N] -> U_dev (N x B), status_dev[B], iters_dev[B] (may be NULL).                 */
+ * f_dev [B][N] -> U_dev (N x B), status_dev[B], iters_dev[B] (may be NULL).  Stateless: always
+ * starts at clip(0) (duffing.py:634-635); the warm start of the loop lives in kmpc_step.      */
 int kmpc_qp_solve(kmpc_handle* h, const void* H_dev, const void* f_dev, void* U_dev,
                   int32_t* status_dev, int32_t* iters_dev, int B, void* stream);
 

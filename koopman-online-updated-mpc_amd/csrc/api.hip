@@ -75,6 +75,7 @@ struct Impl : kmpc_handle {
   T *dP = nullptr, *dK = nullptr, *dQ = nullptr, *dC = nullptr;
   T *dPsi[2] = {nullptr, nullptr};  // [B][L] trajectory-major: [cur], [prev]
   T* dUprev = nullptr;
+  T* dWarm = nullptr;  // [N][B] last minimiser = start of the next solve (pastRes_loc, duffing.py:865)
   int cur = 0;
   bool have_prev = false;  // a previous (psi, u) exists -> next step runs the RLS update
   bool rls_fresh = true;   // next RLS update starts from K_A = 0, bar_X = 0
@@ -115,12 +116,14 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMalloc(&dPsi[0], sizeof(T) * (size_t)L * B));
     HIPCHK(hipMalloc(&dPsi[1], sizeof(T) * (size_t)L * B));
     HIPCHK(hipMalloc(&dUprev, sizeof(T) * (size_t)B));
+    HIPCHK(hipMalloc(&dWarm, sizeof(T) * (size_t)N * B));
     HIPCHK(hipMalloc(&dTmp, sizeof(T) * (size_t)(L * p + n * L + 64)));
     HIPCHK(hipMemset(dK, 0, sizeof(T) * sK * B));
     HIPCHK(hipMemset(dC, 0, sizeof(T) * sC * B));
     HIPCHK(hipMemset(dPsi[0], 0, sizeof(T) * (size_t)L * B));
     HIPCHK(hipMemset(dPsi[1], 0, sizeof(T) * (size_t)L * B));
     HIPCHK(hipMemset(dUprev, 0, sizeof(T) * (size_t)B));
+    HIPCHK(hipMemset(dWarm, 0, sizeof(T) * (size_t)N * B));
     if (c.lift_kind == KMPC_LIFT_MLP) {
       if (c.layers != 2 && c.layers != 3) FAIL(-2, "layers (hidden layers) must be 2 or 3");
       if (c.hidden < 1 || c.hidden > 128) FAIL(-2, "hidden must be in 1..128");
@@ -142,7 +145,7 @@ struct Impl : kmpc_handle {
   }
 
   ~Impl() override {
-    for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev,
+    for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev, (void*)dWarm,
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt})
@@ -228,6 +231,7 @@ struct Impl : kmpc_handle {
     if (dGram) HIPCHK(hipMemsetAsync(dGram, 0, sizeof(double) * (size_t)gram_elems(), s));
     shared_has_samples = false;
     HIPCHK(launch_fill_state<T>(dP, sP, p, (T)cfg.P0, dQ, sQ, L, (T)cfg.barQ0, nullptr, sK, nullptr, sC, n, B, s));
+    HIPCHK(hipMemsetAsync(dWarm, 0, sizeof(T) * (size_t)N * B, s));  // pastRes_loc = zeros (duffing.py:634)
     have_prev = false;
     rls_fresh = true;
     cur = 0;
@@ -355,6 +359,7 @@ struct Impl : kmpc_handle {
     a.u_prev = dUprev; a.x_now = (const T*)X;
     a.ref = (const T*)ref; a.ref_per_traj = rpt;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
+    a.x_warm = cfg.cold_start ? nullptr : dWarm;
     a.accumulate = accumulate ? 1 : 0;
     if (fuse_plant >= 0) { a.plant = fuse_plant; a.plant_switched = fuse_switched; a.plant_h = (T)fuse_h; a.X_rw = (T*)const_cast<void*>(X); }
     HIPCHK(launch_step<T>(a, threads, s));
@@ -469,6 +474,7 @@ struct Impl : kmpc_handle {
     a.H_in = dHs; a.h_shared = 1; a.F_in = dFs; a.f0_in = df0s;
     a.psi_now = dPsi[cur]; a.pn_sl = 1; a.pn_sb = L;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
+    a.x_warm = cfg.cold_start ? nullptr : dWarm;
     HIPCHK(launch_step<T>(a, threads, s));
     have_prev = true;
     cur ^= 1;
@@ -527,10 +533,10 @@ struct Impl : kmpc_handle {
     return 0;
   }
 
-  // ---- state blob: header | P | K | Q | C | psi_prev | u_prev
+  // ---- state blob: header | P | K | Q | C | psi_prev | last minimiser | u_prev
   struct BlobHeader { int32_t magic, dtype, n, L, N, B, have_prev, rls_fresh; };
   int64_t state_bytes() const override {
-    return (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * ((sP + sK + sQ + sC) * (int64_t)B + (int64_t)L * B + B);
+    return (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * ((sP + sK + sQ + sC) * (int64_t)B + (int64_t)L * B + B + (int64_t)N * B);
   }
   int state_export(void* blob, int64_t bytes) override {
     if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_export: buffer too small");
@@ -540,7 +546,7 @@ struct Impl : kmpc_handle {
     memcpy(o, &hd, sizeof(hd)); o += sizeof(hd);
     struct { const T* ptr; size_t cnt; } parts[] = {{dP, (size_t)sP * B}, {dK, (size_t)sK * B}, {dQ, (size_t)sQ * B},
                                                     {dC, (size_t)sC * B}, {dPsi[cur ^ 1], (size_t)L * B},
-                                                    {dUprev, (size_t)B}};
+                                                    {dWarm, (size_t)N * B}, {dUprev, (size_t)B}};
     for (auto& pt : parts) {
       HIPCHK(hipMemcpy(o, pt.ptr, pt.cnt * sizeof(T), hipMemcpyDeviceToHost));
       o += pt.cnt * sizeof(T);
@@ -557,7 +563,7 @@ struct Impl : kmpc_handle {
     HIPCHK(hipDeviceSynchronize());
     struct { T* ptr; size_t cnt; } parts[] = {{dP, (size_t)sP * B}, {dK, (size_t)sK * B}, {dQ, (size_t)sQ * B},
                                               {dC, (size_t)sC * B}, {dPsi[cur ^ 1], (size_t)L * B},
-                                              {dUprev, (size_t)B}};
+                                              {dWarm, (size_t)N * B}, {dUprev, (size_t)B}};
     for (auto& pt : parts) {
       HIPCHK(hipMemcpy(pt.ptr, o, pt.cnt * sizeof(T), hipMemcpyHostToDevice));
       o += pt.cnt * sizeof(T);

@@ -49,6 +49,7 @@ struct StepArgs {
   T* U0;             // [B] or null
   T* u_store;        // [B] handle copy of u_k for the next RLS update, or null
   int32_t* status; int32_t* iters;
+  T* x_warm;       // [N][B] previous minimiser: start of the next solve (pastRes_loc, duffing.py:857-865), or null
   const T* Wterm;  // q x q, PN - Qw I: terminal block of Q_bar (Koopman_update.m:381), or null
   T lam, Qw, Rw, lb, ub;
 };

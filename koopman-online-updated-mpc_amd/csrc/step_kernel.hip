@@ -15,6 +15,21 @@
 #include "kernels.h"
 #include "plant_device.h"
 
+#ifdef KMPC_TRACE
+// Measurement build only (make trace -> libkoopmpc_trace.so, tools/trace_phases.py): lane 0 of every
+// workgroup stamps the 100 MHz wall clock at the phase boundaries.  Never compiled into libkoopmpc.so.
+__device__ unsigned long long kmpc_trace_buf[8192 * 16];
+#define KTRACE(slot)                                                                                      \
+  do {                                                                                                    \
+    if (threadIdx.x == 0 && blockIdx.x < 8192) kmpc_trace_buf[blockIdx.x * 16 + (slot)] = wall_clock64(); \
+  } while (0)
+extern "C" int kmpc_trace_read(void* host, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kmpc_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define KTRACE(slot)
+#endif
+
 namespace kmpc {
 
 // ---------------------------------------------------------------------------------------
@@ -46,11 +61,13 @@ size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2)
 template <typename T> struct Tol;
 template <> struct Tol<double> {
   static __device__ __forceinline__ double kkt() { return 1e-9; }
+  static __device__ __forceinline__ double tight() { return 1e-12; }
   static __device__ __forceinline__ double act() { return 1e-8; }
   static __device__ __forceinline__ double slack() { return 1e-14; }
 };
 template <> struct Tol<float> {
   static __device__ __forceinline__ float kkt() { return 2e-5f; }
+  static __device__ __forceinline__ float tight() { return 2e-6f; }
   static __device__ __forceinline__ float act() { return 1e-5f; }
   static __device__ __forceinline__ float slack() { return 1e-6f; }
 };
@@ -268,7 +285,9 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     for (int r = 0; r < RM; ++r) if (tj == r) { rs = ps[r]; ra = pa[r]; }
   }
   const T gs = tabs(fi) + T(2) * ra * xmaxb;
-  T x = own ? c0 : T(0);
+  // start: the previous minimiser like the reference (pastRes_loc, duffing.py:857-865) when the handle keeps
+  // one, else clip(0) (duffing.py:634-635).  The minimiser is unique: the start only changes the work.
+  T x = own ? (a.x_warm ? tclip(a.x_warm[(size_t)myvar * a.B + b], lb, ub) : c0) : T(0);
   T hx = T(0);  // H x at the start (x need not be uniform: the first variable's box may differ)
   {
     T xc[RM];
@@ -289,11 +308,12 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   T J0 = wave_sum(p0);
   const unsigned long long ownmask = __ballot(own);
   unsigned long long Smask = 0ull;  // lane-space mask of the variables swept into T
-  int it = 0, status = 1, refresh = 0;
+  int it = 0, status = 1, refresh = 0, polish = 0;
+  KTRACE(8);
 
   while (true) {
     T g = T(0);
-    bool bad = false, inI = false;
+    bool bad = false, inI = false, loose = false;
     if (own) {
       g = T(2) * hx + fi;
       const bool atl = x <= lb + eact, atu = x >= ub - eact;
@@ -303,17 +323,27 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
       const T res = tabs(x - tclip(x - g, lb, ub));  // what a projected gradient step would still move
       const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
       bad = !((viol <= tol * gs) || (res <= tol * xs));
+      loose = viol > (T)Tol<T>::tight() * gs;
     }
     const unsigned long long Bmask = __ballot(bad);
+    const bool refine = __ballot(loose) != 0ull;
     const unsigned long long Imask = __ballot(inI);
     if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
-    if (Bmask == 0ull) { status = 0; break; }
+    // The KKT test certifies, it does not define the answer.  A point that passes it only loosely (after a
+    // damped or clipped step, or after a Newton step with a tableau that many set changes have worn) gets up
+    // to two more Newton solves on its face -- iterative refinement -- so that the result does not depend on
+    // the path (cold or warm start) beyond rounding.  A warm start itself is never returned unsolved.
+    if (Bmask == 0ull && (it > 0 || !a.x_warm)) {
+      if (!refine || polish >= 2) { status = 0; break; }
+      ++polish;
+    }
     if (it >= a.max_iter || refresh > 4) { status = 1; break; }
     // Safeguard: projected Newton can crawl (tiny Armijo steps) on ill-conditioned, almost fully saturated
     // problems; after N+10 iterations the caller finishes the solve from the current point with the
     // active-set method of qp_lds (rare: ~4e-5 of the QPs of the cfg3-sized closed loop).
     if (it >= N_ + 10) { status = 3; break; }
     unsigned long long Fmask = ~Imask & ownmask;
+    if (it == 0) KTRACE(9);
 
     bool broke = false;
     for (int pass = 0; pass < 2; ++pass) {
@@ -349,6 +379,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
       Smask = 0ull;
     }
     Fmask = Smask;
+    if (it == 0) KTRACE(10);
 
     // Newton direction on F: p_i = sum_{j in F} T_ij g_j ; straight to the bound on I
     const bool isF = own && ((Fmask >> tid) & 1ull);
@@ -369,6 +400,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     }
     if (!isF) pdir = own ? ((g > T(0) ? lb : (g < T(0) ? ub : x)) - x) : T(0);
 
+    if (it == 0) KTRACE(11);
     // projected Armijo search on the true cost
     T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
     while (true) {
@@ -395,8 +427,13 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     x = xa;
     hx = hxa;
     J0 = Ja;
+    if (it == 0) KTRACE(12);
     ++it;
   }
+  KTRACE(13);
+#ifdef KMPC_TRACE
+  if (threadIdx.x == 0 && blockIdx.x < 8192) kmpc_trace_buf[blockIdx.x * 16 + 15] = (unsigned long long)it;
+#endif
 
   if (status == 3) {  // hand the current point to the active-set solver
     if (own) qx_out[myvar] = x;
@@ -405,6 +442,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   const int B = a.B;
   if (own) {
     if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
+    if (a.x_warm) a.x_warm[(size_t)myvar * B + b] = x;
   }
   if (tid == 0) {  // lane 0 owns variable 0
     const T uout = a.du_mode ? uprev + x : x;  // U0 = U0 + dU*(1)   (Tank_System.m:192)
@@ -419,6 +457,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
     if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
   }
+  KTRACE(14);
   return false;
 }
 
@@ -457,7 +496,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
     for (int j = 0; j < N; ++j) ra += tabs(sH[j * N + tid]);
     gs = tabs(sf[tid]) + T(2) * ra * xmaxb;  // magnitude of the terms of the gradient
     // start: clip(0) as the reference (duffing.py:634-635), or the point the register solver handed over
-    qx[tid] = as_from_start ? tclip(qx[tid], lb, ub) : c0;
+    qx[tid] = as_from_start ? tclip(qx[tid], lb, ub) : (a.x_warm ? tclip(a.x_warm[(size_t)tid * B + b], lb, ub) : c0);
   }
   for (int i = ti; i < N; i += TS)
     for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
@@ -470,7 +509,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
 
   unsigned long long Smask = 0ull;  // variables currently swept into T
   unsigned long long Wmask = 0ull;  // active-set mode: variables held at a bound
-  int it = 0, status = 1, refresh = 0;
+  int it = 0, status = 1, refresh = 0, polish = 0;
   bool mode_as = false, at_min = false;
 
   // every thread gets wave 0's value of a block-uniform quantity
@@ -492,7 +531,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
   while (true) {
     // ---- gradient, KKT residual, natural bound set
     T g = T(0);
-    bool bad = false, inI = false;
+    bool bad = false, inI = false, loose = false;
     if (mine) {
       g = T(2) * hx + sf[tid];
       const bool atl = x <= lb + eact, atu = x >= ub - eact;
@@ -501,11 +540,16 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
       const T res = tabs(x - tclip(x - g, lb, ub));
       const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
       bad = !((viol <= tol * gs) || (res <= tol * xs));
+      loose = viol > (T)Tol<T>::tight() * gs;
     }
     const unsigned long long Bmask = bcast_mask(__ballot(bad));  // wave 0 holds every variable (N <= 64)
+    const bool refine = bcast_mask(__ballot(loose)) != 0ull;
     const unsigned long long Imask = bcast_mask(__ballot(inI));
     if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
-    if (Bmask == 0ull) { status = 0; break; }
+    if (Bmask == 0ull && (it > 0 || as_from_start || !a.x_warm)) {  // see qp_regs
+      if (!refine || mode_as || polish >= 2) { status = 0; break; }
+      ++polish;
+    }
     if (it >= a.max_iter || refresh > 4) { status = 1; break; }
     if (!mode_as && (as_from_start || it >= N + 10)) {
       mode_as = true;
@@ -639,6 +683,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
 
   if (mine) {
     if (a.Useq) a.Useq[(size_t)tid * B + b] = qx[tid];
+    if (a.x_warm) a.x_warm[(size_t)tid * B + b] = qx[tid];
   }
   if (tid == 0) {
     const T uout = a.du_mode ? uprev + qx[0] : qx[0];
@@ -692,6 +737,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   T* const qxa = qx + N;
   T* const qg = qxa + N;
 
+    KTRACE(0);
 
   // =====================================================================================
   // phase 1: recursive least squares (gain form; algebraically K_A inv_K_G of the reference)
@@ -712,6 +758,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     if (tid == 0) sz[L] = a.u_prev[b];
     for (int i = tid; i < n; i += TPB) sx[i] = a.x_now[(size_t)i * B + b];
     __syncthreads();
+    KTRACE(1);
 
     // Pz (P symmetric: column walk is conflict-free in LDS)
     for (int i = tid; i < p; i += TPB) {
@@ -726,6 +773,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     const T d = a.lam + block_sum<T, TPB>(part, red);
     const T dinv = T(1) / d;
     const T linv = T(1) / a.lam;
+    KTRACE(2);
 
     // P <- (P - Pz Pz' / d) / lam                                   duffing.py:931-932
     T* Pw = a.P + (size_t)b * a.strideP;
@@ -749,6 +797,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       Kg[e] = v;
     }
 
+    KTRACE(3);
     if (a.out_kind == OUT_CX) {
       // ---- C = bar_X bar_Q, target x_{k+1}, regressor psi(x_k)      duffing.py:943-953
       const T* Qg = a.Qb + (size_t)b * a.strideQ;
@@ -790,6 +839,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       }
     }
     __syncthreads();
+    KTRACE(4);
   } else if (a.phases & PH_CONDENSE) {
     const T* Kg = a.K + (size_t)b * a.strideK;
     for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
@@ -816,6 +866,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       sEr[e] = -ref[r * N + k];
     }
     __syncthreads();
+    KTRACE(5);
     // v_{j+1} = A v_j, w_{j+1} = A w_j;  g_j = Co v_j;  e_j = Co w_j - r_{j-1}
     if constexpr (L_ > 0 && TPB == 64 && (L_ + Q_ <= 32)) {
       // Static path: lanes 0-31 run the v-chain, lanes 32-63 the w-chain.  Lane t of a half keeps row t
@@ -969,6 +1020,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       }
     }
     // H[a][b] = Qw * S(b-a, N-1-b) (+Rw on the diagonal),  S(d,t) = sum_{s<=t} g_{s+d}.g_s
+    KTRACE(6);
     for (int d = tid; d < N; d += TPB) {
       T acc = T(0);
 #pragma unroll
@@ -1023,6 +1075,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       }
     }
     __syncthreads();
+    KTRACE(7);
     if (a.H_out) {
       T* Hg = a.H_out + (size_t)b * N * N;
       for (int e = tid; e < N * N; e += TPB) Hg[e] = sH[e];

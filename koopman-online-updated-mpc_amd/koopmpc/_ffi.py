@@ -24,6 +24,7 @@ class KmpcConfig(C.Structure):
         ("output_kind", C.c_int32), ("dtype", C.c_int32), ("batch", C.c_int32),
         ("qp_max_iter", C.c_int32), ("threads", C.c_int32),
         ("delta_u", C.c_int32), ("out_row0", C.c_int32), ("out_rows", C.c_int32), ("c_skip_first", C.c_int32),
+        ("cold_start", C.c_int32), ("reserved0", C.c_int32),
         ("lam", C.c_double), ("P0", C.c_double), ("barQ0", C.c_double),
         ("Qw", C.c_double), ("Rw", C.c_double), ("lb", C.c_double), ("ub", C.c_double),
         ("rbf_eps", C.c_double), ("umin", C.c_double), ("umax", C.c_double),

@@ -40,7 +40,7 @@ class KoopmanMPC:
     def __init__(self, n=2, L=8, N=10, batch=1, lift="mlp", weights=None, centres=None, hidden=100, layers=3,
                  output="Cx", dtype=torch.float64, lam=1.0, P0=1e4, barQ0=100.0, Qw=100.0, Rw=1e-4, lb=-2.0,
                  ub=2.0, rbf_eps=1e-4, qp_max_iter=0, threads=0, device=None, delta_u=False, out_row0=0, out_rows=0,
-                 c_skip_first=False, umin=-8.0, umax=8.0):
+                 c_skip_first=False, umin=-8.0, umax=8.0, cold_start=False):
         if not torch.cuda.is_available():
             raise RuntimeError("koopmpc needs a HIP device (MI355X); there is no CPU path")
         self.lib = _ffi.load()
@@ -59,7 +59,7 @@ class KoopmanMPC:
             dtype=_ffi.KMPC_F64 if dtype == torch.float64 else _ffi.KMPC_F32, batch=batch,
             qp_max_iter=qp_max_iter, threads=threads, lam=lam, P0=P0, barQ0=barQ0, Qw=Qw, Rw=Rw, lb=lb, ub=ub,
             rbf_eps=rbf_eps, delta_u=int(bool(delta_u)), out_row0=int(out_row0), out_rows=int(out_rows),
-            c_skip_first=int(bool(c_skip_first)), umin=umin, umax=umax)
+            c_skip_first=int(bool(c_skip_first)), umin=umin, umax=umax, cold_start=int(bool(cold_start)), reserved0=0)
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.lib.kmpc_create(C.byref(cfg), C.byref(h))

@@ -648,6 +648,58 @@ def test_tank_delta_u_closed_loop(torch_mod, KM, lift, threads, N):
     assert worst < 1e-6 and ncap <= 1
 
 
+@pytest.mark.parametrize("L,N,output,lift,threads,tol", [
+    (20, 20, "Cx", "mlp", 0, 1e-9), (20, 20, "Cx", "mlp", 256, 1e-9),
+    (8, 30, "Cx", "mlp", 0, 1e-6),  # long horizon, cond(H) up to ~2e6 in this loop: the north-star tolerance
+])
+def test_warm_start_is_the_same_minimiser_with_less_work(torch_mod, KM, L, N, output, lift, threads, tol):
+    """The reference starts each solve at the previous result (pastRes_loc, duffing.py:857-865); kmpc_step does
+    the same by default.  The QP is strictly convex, so warm and cold starts give the same minimiser (to the
+    KKT tolerance) -- only the number of Newton solves differs."""
+    torch = torch_mod
+    from koopmpc.synth import duffing_rk4, initial_states, offline_data, random_mlp_weights, vdp_rk4
+
+    B = 512
+    rng = np.random.RandomState(5)
+    kw = dict(weights=random_mlp_weights(2, 100, 3, L, seed=4)) if lift == "mlp" else dict(lift="rbf", centres=4 * rng.rand(L, 2) - 2)
+    bnd = 2.0 if output == "Cx" else 6.0
+    plant = "duffing" if output == "Cx" else "vdp"
+    ms = [KM(n=2, L=L, N=N, batch=B, output=output, lb=-bnd, ub=bnd, threads=threads, cold_start=c, **kw) for c in (False, True)]
+    Xo, Yo, Uo = offline_data(plant=vdp_rk4 if plant == "vdp" else duffing_rk4)
+    for m in ms:
+        m.offline_fit(Xo, Yo, Uo, ridge=1e-8)
+    if output == "Cx":
+        r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    else:  # the lifted reference point, vanderpol.py:756-763
+        lift_fn = ms[0].Encoder if lift == "mlp" else ms[0].rbf
+        lr = lift_fn(np.array([[1.0], [0.0]]))
+        r = np.tile(np.reshape(lr.cpu().numpy() if hasattr(lr, "cpu") else np.asarray(lr), (L, 1)), (1, N))
+    X0 = _t(torch, initial_states(B, seed=9))
+    Xs = [X0.clone(), X0.clone()]
+    worst = 0.0
+    for k in range(25):
+        us = [m.step(X, r).clone() for m, X in zip(ms, Xs)]
+        sts = [int(m.status.max().item()) for m in ms]
+        assert sts == [0, 0], (k, sts, [int((m.status != 0).sum()) for m in ms], [int(m.iters.max()) for m in ms])
+        worst = max(worst, float((ms[0].Useq - ms[1].Useq).abs().max()))
+        # both controllers follow the cold-start trajectory so that the comparison stays solve-by-solve
+        Xn = ms[1].plant_step(plant, Xs[1].clone(), us[1])
+        Xs = [Xn.clone(), Xn.clone()]
+        _copy_uprev(ms[0], ms[1])
+    its = [float(m.iters.double().mean()) for m in ms]
+    print("warm vs cold start L=%d N=%d: max |dU| %.2e, last-step mean Newton solves warm %.2f cold %.2f" % (L, N, worst, its[0], its[1]))
+    assert worst < tol
+    assert its[0] <= its[1]
+
+
+def _copy_uprev(dst, src):
+    """u_{k} of `src` (tail of its state blob) into `dst`, so that both see the same transition."""
+    sb, db = src.state_dict()["blob"], dst.state_dict()["blob"].copy()
+    nb = src.B * 8
+    db[-nb:] = sb[-nb:]
+    dst.load_state_dict({"blob": db})
+
+
 def _set_uprev(mpc, sd, uk):
     """Replace the stored u_{k} of every trajectory in a state blob (tail of the blob) and load it back."""
     blob = sd["blob"].copy()
@@ -665,7 +717,7 @@ def test_step_matches_separate_ops_bitwise(torch_mod, KM):
     L, N, B = 20, 20, 37
     w = random_mlp_weights(2, 100, 3, L, seed=3)
     A, Bm, Cm = _rand_model(rng, L, 2)
-    m1 = KM(n=2, L=L, N=N, batch=B, weights=w)
+    m1 = KM(n=2, L=L, N=N, batch=B, weights=w, cold_start=True)  # kmpc_qp_solve is stateless: it starts at clip(0)
     m2 = KM(n=2, L=L, N=N, batch=B, weights=w)
     m1.set_model(A, Bm, Cm); m2.set_model(A, Bm, Cm)
     r = np.tile(np.array([[1.0], [0.0]]), (1, N))

@@ -1,0 +1,60 @@
+"""In-kernel phase timeline of step_kernel (measurement build `make -C koopman-online-updated-mpc_amd trace`).
+Lane 0 of every workgroup stamps the 100 MHz wall clock at the phase boundaries; this prints, per segment,
+the median / p90 / max duration over the 4096 trajectories of one launch at a late closed-loop step.
+    python tools/trace_phases.py [B] [steps] [cold]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "koopman-online-updated-mpc_amd"))
+import numpy as np, torch
+from koopmpc import _ffi
+_ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), "libkoopmpc_trace.so")
+from koopmpc import KoopmanMPC
+from koopmpc.synth import random_mlp_weights, initial_states, offline_data
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+L, N = 20, 20
+cold = len(sys.argv) > 3 and sys.argv[3] == "cold"
+m = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=random_mlp_weights(2, 100, 3, L), cold_start=cold)
+m.offline_fit(*offline_data())
+r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+X = torch.tensor(initial_states(B), dtype=torch.float64, device="cuda:0").contiguous()
+import time
+t0 = time.time()
+X0 = X.clone()
+while time.time() - t0 < 1.0:  # clock ramp
+    m.rollout("duffing", X, r, 10, step0=0, switch_step=10**9)
+    torch.cuda.synchronize()
+m.reset()
+m.offline_fit(*offline_data())
+X.copy_(X0)
+m.iters.zero_()
+m.rollout("duffing", X, r, steps, step0=0)
+torch.cuda.synchronize()
+nb = min(B, 8192)
+buf = np.zeros(8192 * 16, dtype=np.uint64)
+lib = _ffi.load()
+lib.kmpc_trace_read.restype = C.c_int
+lib.kmpc_trace_read.argtypes = [C.c_void_p, C.c_size_t]
+assert lib.kmpc_trace_read(buf.ctypes.data, buf.nbytes) == 0
+t = buf.reshape(8192, 16)[:nb].astype(np.int64)
+names = ["start", "rls: state in LDS", "rls: Pz, d", "rls: P, K written", "rls: C part", "cond: init", "cond: chains",
+         "cond: H, f", "qp: setup", "qp: first KKT", "qp: sweeps", "qp: direction", "qp: first Armijo", "qp: loop exit",
+         "end"]
+k0 = t[:, 0].min()
+print("launch span: %.2f us; wave start spread %.2f us" % ((t[:, 14].max() - k0) / 100.0, (t[:, 0].max() - k0) / 100.0))
+print("%-22s %8s %8s %8s   (us, per wave)" % ("segment", "median", "p90", "max"))
+for i in range(1, 15):
+    d = (t[:, i] - t[:, i - 1]) / 100.0
+    print("%-22s %8.2f %8.2f %8.2f" % (names[i], np.median(d), np.percentile(d, 90), d.max()))
+tot = (t[:, 14] - t[:, 0]) / 100.0
+print("%-22s %8.2f %8.2f %8.2f" % ("whole wave", np.median(tot), np.percentile(tot, 90), tot.max()))
+its = t[:, 15]
+print("Newton iterations in this launch: histogram", np.bincount(its.astype(int)).tolist())
+for k in sorted(set(its.tolist())):
+    sel = its == k
+    print("  it=%2d: %5d waves, wave time median %.1f max %.1f us, qp loop after first iteration median %.2f us" % (
+        k, sel.sum(), np.median(tot[sel]), tot[sel].max(), np.median((t[sel, 13] - t[sel, 12]) / 100.0)))
+fin = np.sort((t[:, 14] - k0) / 100.0)
+print("finish-time quantiles (us since first wave start): 50%% %.1f  90%% %.1f  99%% %.1f  99.9%% %.1f  max %.1f" % tuple(
+    fin[[int(nb * f) - 1 for f in (0.5, 0.9, 0.99, 0.999, 1.0)]]))
+print("iters: mean %.2f max %d" % (float(m.iters.double().mean()) / (steps + 0.0), int(m.iters.max())))
