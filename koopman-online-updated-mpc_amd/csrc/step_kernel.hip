@@ -75,6 +75,39 @@ template <> struct Tol<float> {
 template <typename T> __device__ __forceinline__ T tabs(T v) { return v < T(0) ? -v : v; }
 template <typename T> __device__ __forceinline__ T tclip(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+// ---- register-resident mat-vec chain (condense, static path): the current vector lives in the lanes and is
+// read with the f64 DPP row broadcast of gfx90a+ -- v_fmac_f64_dpp ... row_newbcast:n multiplies by lane n of
+// the reader's own 16-lane row -- so a chain step touches neither LDS nor a barrier.
+template <int LANE, bool NOP>
+__device__ __forceinline__ void fmac_rowbcast(double& acc, double vec, double coef) {
+  // a VALU write of `vec` must be 2 wait states old before DPP reads it: the first use of a step carries the nop
+  if constexpr (NOP)
+    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(vec), "v"(coef), "n"(LANE));
+  else
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(vec), "v"(coef), "n"(LANE));
+}
+// acc[l & 3] += row[l] * vec[l], vec[l] = lane l of v0 (l < 16) or lane l-16 of v1, within the reader's row
+template <int L_, int l = 0>
+__device__ __forceinline__ void chain_dot(double (&ac)[4], double v0, double v1, const double (&row)[L_]) {
+  if constexpr (l < L_) {
+    if constexpr (l < 16) fmac_rowbcast<l, l == 0>(ac[l & 3], v0, row[l]);
+    else fmac_rowbcast<l - 16, l == 16>(ac[l & 3], v1, row[l]);
+    chain_dot<L_, l + 1>(ac, v0, v1, row);
+  }
+}
+// Lane t of a 32-lane half holds element t.  v_permlane16_swap (gfx950) exchanges the odd 16-lane rows of its
+// first operand with the even rows of the second: with both = a, every row of a half receives
+// v0 = elements 0..15 and v1 = elements 16..31 of that half, the layout chain_dot reads.
+__device__ __forceinline__ void half_gather(double a, double& v0, double& v1) {
+  const int lo = __double2loint(a), hi = __double2hiint(a);
+  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  v0 = __hiloint2double(rh[0], rl[0]);
+  v1 = __hiloint2double(rh[1], rl[1]);
+}
+
 // ---- wave-wide sum on DPP (no LDS crossbar): Hillis-Steele prefix inside each 16-lane row with
 // row_shr 1/2/4/8 (bound_ctrl zero-fills), then the four row totals are read from lanes 15/31/47/63.
 __device__ __forceinline__ int dpp_shr(int v, int ctrl) {
@@ -882,6 +915,27 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       // x+ = A x + B s with s = 1 on the v-chain (B~ = [B; 1]) and s = u_prev on the w-chain
       const T bs = (a.du_mode && isA) ? sK[t * p + L] * (half ? a.u_prev[b] : T(1)) : T(0);
       if (!cx && half == 0 && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
+      if constexpr (sizeof(T) == 8) {
+        // float64: the vector stays in the lanes (DPP row broadcast + one cross-row swap per step); LDS only
+        // receives the outputs g_j, e_j.  11 -> 4 us for the 21 steps of cfg2 (tools/trace_phases.py): the
+        // broadcast LDS reads of the version below kept the LDS pipe of the CU busy for the whole recursion.
+        double v0, v1;
+        half_gather(isA ? (double)(half ? sW[t] : sV[t]) : 0.0, v0, v1);
+        for (int j = 0; j <= N; ++j) {
+          double ac4[4] = {0.0, 0.0, 0.0, 0.0};
+          chain_dot<L_>(ac4, v0, v1, row);
+          const double acc = ((ac4[0] + ac4[1]) + (ac4[2] + ac4[3])) + (isA ? bs : 0.0);
+          if (half == 0) {
+            if (isA && !cx && j + 1 < N) sG[(j + 1) * q + t] = acc;  // g_{j+1} = v_{j+1}
+            if (isC && j < N) sG[j * q + (t - L)] = acc;             // g_j = Co v_j
+          } else {
+            if (isA && !cx && j < N) sEr[j * q + t] += acc;          // e_{j+1} = w_{j+1} - r_j
+            if (isC && j >= 1) sEr[(j - 1) * q + (t - L)] += acc;    // e_j = Co w_j - r_{j-1}
+          }
+          half_gather(acc, v0, v1);  // v_{j+1} / w_{j+1} (lanes >= L are never read back)
+        }
+        __syncthreads();
+      } else {
       int cur = 0;
       for (int j = 0; j <= N; ++j) {
         const T* vec = (half ? sW : sV) + cur * L;
@@ -920,6 +974,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
         }
         __syncthreads();
         cur ^= 1;
+      }
       }
     } else if constexpr (L_ > 0 && TPB == 64 && (L_ + Q_ <= 64) && ((L_ & 1) == 0)) {
       // Static path for 32 < L + q <= 64 (cfg4 sizes): lane t keeps row t of [A; Co] in registers and
