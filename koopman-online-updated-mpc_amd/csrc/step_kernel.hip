@@ -21,7 +21,7 @@
 __device__ unsigned long long kmpc_trace_buf[8192 * 16];
 #define KTRACE(slot)                                                                                      \
   do {                                                                                                    \
-    if (threadIdx.x == 0 && blockIdx.x < 8192) kmpc_trace_buf[blockIdx.x * 16 + (slot)] = wall_clock64(); \
+    if (tid == 0 && b < 8192) kmpc_trace_buf[b * 16 + (slot)] = wall_clock64();                          \
   } while (0)
 extern "C" int kmpc_trace_read(void* host, size_t bytes) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kmpc_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
@@ -58,6 +58,23 @@ size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2)
 // ---------------------------------------------------------------------------------------
 // device helpers
 // ---------------------------------------------------------------------------------------
+// One trajectory is solved by TPB threads.  TPB == 64: a single wave -- its lanes exchange data through LDS in
+// program order, so a "barrier" is only a compiler/memory fence at wavefront scope and the code may run as one
+// wave of a larger workgroup (the fused roll-out kernel puts 16 trajectories in a workgroup).  TPB == 256:
+// a real workgroup barrier.
+template <int TPB> __device__ __forceinline__ void block_sync() {
+  if constexpr (TPB == 64) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  } else {
+    __syncthreads();
+  }
+}
+template <int TPB> __device__ __forceinline__ int local_tid() {
+  return TPB == 64 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+}
+
 template <typename T> struct Tol;
 template <> struct Tol<double> {
   static __device__ __forceinline__ double kkt() { return 1e-9; }
@@ -142,9 +159,9 @@ template <typename T, int TPB> __device__ __forceinline__ T block_sum(T v, T* re
   v = wave_sum(v);
   if (TPB == 64) return v;
   const int w = threadIdx.x >> 6;
-  __syncthreads();  // protect red[] from the previous use
+  block_sync<TPB>();  // protect red[] from the previous use
   if ((threadIdx.x & 63) == 0) red[w] = v;
-  __syncthreads();
+  block_sync<TPB>();
   T s = T(0);
 #pragma unroll
   for (int i = 0; i < TPB / 64; ++i) s += red[i];
@@ -161,9 +178,9 @@ template <typename T, int TPB> __device__ __forceinline__ void block_sum2(T& v0,
   v1 = (lane_bcast(v1, 15) + lane_bcast(v1, 31)) + (lane_bcast(v1, 47) + lane_bcast(v1, 63));
   if (TPB == 64) return;
   const int w = threadIdx.x >> 6;
-  __syncthreads();
+  block_sync<TPB>();
   if ((threadIdx.x & 63) == 0) { red[w] = v0; red[4 + w] = v1; }
-  __syncthreads();
+  block_sync<TPB>();
   T s0 = T(0), s1 = T(0);
 #pragma unroll
   for (int i = 0; i < TPB / 64; ++i) { s0 += red[i]; s1 += red[4 + i]; }
@@ -274,7 +291,7 @@ template <typename T> __device__ __forceinline__ T wave_min_x(T v) {
 template <typename T, int N_>
 __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, int b, T* red, T* qx_out) {
   constexpr int RM = (N_ + 7) / 8;
-  const int tid = threadIdx.x, ti = tid >> 3, tj = tid & 7;
+  const int tid = threadIdx.x & 63, ti = tid >> 3, tj = tid & 7;
   const int myvar = ti + 8 * tj;
   const bool own = (tj < RM) && (myvar < N_);
   // per-variable box: in the delta-u form the first increment also keeps the absolute input inside
@@ -465,7 +482,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   }
   KTRACE(13);
 #ifdef KMPC_TRACE
-  if (threadIdx.x == 0 && blockIdx.x < 8192) kmpc_trace_buf[blockIdx.x * 16 + 15] = (unsigned long long)it;
+  if (tid == 0 && b < 8192) kmpc_trace_buf[b * 16 + 15] = (unsigned long long)it;
 #endif
 
   if (status == 3) {  // hand the current point to the active-set solver
@@ -504,7 +521,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
 template <typename T, int TPB>
 __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T* qxa, T* qg, T* red,
                                        const StepArgs<T>& a, int b, int N, bool as_from_start) {
-  const int tid = threadIdx.x, B = a.B;
+  const int tid = local_tid<TPB>(), B = a.B;
   const T uprev = a.du_mode ? a.u_prev[b] : T(0);
   T lb = a.lb, ub = a.ub;
   const T tol = (T)Tol<T>::kkt();
@@ -533,7 +550,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
   }
   for (int i = ti; i < N; i += TS)
     for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
-  __syncthreads();
+  block_sync<TPB>();
   T x = mine ? qx[tid] : T(0), hx = T(0);
   if (mine) {  // H x at the start (x need not be uniform: the first variable's box may differ)
     for (int j = 0; j < N; ++j) hx += sH[j * N + tid] * qx[j];
@@ -548,16 +565,16 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
   // every thread gets wave 0's value of a block-uniform quantity
   auto bcast_mask = [&](unsigned long long m) -> unsigned long long {
     if (TPB == 64) return m;
-    __syncthreads();
+    block_sync<TPB>();
     if (tid == 0) smask[0] = m;
-    __syncthreads();
+    block_sync<TPB>();
     return smask[0];
   };
   auto bcast_val = [&](T v) -> T {
     if (TPB == 64) return v;
-    __syncthreads();
+    block_sync<TPB>();
     if (tid == 0) sval[0] = v;
-    __syncthreads();
+    block_sync<TPB>();
     return sval[0];
   };
 
@@ -632,7 +649,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
             }
           }
         }
-        __syncthreads();
+        block_sync<TPB>();
         if (mine) {
           if (tid == k) {
             sM[k * N + k] = -dinv;
@@ -642,14 +659,14 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
             sM[tid * N + k] = v;
           }
         }
-        __syncthreads();
+        block_sync<TPB>();
         Smask ^= (1ull << k);
       }
       if (!broke || pass == 1) break;
       ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
       for (int i = ti; i < N; i += TS)
         for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
-      __syncthreads();
+      block_sync<TPB>();
       Smask = 0ull;
     }
     Fmask = Smask;  // what is actually swept (a variable whose pivot broke down stays fixed)
@@ -657,7 +674,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
     // ---- direction: Newton on F (T_FF = -(2H_FF)^-1) as a mat-vec with the masked gradient
     const bool isF = mine && ((Fmask >> tid) & 1ull);
     if (mine) qg[tid] = isF ? g : T(0);
-    __syncthreads();
+    block_sync<TPB>();
     T pdir = T(0);
     if (isF) {
       for (int j = 0; j < N; ++j) pdir += sM[j * N + tid] * qg[j];
@@ -691,7 +708,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
         if (tid == jb) xa = pdir < T(0) ? lb : ub;  // the blocking variable sits exactly on its bound
         qxa[tid] = xa;
       }
-      __syncthreads();
+      block_sync<TPB>();
       T pJa = T(0), pdec = T(0);
       if (mine) {
         hxa = T(0);
@@ -704,7 +721,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
       const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
       if (one_shot || (J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
       alpha *= T(0.25);
-      __syncthreads();
+      block_sync<TPB>();
     }
     x = xa;
     hx = hxa;
@@ -712,7 +729,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
     ++it;
   }
   if (mine) qx[tid] = x;
-  __syncthreads();
+  block_sync<TPB>();
 
   if (mine) {
     if (a.Useq) a.Useq[(size_t)tid * B + b] = qx[tid];
@@ -738,11 +755,8 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
 // Four waves per SIMD (<= 128 VGPRs) for the small static configurations: BASELINE cfg2 puts exactly 4096
 // trajectories = 4 waves per SIMD on the chip, so one register too many costs a whole second round.
 template <typename T, int TPB, int L_, int N_, int Q_>
-__global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  T* const sm = reinterpret_cast<T*>(smem_raw);
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x;
+__device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* const sm) {
+  const int tid = local_tid<TPB>();
   const int n = a.n, L = L_ ? L_ : a.L, p = L + 1, q = Q_ ? Q_ : a.q, N = N_ ? N_ : a.N, B = a.B;
 
   T* const sX = sm;            // P / bar_Q / H
@@ -778,6 +792,28 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   if (a.phases & PH_RLS) {
     const T* Pg = a.P + (size_t)b * a.strideP;
     T* Kg = a.K + (size_t)b * a.strideK;
+    // Static sizes: bar_Q and C are requested from HBM now, together with P and K, and wait in registers
+    // until the first half of the update is done with the LDS region they go to -- otherwise their latency
+    // sits exposed in the middle of the phase (tools/trace_phases.py: 6.4 -> ~3 us for the C part).
+    constexpr int QPRE = (L_ > 0) ? (L_ * L_ + TPB - 1) / TPB : 0;
+    constexpr bool PREFETCH = (L_ > 0) && (QPRE <= 16);
+    T qpre[PREFETCH ? QPRE : 1], cpre[PREFETCH ? 2 : 1];
+    if constexpr (PREFETCH) {
+      if (a.out_kind == OUT_CX) {
+        const T* Qg0 = a.Qb + (size_t)b * a.strideQ;
+        const T* Cg0 = a.C + (size_t)b * a.strideC;
+#pragma unroll
+        for (int i = 0; i < QPRE; ++i) {
+          const int e = tid + i * TPB;
+          qpre[i] = e < L * L ? Qg0[e] : T(0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          const int e = tid + i * TPB;
+          cpre[i] = (!a.first_update && e < n * L) ? Cg0[e] : T(0);
+        }
+      }
+    }
     for (int e = tid; e < p * p; e += TPB) sX[e] = Pg[e];
     if (a.first_update) {
       for (int e = tid; e < L * p; e += TPB) sK[e] = T(0);
@@ -790,7 +826,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     }
     if (tid == 0) sz[L] = a.u_prev[b];
     for (int i = tid; i < n; i += TPB) sx[i] = a.x_now[(size_t)i * B + b];
-    __syncthreads();
+    block_sync<TPB>();
     KTRACE(1);
 
     // Pz (P symmetric: column walk is conflict-free in LDS)
@@ -800,7 +836,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       for (int j = 0; j < p; ++j) acc += sX[j * p + i] * sz[j];
       sPz[i] = acc;
     }
-    __syncthreads();
+    block_sync<TPB>();
     T part = T(0);
     for (int i = tid; i < p; i += TPB) part += sz[i] * sPz[i];
     const T d = a.lam + block_sum<T, TPB>(part, red);
@@ -821,7 +857,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       for (int j = 0; j < p; ++j) acc -= sK[r * p + j] * sz[j];
       sE[r] = acc;
     }
-    __syncthreads();
+    block_sync<TPB>();
     // K <- K + (y - K z) g',  g = Pz / d                            duffing.py:927-938
     for (int e = tid; e < L * p; e += TPB) {
       const int r = e / p, j = e - r * p;
@@ -835,14 +871,29 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       // ---- C = bar_X bar_Q, target x_{k+1}, regressor psi(x_k)      duffing.py:943-953
       const T* Qg = a.Qb + (size_t)b * a.strideQ;
       T* Cg = a.C + (size_t)b * a.strideC;
-      __syncthreads();  // everyone is done with P in sX and with sE / sPz
-      for (int e = tid; e < L * L; e += TPB) sX[e] = Qg[e];
-      if (a.first_update) {
-        for (int e = tid; e < n * L; e += TPB) sC[e] = T(0);
+      block_sync<TPB>();  // everyone is done with P in sX and with sE / sPz
+      if (PREFETCH && n * L <= 2 * TPB) {
+        if constexpr (PREFETCH) {
+#pragma unroll
+          for (int i = 0; i < QPRE; ++i) {
+            const int e = tid + i * TPB;
+            if (e < L * L) sX[e] = qpre[i];
+          }
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int e = tid + i * TPB;
+            if (e < n * L) sC[e] = cpre[i];
+          }
+        }
       } else {
-        for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
+        for (int e = tid; e < L * L; e += TPB) sX[e] = Qg[e];
+        if (a.first_update) {
+          for (int e = tid; e < n * L; e += TPB) sC[e] = T(0);
+        } else {
+          for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
+        }
       }
-      __syncthreads();
+      block_sync<TPB>();
       for (int i = tid; i < L; i += TPB) {
         T acc = T(0);
 #pragma unroll
@@ -854,7 +905,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
         for (int j = 0; j < L; ++j) acc -= sC[r * L + j] * sz[j];
         sE[r] = acc;
       }
-      __syncthreads();
+      block_sync<TPB>();
       T part2 = T(0);
       for (int i = tid; i < L; i += TPB) part2 += sz[i] * sPz[i];
       const T dc = a.lam + block_sum<T, TPB>(part2, red);
@@ -871,7 +922,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
         Cg[e] = v;
       }
     }
-    __syncthreads();
+    block_sync<TPB>();
     KTRACE(4);
   } else if (a.phases & PH_CONDENSE) {
     const T* Kg = a.K + (size_t)b * a.strideK;
@@ -881,7 +932,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
     }
     for (int i = tid; i < L; i += TPB) sy[i] = a.psi_now[i * a.pn_sl + b * a.pn_sb];
-    __syncthreads();
+    block_sync<TPB>();
   }
 
   // =====================================================================================
@@ -898,7 +949,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       const int k = e / q, r = e - k * q;
       sEr[e] = -ref[r * N + k];
     }
-    __syncthreads();
+    block_sync<TPB>();
     KTRACE(5);
     // v_{j+1} = A v_j, w_{j+1} = A w_j;  g_j = Co v_j;  e_j = Co w_j - r_{j-1}
     if constexpr (L_ > 0 && TPB == 64 && (L_ + Q_ <= 32)) {
@@ -934,7 +985,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
           }
           half_gather(acc, v0, v1);  // v_{j+1} / w_{j+1} (lanes >= L are never read back)
         }
-        __syncthreads();
+        block_sync<TPB>();
       } else {
       int cur = 0;
       for (int j = 0; j <= N; ++j) {
@@ -972,7 +1023,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
           }
           if (isC && j >= 1) sEr[(j - 1) * q + (t - L)] += acc;  // e_j = Co w_j - r_{j-1}
         }
-        __syncthreads();
+        block_sync<TPB>();
         cur ^= 1;
       }
       }
@@ -1015,7 +1066,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
           if (j < N) sG[j * q + (t - L)] = accv;             // g_j = Co v_j
           if (j >= 1) sEr[(j - 1) * q + (t - L)] += accw;    // e_j = Co w_j - r_{j-1}
         }
-        __syncthreads();
+        block_sync<TPB>();
         cur ^= 1;
       }
     } else {
@@ -1070,7 +1121,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
             }
           }
         }
-        __syncthreads();
+        block_sync<TPB>();
         cur ^= 1;
       }
     }
@@ -1110,7 +1161,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     if (a.Wterm) {
       // terminal block of Q_bar is PN instead of Qw I (Koopman_update.m:381); Wterm = PN - Qw I:
       //   H[a][b] += g_{N-1-a}' sym(W) g_{N-1-b},   f[a] += 2 g_{N-1-a}' W e_N
-      __syncthreads();
+      block_sync<TPB>();
       for (int e = tid; e < N * N; e += TPB) {
         const int aa = e / N, bb = e - aa * N;
         const T* ga = sG + (N - 1 - aa) * q;
@@ -1129,7 +1180,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
         sf[aa] += T(2) * acc;
       }
     }
-    __syncthreads();
+    block_sync<TPB>();
     KTRACE(7);
     if (a.H_out) {
       T* Hg = a.H_out + (size_t)b * N * N;
@@ -1145,7 +1196,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     if (a.F_in) {
       // shared-model mode: f_b = F psi_b + f0 (the per-trajectory part of the condensed QP)
       for (int i = tid; i < L; i += TPB) sy[i] = a.psi_now[i * a.pn_sl + b * a.pn_sb];
-      __syncthreads();
+      block_sync<TPB>();
       for (int e = tid; e < N; e += TPB) {
         T acc = a.f0_in[e];
         for (int l = 0; l < L; ++l) acc += a.F_in[e * L + l] * sy[l];
@@ -1155,7 +1206,7 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
       const T* fg = a.f_in + (size_t)b * N;
       for (int e = tid; e < N; e += TPB) sf[e] = fg[e];
     }
-    __syncthreads();
+    block_sync<TPB>();
   }
 
   // =====================================================================================
@@ -1171,13 +1222,20 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
     if constexpr (N_ > 0 && N_ <= 40 && TPB == 64) {
       // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
       if (qp_regs<T, N_>(sH, sf, a, b, red, qx)) {
-        __syncthreads();
+        block_sync<TPB>();
         qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, b, N, true);
       }
     } else {
       qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, b, N, false);
     }
   }
+}
+
+// one workgroup of TPB threads per trajectory
+template <typename T, int TPB, int L_, int N_, int Q_>
+__global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  step_body<T, TPB, L_, N_, Q_>(a, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
 
 // ---------------------------------------------------------------------------------------
