@@ -148,7 +148,7 @@ struct Impl : kmpc_handle {
     for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev, (void*)dWarm,
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
-                      (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt})
+                      (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -181,6 +181,7 @@ struct Impl : kmpc_handle {
       if ((rc = upload_padded(dbh[layer - 1], b, 1, rows, 1, Hp))) return rc;
     }
     layer_set[layer] = true;
+    packed_ok = false;
     return 0;
   }
 
@@ -382,6 +383,78 @@ struct Impl : kmpc_handle {
     return 0;
   }
 
+  // ---- fused roll-out (one launch for all the steps; rollout_kernel in step_kernel.hip) ----------------
+  T *dWhp[2] = {nullptr, nullptr}, *dWop = nullptr;  // hidden / output weights as MFMA A-fragments
+  bool packed_ok = false;
+  int fused_launches = 0;   // profiling: launches and steps covered by the recorded events
+  int64_t fused_steps = 0;
+  int pack_encoder(hipStream_t s) {
+    if (packed_ok) return 0;
+    const int KS = (cfg.hidden + 3) / 4;
+    const int nhh = cfg.layers - 1;
+    for (int k = 0; k < nhh; ++k) {
+      if (!dWhp[k]) HIPCHK(hipMalloc(&dWhp[k], sizeof(T) * (size_t)(Hp / 16) * KS * 64));
+      HIPCHK(launch_pack_afrag<T>(dWh[k], Hp, Hp, KS, dWhp[k], s));
+    }
+    if (!dWop) HIPCHK(hipMalloc(&dWop, sizeof(T) * (size_t)(Lp / 16) * KS * 64));
+    HIPCHK(launch_pack_afrag<T>(dWo, Lp, Hp, KS, dWop, s));
+    packed_ok = true;
+    return 0;
+  }
+  bool fused_rollout_ok() const {
+    static const bool off = getenv("KMPC_NO_FUSED_ROLLOUT") != nullptr;  // measurement aid: per-step launches
+    return !off && n == 2 && rollout_fused_available<T>(n, L, N, q, threads, cfg.lift_kind != KMPC_LIFT_MLP);
+  }
+  int rollout_fused(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
+                    void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) {
+    int rc = check_lift_ready();
+    if (rc) return rc;
+    RolloutArgs<T> r{};
+    r.s = base_args(B);
+    r.s.u_prev = dUprev; r.s.x_now = (const T*)X;
+    r.s.ref = (const T*)ref; r.s.ref_per_traj = rpt;
+    r.s.U0 = dU0; r.s.Useq = nullptr; r.s.u_store = dUprev; r.s.status = st; r.s.iters = it;
+    r.s.x_warm = cfg.cold_start ? nullptr : dWarm;
+    r.s.plant = plant; r.s.plant_h = (T)hs; r.s.X_rw = (T*)X;
+    r.s.pp_sl = 1; r.s.pp_sb = L; r.s.pn_sl = 1; r.s.pn_sb = L;
+    r.s.accumulate = 1;
+    if (cfg.lift_kind == KMPC_LIFT_MLP) {
+      if ((rc = pack_encoder(s))) return rc;
+      r.lift_rbf = 0;
+      r.W1 = dW1; r.b1 = db1; r.Whp[0] = dWhp[0]; r.Whp[1] = dWhp[1]; r.bh[0] = dbh[0]; r.bh[1] = dbh[1];
+      r.Wop = dWop; r.bo = dbo; r.Hp = Hp; r.Lp = Lp; r.KS = (cfg.hidden + 3) / 4; r.nhh = cfg.layers - 1;
+    } else {
+      r.lift_rbf = 1;
+      r.cx = dcx; r.eps = (T)cfg.rbf_eps; r.rbf_matlab = cfg.lift_kind == KMPC_LIFT_RBF_MATLAB ? 1 : 0;
+    }
+    r.psi[0] = dPsi[0]; r.psi[1] = dPsi[1]; r.cur = cur;
+    r.steps = steps; r.step0 = step0; r.switch_step = switch_step;
+    r.have_prev = have_prev ? 1 : 0; r.rls_fresh = rls_fresh ? 1 : 0;
+    r.U_log = (T*)Ulog; r.X_log = (T*)Xlog;
+    const bool rec = prof && ev_used + 3 <= EV_CAP;
+    if (rec) {
+      while (ev.size() < ev_used + 3) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ev.push_back(e);
+      }
+      HIPCHK(hipEventRecord(ev[ev_used], s));
+      HIPCHK(hipEventRecord(ev[ev_used + 1], s));  // (no separate lift kernel)
+    }
+    HIPCHK(launch_rollout_fused<T>(r, s));
+    if (rec) {
+      HIPCHK(hipEventRecord(ev[ev_used + 2], s));
+      ev_used += 3;
+      fused_launches += 1;
+      fused_steps += steps;
+    }
+    // the host-side flags follow the kernel's own bookkeeping
+    if (steps >= 2 || (steps == 1 && have_prev)) rls_fresh = false;
+    have_prev = true;
+    cur ^= (steps & 1);
+    return 0;
+  }
+
   T* dU0 = nullptr;  // rollout scratch [B]
   bool accumulate = false;
   int fuse_plant = -1, fuse_switched = 0;  // rollouts: the step kernel advances the plant itself
@@ -392,6 +465,10 @@ struct Impl : kmpc_handle {
     if (!dU0) HIPCHK(hipMalloc(&dU0, sizeof(T) * (size_t)B));
     if (st) HIPCHK(hipMemsetAsync(st, 0, sizeof(int32_t) * (size_t)B, s));
     if (it) HIPCHK(hipMemsetAsync(it, 0, sizeof(int32_t) * (size_t)B, s));
+    if (n != 2) FAIL(-3, "plants are two-state systems");
+    if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
+    if (steps > 0 && fused_rollout_ok())
+      return rollout_fused(plant, X, ref, rpt, steps, step0, switch_step, hs, Ulog, Xlog, st, it, s);
     for (int i = 0; i < steps; ++i) {
       const int gi = step0 + i;
       T* u = Ulog ? (T*)Ulog + (size_t)i * B : dU0;

@@ -111,4 +111,22 @@ hipError_t launch_axpby(double* g, const double* d, double a, int count, hipStre
 INST(float)
 INST(double)
 
+// Row-major zero-padded weights (Mp x Hp) -> MFMA A-fragments [tile][k-step][lane]: lane l of tile t, k-step ks
+// holds W[16 t + (l & 15)][4 ks + (l >> 4)], so a wave reads one fragment as 64 consecutive elements.
+template <typename T> __global__ void pack_afrag_kernel(const T* src, int Mp, int Hp, int KS, T* dst) {
+  const int total = (Mp / 16) * KS * 64;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int l = e & 63, ks = (e >> 6) % KS, t = (e >> 6) / KS;
+    const int col = 4 * ks + (l >> 4);
+    dst[e] = col < Hp ? src[(size_t)(16 * t + (l & 15)) * Hp + col] : T(0);
+  }
+}
+template <typename T> hipError_t launch_pack_afrag(const T* src, int Mp, int Hp, int KS, T* dst, hipStream_t s) {
+  const int total = (Mp / 16) * KS * 64;
+  hipLaunchKernelGGL((pack_afrag_kernel<T>), dim3((total + 255) / 256), dim3(256), 0, s, src, Mp, Hp, KS, dst);
+  return hipGetLastError();
+}
+template hipError_t launch_pack_afrag<float>(const float*, int, int, int, float*, hipStream_t);
+template hipError_t launch_pack_afrag<double>(const double*, int, int, int, double*, hipStream_t);
+
 }  // namespace kmpc

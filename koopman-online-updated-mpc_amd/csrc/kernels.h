@@ -67,6 +67,25 @@ template <typename T> struct LiftArgs {
   const T* cx; T eps; int rbf_matlab;
 };
 
+// Fused roll-out (float64, single-wave trajectories): ONE launch runs `steps` iterations of the loop body
+// lift -> RLS -> condense -> QP -> plant for 16 trajectories per workgroup (rollout_kernel in step_kernel.hip).
+template <typename T> struct RolloutArgs {
+  StepArgs<T> s;            // per-step template; phases / first_update / plant_switched / psi pointers are set in-kernel
+  int lift_rbf;             // 0: MLP encoder on MFMA (cooperative), 1: thin-plate RBF (per wave)
+  // MLP: W1 (Hp x 4) and biases as in LiftArgs; hidden and output weights as packed MFMA A-fragments
+  // [tile][k-step][lane] (pack_afrag_kernel), KS = ceil(hidden / 4) k-steps of 4
+  const T* W1; const T* b1;
+  const T* Whp[2]; const T* bh[2];
+  const T* Wop; const T* bo;
+  int Hp, Lp, KS, nhh;
+  const T* cx; T eps; int rbf_matlab;
+  T* psi[2];                // [B][L] ping-pong: psi[cur] receives the lift of the first step
+  int cur;
+  int steps, step0, switch_step, have_prev, rls_fresh;
+  int wstride;              // per-wave LDS region in elements
+  T* U_log; T* X_log;       // optional (steps x B), (steps x n x B)
+};
+
 // K7: Gram sums of one step's transitions (rows [psi_prev; u_prev; psi_now; x_now] against [psi_prev; u_prev])
 template <typename T> struct GramArgs {
   int B, n, L, max_blocks;
@@ -83,6 +102,10 @@ template <typename T> struct PlantArgs {
 size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2);
 
 template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s);
+// true if (T, n, L, N, q, threads, lift kind) has a fused roll-out instantiation that fits in LDS
+template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf);
+template <typename T> hipError_t launch_rollout_fused(const RolloutArgs<T>& a, hipStream_t s);
+template <typename T> hipError_t launch_pack_afrag(const T* src, int Mp, int Hp, int KS, T* dst, hipStream_t s);
 template <typename T> hipError_t launch_lift_mlp(const LiftArgs<T>& a, hipStream_t s);
 template <typename T> hipError_t launch_lift_rbf(const LiftArgs<T>& a, hipStream_t s);
 template <typename T> hipError_t launch_plant(const PlantArgs<T>& a, hipStream_t s);

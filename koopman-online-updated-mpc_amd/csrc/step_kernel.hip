@@ -72,8 +72,21 @@ template <int TPB> __device__ __forceinline__ void block_sync() {
   }
 }
 template <int TPB> __device__ __forceinline__ int local_tid() {
-  return TPB == 64 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+  int t = TPB == 64 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+  // opaque on purpose: inside the step loop of the fused roll-out every address and mask derived from the lane
+  // index is loop-invariant, and hoisting them all out of the loop costs far more registers than recomputing
+  asm volatile("" : "+v"(t));
+  return t;
 }
+
+// the arguments that change from step to step inside a fused roll-out (everything else stays in the kernel
+// argument segment); the per-step kernel fills it from its StepArgs
+template <typename T> struct StepVar {
+  int phases, first_update, plant_switched;
+  const T* psi_prev;
+  const T* psi_now;
+  T* U0;
+};
 
 template <typename T> struct Tol;
 template <> struct Tol<double> {
@@ -289,9 +302,10 @@ template <typename T> __device__ __forceinline__ T wave_min_x(T v) {
 }
 
 template <typename T, int N_>
-__device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, int b, T* red, T* qx_out) {
+__device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
+                                        T* red, T* qx_out) {
   constexpr int RM = (N_ + 7) / 8;
-  const int tid = threadIdx.x & 63, ti = tid >> 3, tj = tid & 7;
+  const int tid = local_tid<64>(), ti = tid >> 3, tj = tid & 7;
   const int myvar = ti + 8 * tj;
   const bool own = (tj < RM) && (myvar < N_);
   // per-variable box: in the delta-u form the first increment also keeps the absolute input inside
@@ -496,11 +510,11 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   }
   if (tid == 0) {  // lane 0 owns variable 0
     const T uout = a.du_mode ? uprev + x : x;  // U0 = U0 + dU*(1)   (Tank_System.m:192)
-    if (a.U0) a.U0[b] = uout;
+    if (sv.U0) sv.U0[b] = uout;
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
       T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
-      plant_apply<T>(a.plant, a.plant_switched, a.plant_h, x1, x2, uout);
+      plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
     }
@@ -520,7 +534,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
 // ---------------------------------------------------------------------------------------
 template <typename T, int TPB>
 __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T* qxa, T* qg, T* red,
-                                       const StepArgs<T>& a, int b, int N, bool as_from_start) {
+                                       const StepArgs<T>& a, const StepVar<T>& sv, int b, int N, bool as_from_start) {
   const int tid = local_tid<TPB>(), B = a.B;
   const T uprev = a.du_mode ? a.u_prev[b] : T(0);
   T lb = a.lb, ub = a.ub;
@@ -737,11 +751,11 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
   }
   if (tid == 0) {
     const T uout = a.du_mode ? uprev + qx[0] : qx[0];
-    if (a.U0) a.U0[b] = uout;
+    if (sv.U0) sv.U0[b] = uout;
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
       T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
-      plant_apply<T>(a.plant, a.plant_switched, a.plant_h, x1, x2, uout);
+      plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
     }
@@ -755,7 +769,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
 // Four waves per SIMD (<= 128 VGPRs) for the small static configurations: BASELINE cfg2 puts exactly 4096
 // trajectories = 4 waves per SIMD on the chip, so one register too many costs a whole second round.
 template <typename T, int TPB, int L_, int N_, int Q_>
-__device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* const sm) {
+__device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>& sv, const int b, T* const sm) {
   const int tid = local_tid<TPB>();
   const int n = a.n, L = L_ ? L_ : a.L, p = L + 1, q = Q_ ? Q_ : a.q, N = N_ ? N_ : a.N, B = a.B;
 
@@ -789,7 +803,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* 
   // =====================================================================================
   // phase 1: recursive least squares (gain form; algebraically K_A inv_K_G of the reference)
   // =====================================================================================
-  if (a.phases & PH_RLS) {
+  if (sv.phases & PH_RLS) {
     const T* Pg = a.P + (size_t)b * a.strideP;
     T* Kg = a.K + (size_t)b * a.strideK;
     // Static sizes: bar_Q and C are requested from HBM now, together with P and K, and wait in registers
@@ -810,19 +824,19 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* 
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int e = tid + i * TPB;
-          cpre[i] = (!a.first_update && e < n * L) ? Cg0[e] : T(0);
+          cpre[i] = (!sv.first_update && e < n * L) ? Cg0[e] : T(0);
         }
       }
     }
     for (int e = tid; e < p * p; e += TPB) sX[e] = Pg[e];
-    if (a.first_update) {
+    if (sv.first_update) {
       for (int e = tid; e < L * p; e += TPB) sK[e] = T(0);
     } else {
       for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
     }
     for (int i = tid; i < L; i += TPB) {
-      sz[i] = a.psi_prev[i * a.pp_sl + b * a.pp_sb];
-      sy[i] = a.psi_now[i * a.pn_sl + b * a.pn_sb];
+      sz[i] = sv.psi_prev[i * a.pp_sl + b * a.pp_sb];
+      sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
     }
     if (tid == 0) sz[L] = a.u_prev[b];
     for (int i = tid; i < n; i += TPB) sx[i] = a.x_now[(size_t)i * B + b];
@@ -887,7 +901,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* 
         }
       } else {
         for (int e = tid; e < L * L; e += TPB) sX[e] = Qg[e];
-        if (a.first_update) {
+        if (sv.first_update) {
           for (int e = tid; e < n * L; e += TPB) sC[e] = T(0);
         } else {
           for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
@@ -917,28 +931,28 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* 
       }
       for (int e = tid; e < n * L; e += TPB) {
         const int r = e / L, j = e - r * L;
-        const T v = (a.c_skip_first && a.first_update) ? T(0) : sC[e] + sE[r] * (sPz[j] * dcinv);
+        const T v = (a.c_skip_first && sv.first_update) ? T(0) : sC[e] + sE[r] * (sPz[j] * dcinv);
         sC[e] = v;
         Cg[e] = v;
       }
     }
     block_sync<TPB>();
     KTRACE(4);
-  } else if (a.phases & PH_CONDENSE) {
+  } else if (sv.phases & PH_CONDENSE) {
     const T* Kg = a.K + (size_t)b * a.strideK;
     for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
     if (a.out_kind == OUT_CX) {
       const T* Cg = a.C + (size_t)b * a.strideC;
       for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
     }
-    for (int i = tid; i < L; i += TPB) sy[i] = a.psi_now[i * a.pn_sl + b * a.pn_sb];
+    for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
     block_sync<TPB>();
   }
 
   // =====================================================================================
   // phase 2: condensed QP  H = Qw Phi'Phi + Rw I,  f = 2 Qw Phi'(Gamma psi - r)
   // =====================================================================================
-  if (a.phases & PH_CONDENSE) {
+  if (sv.phases & PH_CONDENSE) {
     const T* ref = a.ref + (a.ref_per_traj ? (size_t)b * q * N : 0);
     const bool cx = (a.out_kind == OUT_CX);
     for (int i = tid; i < L; i += TPB) {
@@ -1190,12 +1204,12 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* 
       T* fg = a.f_out + (size_t)b * N;
       for (int e = tid; e < N; e += TPB) fg[e] = sf[e];
     }
-  } else if (a.phases & PH_QP) {
+  } else if (sv.phases & PH_QP) {
     const T* Hg = a.H_in + (a.h_shared ? (size_t)0 : (size_t)b * N * N);
     for (int e = tid; e < N * N; e += TPB) sH[e] = Hg[e];
     if (a.F_in) {
       // shared-model mode: f_b = F psi_b + f0 (the per-trajectory part of the condensed QP)
-      for (int i = tid; i < L; i += TPB) sy[i] = a.psi_now[i * a.pn_sl + b * a.pn_sb];
+      for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
       block_sync<TPB>();
       for (int e = tid; e < N; e += TPB) {
         T acc = a.f0_in[e];
@@ -1218,15 +1232,15 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* 
   // in T only costs an extra (cheap) iteration.  Cold start at clip(0) as the reference
   // (duffing.py:634-635); the minimiser is unique, so the start only affects the work.
   // =====================================================================================
-  if (a.phases & PH_QP) {
+  if (sv.phases & PH_QP) {
     if constexpr (N_ > 0 && N_ <= 40 && TPB == 64) {
       // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
-      if (qp_regs<T, N_>(sH, sf, a, b, red, qx)) {
+      if (qp_regs<T, N_>(sH, sf, a, sv, b, red, qx)) {
         block_sync<TPB>();
-        qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, b, N, true);
+        qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
       }
     } else {
-      qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, b, N, false);
+      qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, false);
     }
   }
 }
@@ -1235,8 +1249,248 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const int b, T* 
 template <typename T, int TPB, int L_, int N_, int Q_>
 __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  step_body<T, TPB, L_, N_, Q_>(a, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
+  const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0};
+  step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
+
+// ---------------------------------------------------------------------------------------
+// Fused roll-out: `steps` iterations of the reference loop body (duffing.py:823-1012) in ONE launch.
+//
+// A workgroup of 16 waves owns 16 trajectories and walks them through all the steps; workgroups never
+// synchronise with each other, so the launch no longer waits for the slowest QP of the whole batch at every
+// step (a per-step launch is one round of waves: it lasts as long as its slowest trajectory), only the 16
+// trajectories of a workgroup meet -- at the lift, which they compute together:
+//   MLP encoder on v_mfma_f64_16x16x4_f64 with the 16 trajectories as the N dimension; the 16 waves split
+//   the hidden rows (M tiles) and the K dimension, partial tiles are summed through LDS in a fixed order.
+//   The lift scratch overlays the per-wave LDS regions, which are dead between two steps.
+// RBF lift: every wave lifts its own state, the waves of a workgroup never meet.
+// ---------------------------------------------------------------------------------------
+typedef double d4_t __attribute__((ext_vector_type(4)));
+constexpr int RO_WAVES = 16;
+constexpr int RO_PART = RO_WAVES * 2 * 256;         // partial accumulator tiles [wave][slot][256]
+constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
+constexpr int RO_SCRATCH = RO_PART + 2 * RO_ACT + 64 * 16;  // + psi (Lp <= 64) x 16
+constexpr int RO_KC = 8;                            // k-steps per wave and layer (KS <= 32, four K chunks)
+
+__device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int t0, bool t1ok, int ks0, int ks1,
+                                               int lane, double (&af0)[RO_KC], double (&af1)[RO_KC]) {
+#pragma unroll
+  for (int i = 0; i < RO_KC; ++i) {
+    const int ks = ks0 + i;
+    const bool ok = ks < ks1;
+    af0[i] = ok ? Wp[((size_t)t0 * KS + ks) * 64 + lane] : 0.0;
+    af1[i] = (ok && t1ok) ? Wp[((size_t)(t0 + 4) * KS + ks) * 64 + lane] : 0.0;
+  }
+}
+
+template <int L_, int N_, int Q_>
+__global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArgs<double> ra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* const smem = reinterpret_cast<double*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: trajectory index and LDS base stay scalar
+  const int B = ra.s.B, n = ra.s.n, L = L_;
+  const int b0 = blockIdx.x * (int)(blockDim.x >> 6), b = b0 + wave;  // 16 waves (MLP lift); RBF: as many as fit in LDS
+  const bool live = b < B;
+  // lift scratch (overlays the per-wave regions between two steps)
+  double* const sPart = smem;
+  double* const sAct0 = smem + RO_PART;
+  double* const sAct1 = sAct0 + RO_ACT;
+  double* const sPsi = sAct1 + RO_ACT;
+
+  bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
+  int cur = ra.cur;
+  const int Hp = ra.Hp, KS = ra.KS, MTH = Hp >> 4, MTO = ra.Lp >> 4;
+  // hidden layers: wave (mg, kq) owns M tiles mg, mg+4 and the kq-th quarter of the k-steps
+  const int mg = wave & 3, kq = wave >> 2;
+  const int kch = (KS + 3) >> 2;
+  const int hks0 = kq * kch, hks1 = (hks0 + kch < KS) ? hks0 + kch : KS;
+  const bool t1ok = mg + 4 < MTH;
+  // output layer: tile to, k-chunk kc of nch
+  const int MTOp = MTO == 3 ? 4 : MTO, nch = RO_WAVES / MTOp;
+  const int to = wave % MTOp, kc = wave / MTOp;
+  const int och = (KS + nch - 1) / nch;
+  const int oks0 = kc * och, oks1 = (oks0 + och < KS) ? oks0 + och : KS;
+  const bool took = to < MTO;
+
+  typedef const RolloutArgs<double> __attribute__((address_space(4))) * kernarg_ptr_t;
+  for (int k = 0; k < ra.steps; ++k) {
+    // The step arguments stay in the kernel-argument segment and are re-read where they are used: hoisted out
+    // of this loop they would pin ~150 scalar registers for the whole kernel (the asm hides the loop invariance).
+    kernarg_ptr_t kp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const StepArgs<double>& a = *(const StepArgs<double>*)(&kp->s);  // psi strides (1, L), accumulate = 1: host
+    double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
+    if (ra.lift_rbf) {
+      if (live && lane < L) {
+        double x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = (i < n) ? a.X_rw[(size_t)i * B + b] : 0.0;
+        const double* c = ra.cx + (size_t)lane * n;
+        if (ra.rbf_matlab) {
+          double r2 = 0.0;
+          for (int i = 0; i < n; ++i) { const double d = x[i] - c[i]; r2 += d * d; }
+          psi_i = r2 > 0.0 ? r2 * log(sqrt(r2)) : 0.0;
+        } else {
+          double xx = 0.0, cc = 0.0, xc = 0.0;
+          for (int i = 0; i < n; ++i) { xx += x[i] * x[i]; cc += c[i] * c[i]; xc += x[i] * c[i]; }
+          double d2 = xx - 2.0 * xc + cc;
+          d2 = d2 > 0.0 ? d2 : 0.0;
+          const double d = sqrt(d2);
+          psi_i = d * d * log(d + ra.eps);
+        }
+      }
+    } else {
+      double af0[RO_KC], af1[RO_KC];
+      if (ra.nhh > 0) ro_load_afrags(ra.Whp[0], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
+      __syncthreads();  // every wave is done with its LDS region (previous step) and with X
+      // ---- layer 1 (K = n <= 4) on the VALU, straight into B-fragment layout
+      for (int e = tid; e < Hp * 16; e += 64 * RO_WAVES) {
+        const int row = e >> 4, col = e & 15;
+        const int bb = b0 + col;
+        double v = ra.b1[row];
+        if (bb < B) {
+          const double* wr = ra.W1 + 4 * row;
+          for (int i = 0; i < n; ++i) v += wr[i] * a.X_rw[(size_t)i * B + bb];
+        }
+        sAct0[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+      }
+      __syncthreads();
+      // ---- hidden -> hidden layers
+      for (int h = 0; h < ra.nhh; ++h) {
+        const double* act = (h & 1) ? sAct1 : sAct0;
+        double* actn = (h & 1) ? sAct0 : sAct1;
+        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int i = 0; i < RO_KC; ++i) {
+          if (hks0 + i < hks1) {
+            const double bf = act[(hks0 + i) * 64 + lane];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i], bf, acc0, 0, 0, 0);
+            if (t1ok) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[i], bf, acc1, 0, 0, 0);
+          }
+        }
+        double* pw = sPart + (size_t)wave * 512;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { pw[r * 64 + lane] = acc0[r]; pw[256 + r * 64 + lane] = acc1[r]; }
+        // the next layer's weights travel while the partial tiles are reduced
+        if (h + 1 < ra.nhh) ro_load_afrags(ra.Whp[h + 1], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
+        else if (took) ro_load_afrags(ra.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
+        __syncthreads();
+        const double* bias = ra.bh[h];
+        for (int e = tid; e < MTH * 256; e += 64 * RO_WAVES) {
+          const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
+          const double* pp = sPart + (size_t)(t & 3) * 512 + (size_t)(t >> 2) * 256 + rl;
+          const double sum = (pp[0] + pp[4 * 512]) + (pp[8 * 512] + pp[12 * 512]);  // kq = 0..3, fixed order
+          const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
+          const double v = sum + bias[row];
+          actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+        }
+        __syncthreads();
+      }
+      // ---- output layer
+      {
+        const double* act = (ra.nhh & 1) ? sAct1 : sAct0;
+        if (ra.nhh == 0 && took) ro_load_afrags(ra.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
+        d4_t acc0 = {0.0, 0.0, 0.0, 0.0};
+        if (took) {
+#pragma unroll
+          for (int i = 0; i < RO_KC; ++i)
+            if (oks0 + i < oks1)
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i], act[(oks0 + i) * 64 + lane], acc0, 0, 0, 0);
+        }
+        double* pw = sPart + (size_t)wave * 512;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) pw[r * 64 + lane] = acc0[r];
+        __syncthreads();
+        for (int e = tid; e < MTO * 256; e += 64 * RO_WAVES) {
+          const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
+          double sum = 0.0;
+          for (int c = 0; c < nch; ++c) sum += sPart[(size_t)(c * MTOp + t) * 512 + rl];
+          const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
+          sPsi[row * 16 + col] = sum + ra.bo[row];
+        }
+        __syncthreads();
+        if (lane < L) psi_i = sPsi[lane * 16 + wave];
+        __syncthreads();  // the scratch is free again: the waves go their own way
+      }
+    }
+
+    if (live) {
+      int woff = wave * ra.wstride, bk = b;
+      asm volatile("" : "+s"(woff), "+s"(bk));  // (as local_tid: keeps the step's address arithmetic inside the loop)
+      double* const wsm = smem + woff;
+      double* const psi_now = ra.psi[cur];
+      if (lane < L) psi_now[(size_t)b * L + lane] = psi_i;
+      __threadfence_block();  // the step reads psi back through its ordinary (global) input
+      StepVar<double> sv;
+      sv.psi_now = psi_now;
+      sv.psi_prev = ra.psi[cur ^ 1];
+      sv.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
+      sv.first_update = fresh ? 1 : 0;
+      sv.plant_switched = (ra.switch_step >= 0 && ra.step0 + k >= ra.switch_step) ? 1 : 0;
+      sv.U0 = ra.U_log ? ra.U_log + (size_t)k * B : a.U0;
+      step_body<double, 64, L_, N_, Q_>(a, sv, bk, wsm);
+      if (ra.X_log) {
+        __threadfence_block();
+        if (lane < n) ra.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
+      }
+    }
+    if (have_prev) fresh = false;
+    have_prev = true;
+    cur ^= 1;
+  }
+}
+
+// waves (= trajectories) per workgroup of the fused roll-out: the MLP lift is written for 16; the RBF lift
+// needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.  0: does not fit.
+static int rollout_waves(int n, int L, int q, int N, bool rbf) {
+  const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr) + 15) & ~(size_t)15;
+  const int fit = (int)((160 * 1024) / per_wave);
+  if (!rbf) return fit >= RO_WAVES ? RO_WAVES : 0;
+  return fit >= RO_WAVES ? RO_WAVES : (fit >= 8 ? 8 : (fit >= 4 ? 4 : 0));
+}
+template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
+  RolloutArgs<double> k = a;
+  const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, a.lift_rbf != 0);
+  if (waves == 0) return hipErrorInvalidValue;
+  const size_t per_wave = step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2) / sizeof(double);
+  k.wstride = (int)((per_wave + 1) & ~(size_t)1);
+  size_t elems = (size_t)k.wstride * waves;
+  if (!a.lift_rbf && elems < (size_t)RO_SCRATCH) elems = RO_SCRATCH;
+  const size_t lds = elems * sizeof(double);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  const int grid = (a.s.B + waves - 1) / waves;
+  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_>), dim3(grid), dim3(64 * waves), lds, s, k);
+  return hipGetLastError();
+}
+
+template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
+  if (sizeof(T) != 8 || threads == 256 || n > 4) return false;
+  const bool inst = (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
+                    (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2);
+  return inst && rollout_waves(n, L, q, N, rbf) > 0;
+}
+template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
+  if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
+  if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 4 * RO_KC || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
+    return hipErrorInvalidValue;
+  if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
+  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 2) return launch_rollout_impl<8, 10, 2>(a, s);
+  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 8) return launch_rollout_impl<8, 10, 8>(a, s);
+  if (a.s.L == 8 && a.s.N == 30 && a.s.q == 8) return launch_rollout_impl<8, 30, 8>(a, s);
+  if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);
+  return hipErrorInvalidValue;
+}
+template <> hipError_t launch_rollout_fused<float>(const RolloutArgs<float>&, hipStream_t) { return hipErrorInvalidValue; }
+template bool rollout_fused_available<float>(int, int, int, int, int, bool);
+template bool rollout_fused_available<double>(int, int, int, int, int, bool);
 
 // ---------------------------------------------------------------------------------------
 // launcher
