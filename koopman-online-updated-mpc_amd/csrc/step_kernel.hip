@@ -1287,8 +1287,8 @@ template <int L_, int N_, int Q_>
 __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArgs<double> ra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* const smem = reinterpret_cast<double*>(smem_raw);
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave-uniform: trajectory index and LDS base stay scalar
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave-uniform: trajectory index and LDS base stay scalar
   const int B = ra.s.B, n = ra.s.n, L = L_;
   const int b0 = blockIdx.x * (int)(blockDim.x >> 6), b = b0 + wave;  // 16 waves (MLP lift); RBF: as many as fit in LDS
   const bool live = b < B;
@@ -1319,15 +1319,19 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
     // of this loop they would pin ~150 scalar registers for the whole kernel (the asm hides the loop invariance).
     kernarg_ptr_t kp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(kp));
+    const RolloutArgs<double> __attribute__((address_space(4)))& R = *kp;
     const StepArgs<double>& a = *(const StepArgs<double>*)(&kp->s);  // psi strides (1, L), accumulate = 1: host
+    int tid = tid0;
+    asm volatile("" : "+v"(tid));  // (as local_tid: per-lane addresses are recomputed in the loop, not carried across it)
+    const int lane = tid & 63;
     double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
-    if (ra.lift_rbf) {
+    if (R.lift_rbf) {
       if (live && lane < L) {
         double x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = (i < n) ? a.X_rw[(size_t)i * B + b] : 0.0;
-        const double* c = ra.cx + (size_t)lane * n;
-        if (ra.rbf_matlab) {
+        const double* c = R.cx + (size_t)lane * n;
+        if (R.rbf_matlab) {
           double r2 = 0.0;
           for (int i = 0; i < n; ++i) { const double d = x[i] - c[i]; r2 += d * d; }
           psi_i = r2 > 0.0 ? r2 * log(sqrt(r2)) : 0.0;
@@ -1337,27 +1341,27 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
           double d2 = xx - 2.0 * xc + cc;
           d2 = d2 > 0.0 ? d2 : 0.0;
           const double d = sqrt(d2);
-          psi_i = d * d * log(d + ra.eps);
+          psi_i = d * d * log(d + R.eps);
         }
       }
     } else {
       double af0[RO_KC], af1[RO_KC];
-      if (ra.nhh > 0) ro_load_afrags(ra.Whp[0], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
+      if (R.nhh > 0) ro_load_afrags(R.Whp[0], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
       __syncthreads();  // every wave is done with its LDS region (previous step) and with X
       // ---- layer 1 (K = n <= 4) on the VALU, straight into B-fragment layout
       for (int e = tid; e < Hp * 16; e += 64 * RO_WAVES) {
         const int row = e >> 4, col = e & 15;
         const int bb = b0 + col;
-        double v = ra.b1[row];
+        double v = R.b1[row];
         if (bb < B) {
-          const double* wr = ra.W1 + 4 * row;
+          const double* wr = R.W1 + 4 * row;
           for (int i = 0; i < n; ++i) v += wr[i] * a.X_rw[(size_t)i * B + bb];
         }
         sAct0[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
       }
       __syncthreads();
       // ---- hidden -> hidden layers
-      for (int h = 0; h < ra.nhh; ++h) {
+      for (int h = 0; h < R.nhh; ++h) {
         const double* act = (h & 1) ? sAct1 : sAct0;
         double* actn = (h & 1) ? sAct0 : sAct1;
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
@@ -1373,10 +1377,10 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pw[r * 64 + lane] = acc0[r]; pw[256 + r * 64 + lane] = acc1[r]; }
         // the next layer's weights travel while the partial tiles are reduced
-        if (h + 1 < ra.nhh) ro_load_afrags(ra.Whp[h + 1], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
-        else if (took) ro_load_afrags(ra.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
+        if (h + 1 < R.nhh) ro_load_afrags(R.Whp[h + 1], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
+        else if (took) ro_load_afrags(R.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
         __syncthreads();
-        const double* bias = ra.bh[h];
+        const double* bias = R.bh[h];
         for (int e = tid; e < MTH * 256; e += 64 * RO_WAVES) {
           const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
           const double* pp = sPart + (size_t)(t & 3) * 512 + (size_t)(t >> 2) * 256 + rl;
@@ -1389,8 +1393,8 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
       }
       // ---- output layer
       {
-        const double* act = (ra.nhh & 1) ? sAct1 : sAct0;
-        if (ra.nhh == 0 && took) ro_load_afrags(ra.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
+        const double* act = (R.nhh & 1) ? sAct1 : sAct0;
+        if (R.nhh == 0 && took) ro_load_afrags(R.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0};
         if (took) {
 #pragma unroll
@@ -1407,7 +1411,7 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
           double sum = 0.0;
           for (int c = 0; c < nch; ++c) sum += sPart[(size_t)(c * MTOp + t) * 512 + rl];
           const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
-          sPsi[row * 16 + col] = sum + ra.bo[row];
+          sPsi[row * 16 + col] = sum + R.bo[row];
         }
         __syncthreads();
         if (lane < L) psi_i = sPsi[lane * 16 + wave];
@@ -1416,23 +1420,23 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
     }
 
     if (live) {
-      int woff = wave * ra.wstride, bk = b;
+      int woff = wave * R.wstride, bk = b;
       asm volatile("" : "+s"(woff), "+s"(bk));  // (as local_tid: keeps the step's address arithmetic inside the loop)
       double* const wsm = smem + woff;
-      double* const psi_now = ra.psi[cur];
+      double* const psi_now = R.psi[cur];
       if (lane < L) psi_now[(size_t)b * L + lane] = psi_i;
       __threadfence_block();  // the step reads psi back through its ordinary (global) input
       StepVar<double> sv;
       sv.psi_now = psi_now;
-      sv.psi_prev = ra.psi[cur ^ 1];
+      sv.psi_prev = R.psi[cur ^ 1];
       sv.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
       sv.first_update = fresh ? 1 : 0;
-      sv.plant_switched = (ra.switch_step >= 0 && ra.step0 + k >= ra.switch_step) ? 1 : 0;
-      sv.U0 = ra.U_log ? ra.U_log + (size_t)k * B : a.U0;
+      sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
+      sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
       step_body<double, 64, L_, N_, Q_>(a, sv, bk, wsm);
-      if (ra.X_log) {
+      if (R.X_log) {
         __threadfence_block();
-        if (lane < n) ra.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
+        if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
       }
     }
     if (have_prev) fresh = false;
