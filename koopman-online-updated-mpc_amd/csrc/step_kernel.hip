@@ -18,16 +18,21 @@
 #ifdef KMPC_TRACE
 // Measurement build only (make trace -> libkoopmpc_trace.so, tools/trace_phases.py): lane 0 of every
 // workgroup stamps the 100 MHz wall clock at the phase boundaries.  Never compiled into libkoopmpc.so.
-__device__ unsigned long long kmpc_trace_buf[8192 * 16];
+__device__ unsigned long long kmpc_trace_buf[8192 * 32];
 #define KTRACE(slot)                                                                                      \
   do {                                                                                                    \
-    if (tid == 0 && b < 8192) kmpc_trace_buf[b * 16 + (slot)] = wall_clock64();                          \
+    if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + (slot)] = wall_clock64();                          \
   } while (0)
 extern "C" int kmpc_trace_read(void* host, size_t bytes) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kmpc_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
 }
+#define KTRACE_RO(slot)                                                                                   \
+  do {                                                                                                    \
+    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + (slot)] = wall_clock64();                          \
+  } while (0)
 #else
 #define KTRACE(slot)
+#define KTRACE_RO(slot)
 #endif
 
 namespace kmpc {
@@ -86,6 +91,7 @@ template <typename T> struct StepVar {
   const T* psi_prev;
   const T* psi_now;
   T* U0;
+  T* x_next;  // fused roll-out: LDS slot that receives x_{k+1} for the workgroup's next lift (else null)
 };
 
 template <typename T> struct Tol;
@@ -496,7 +502,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   }
   KTRACE(13);
 #ifdef KMPC_TRACE
-  if (tid == 0 && b < 8192) kmpc_trace_buf[b * 16 + 15] = (unsigned long long)it;
+  if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + 15] = (unsigned long long)it;
 #endif
 
   if (status == 3) {  // hand the current point to the active-set solver
@@ -517,6 +523,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
       plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
+      if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
     }
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
     if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
@@ -758,6 +765,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
       plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
+      if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
     }
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
     if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
@@ -1249,7 +1257,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 template <typename T, int TPB, int L_, int N_, int Q_>
 __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0};
+  const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr};
   step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
 
@@ -1269,7 +1277,8 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int RO_WAVES = 16;
 constexpr int RO_PART = RO_WAVES * 2 * 256;         // partial accumulator tiles [wave][slot][256]
 constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
-constexpr int RO_SCRATCH = RO_PART + 2 * RO_ACT + 64 * 16;  // + psi (Lp <= 64) x 16
+constexpr int RO_SCRATCH = RO_PART + 2 * RO_ACT;    // overlays the per-wave regions between two steps
+constexpr int RO_KEEP = 64 * 16 + RO_WAVES * 4;     // not overlaid: psi (Lp <= 64) x 16, x_{k+1} of the 16 trajectories
 constexpr int RO_KC = 8;                            // k-steps per wave and layer (KS <= 32, four K chunks)
 
 __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int t0, bool t1ok, int ks0, int ks1,
@@ -1296,7 +1305,10 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
   double* const sPart = smem;
   double* const sAct0 = smem + RO_PART;
   double* const sAct1 = sAct0 + RO_ACT;
-  double* const sPsi = sAct1 + RO_ACT;
+  double* const sPsi = smem + ra.keep_off;  // behind the per-wave regions: survives into the step
+  double* const sXn = sPsi + 64 * 16;
+  if (!ra.lift_rbf && (tid0 & 63) < 4)
+    sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? ra.s.X_rw[(size_t)(tid0 & 63) * B + b] : 0.0;
 
   bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
   int cur = ra.cur;
@@ -1324,6 +1336,9 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
     int tid = tid0;
     asm volatile("" : "+v"(tid));  // (as local_tid: per-lane addresses are recomputed in the loop, not carried across it)
     const int lane = tid & 63;
+#ifdef KMPC_TRACE
+    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 16] = wall_clock64();  // this wave is ready for step k
+#endif
     double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
     if (R.lift_rbf) {
       if (live && lane < L) {
@@ -1347,23 +1362,43 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
     } else {
       double af0[RO_KC], af1[RO_KC];
       if (R.nhh > 0) ro_load_afrags(R.Whp[0], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
-      __syncthreads();  // every wave is done with its LDS region (previous step) and with X
+      // first-layer rows of this thread's two outputs (Hp * 16 <= 2048 = 2 per thread); W1 is zero-padded to 4 columns
+      double w1r[2][4], b1r[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = tid + j * 64 * RO_WAVES;
+        const int row = e < Hp * 16 ? (e >> 4) : 0;
+        b1r[j] = R.b1[row];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) w1r[j][i] = R.W1[4 * row + i];
+      }
+      __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all 16 is in sXn
+      KTRACE_RO(20);
       // ---- layer 1 (K = n <= 4) on the VALU, straight into B-fragment layout
-      for (int e = tid; e < Hp * 16; e += 64 * RO_WAVES) {
-        const int row = e >> 4, col = e & 15;
-        const int bb = b0 + col;
-        double v = R.b1[row];
-        if (bb < B) {
-          const double* wr = R.W1 + 4 * row;
-          for (int i = 0; i < n; ++i) v += wr[i] * a.X_rw[(size_t)i * B + bb];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int e = tid + j * 64 * RO_WAVES;
+        if (e < Hp * 16) {
+          const int row = e >> 4, col = e & 15;
+          const double* xc = sXn + 4 * col;
+          const double v = b1r[j] + ((w1r[j][0] * xc[0] + w1r[j][1] * xc[1]) + (w1r[j][2] * xc[2] + w1r[j][3] * xc[3]));
+          sAct0[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
         }
-        sAct0[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
       }
       __syncthreads();
+      KTRACE_RO(21);
       // ---- hidden -> hidden layers
       for (int h = 0; h < R.nhh; ++h) {
         const double* act = (h & 1) ? sAct1 : sAct0;
         double* actn = (h & 1) ? sAct0 : sAct1;
+        // biases of the two outputs this thread reduces below: requested now, they arrive behind the MFMAs
+        double bpre[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int e = tid + j * 64 * RO_WAVES;
+          const int rl = e & 255;
+          bpre[j] = e < MTH * 256 ? R.bh[h][16 * (e >> 8) + ((rl & 63) >> 4) + 4 * (rl >> 6)] : 0.0;
+        }
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int i = 0; i < RO_KC; ++i) {
@@ -1376,25 +1411,32 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
         double* pw = sPart + (size_t)wave * 512;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pw[r * 64 + lane] = acc0[r]; pw[256 + r * 64 + lane] = acc1[r]; }
+        if (h == 0) KTRACE_RO(25);  // MFMAs of the first hidden layer issued and stored
         // the next layer's weights travel while the partial tiles are reduced
         if (h + 1 < R.nhh) ro_load_afrags(R.Whp[h + 1], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
         else if (took) ro_load_afrags(R.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
         __syncthreads();
-        const double* bias = R.bh[h];
-        for (int e = tid; e < MTH * 256; e += 64 * RO_WAVES) {
-          const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
-          const double* pp = sPart + (size_t)(t & 3) * 512 + (size_t)(t >> 2) * 256 + rl;
-          const double sum = (pp[0] + pp[4 * 512]) + (pp[8 * 512] + pp[12 * 512]);  // kq = 0..3, fixed order
-          const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
-          const double v = sum + bias[row];
-          actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int e = tid + j * 64 * RO_WAVES;
+          if (e < MTH * 256) {
+            const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
+            const double* pp = sPart + (size_t)(t & 3) * 512 + (size_t)(t >> 2) * 256 + rl;
+            const double sum = (pp[0] + pp[4 * 512]) + (pp[8 * 512] + pp[12 * 512]);  // kq = 0..3, fixed order
+            const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
+            const double v = sum + bpre[j];
+            actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+          }
         }
         __syncthreads();
+        KTRACE_RO(22 + h);
       }
       // ---- output layer
       {
         const double* act = (R.nhh & 1) ? sAct1 : sAct0;
         if (R.nhh == 0 && took) ro_load_afrags(R.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
+        const int orl = tid & 255;
+        const double bopre = tid < MTO * 256 ? R.bo[16 * (tid >> 8) + ((orl & 63) >> 4) + 4 * (orl >> 6)] : 0.0;
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0};
         if (took) {
 #pragma unroll
@@ -1406,19 +1448,22 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
 #pragma unroll
         for (int r = 0; r < 4; ++r) pw[r * 64 + lane] = acc0[r];
         __syncthreads();
-        for (int e = tid; e < MTO * 256; e += 64 * RO_WAVES) {
-          const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
+        if (tid < MTO * 256) {  // MTO * 256 <= 1024 threads
+          const int t = tid >> 8, rl = orl, r = rl >> 6, l = rl & 63;
           double sum = 0.0;
           for (int c = 0; c < nch; ++c) sum += sPart[(size_t)(c * MTOp + t) * 512 + rl];
           const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
-          sPsi[row * 16 + col] = sum + R.bo[row];
+          sPsi[row * 16 + col] = sum + bopre;
         }
-        __syncthreads();
+        __syncthreads();  // psi is outside the overlay: from here the waves go their own way
         if (lane < L) psi_i = sPsi[lane * 16 + wave];
-        __syncthreads();  // the scratch is free again: the waves go their own way
       }
     }
 
+#ifdef KMPC_TRACE
+    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 17] = wall_clock64();  // lift done
+    if (lane == 0 && b < 8192 && k == 0) kmpc_trace_buf[b * 32 + 19] = wall_clock64();
+#endif
     if (live) {
       int woff = wave * R.wstride, bk = b;
       asm volatile("" : "+s"(woff), "+s"(bk));  // (as local_tid: keeps the step's address arithmetic inside the loop)
@@ -1433,12 +1478,16 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
       sv.first_update = fresh ? 1 : 0;
       sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
       sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
+      sv.x_next = R.lift_rbf ? nullptr : sXn + wave * 4;
       step_body<double, 64, L_, N_, Q_>(a, sv, bk, wsm);
       if (R.X_log) {
         __threadfence_block();
         if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
       }
     }
+#ifdef KMPC_TRACE
+    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 18] = wall_clock64();  // step k done
+#endif
     if (have_prev) fresh = false;
     have_prev = true;
     cur ^= 1;
@@ -1450,7 +1499,7 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
 static int rollout_waves(int n, int L, int q, int N, bool rbf) {
   const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr) + 15) & ~(size_t)15;
   const int fit = (int)((160 * 1024) / per_wave);
-  if (!rbf) return fit >= RO_WAVES ? RO_WAVES : 0;
+  if (!rbf) return (RO_WAVES * per_wave + RO_KEEP * sizeof(double) <= 160 * 1024) ? RO_WAVES : 0;
   return fit >= RO_WAVES ? RO_WAVES : (fit >= 8 ? 8 : (fit >= 4 ? 4 : 0));
 }
 template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
@@ -1461,6 +1510,8 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   k.wstride = (int)((per_wave + 1) & ~(size_t)1);
   size_t elems = (size_t)k.wstride * waves;
   if (!a.lift_rbf && elems < (size_t)RO_SCRATCH) elems = RO_SCRATCH;
+  k.keep_off = (int)elems;
+  if (!a.lift_rbf) elems += RO_KEEP;
   const size_t lds = elems * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t configured = 0;

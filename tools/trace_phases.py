@@ -31,15 +31,33 @@ m.iters.zero_()
 m.rollout("duffing", X, r, steps, step0=0)
 torch.cuda.synchronize()
 nb = min(B, 8192)
-buf = np.zeros(8192 * 16, dtype=np.uint64)
+buf = np.zeros(8192 * 32, dtype=np.uint64)
 lib = _ffi.load()
 lib.kmpc_trace_read.restype = C.c_int
 lib.kmpc_trace_read.argtypes = [C.c_void_p, C.c_size_t]
 assert lib.kmpc_trace_read(buf.ctypes.data, buf.nbytes) == 0
-t = buf.reshape(8192, 16)[:nb].astype(np.int64)
+t = buf.reshape(8192, 32)[:nb].astype(np.int64)
 names = ["start", "rls: state in LDS", "rls: Pz, d", "rls: P, K written", "rls: C part", "cond: init", "cond: chains",
          "cond: H, f", "qp: setup", "qp: first KKT", "qp: sweeps", "qp: direction", "qp: first Armijo", "qp: loop exit",
          "end"]
+fused = bool((t[:, 17] > 0).any())
+if fused:  # roll-out kernel: one launch for all the steps; the per-step stamps are those of the LAST step
+    total = (t[:, 18].max() - t[:, 19].min()) / 100.0
+    print("fused roll-out: %d steps in %.1f us after the first lift => %.2f us/step" % (steps, total, total / max(1, steps - 1)))
+    wg = (np.arange(nb) // 16)
+    lift = (t[:, 17] - t[:, 16]) / 100.0      # wait for the workgroup's slowest wave + cooperative lift
+    body = (t[:, 18] - t[:, 17]) / 100.0
+    ready = t[:, 16].reshape(-1, 16)
+    wait = (ready.max(1, keepdims=True) - ready).reshape(-1) / 100.0  # idle time before the lift barrier
+    print("last step: wait for the slowest of 16  median %.2f p90 %.2f max %.2f us" % (np.median(wait), np.percentile(wait, 90), wait.max()))
+    print("           lift (after the last wave arrived) median %.2f us" % np.median(((t[:, 17].reshape(-1, 16).min(1) - ready.max(1)) / 100.0)))
+    seg = [("all arrived -> layer 1 done", 20, 21), ("hidden layer 1: MFMA + partial store", 21, 25), ("hidden layer 1: barrier + reduce", 25, 22),
+           ("hidden layer 2", 22, 23), ("output layer + psi pick-up", 23, 17)]
+    for nm, i0, i1 in seg:
+        d = (t[:, i1] - t[:, i0]) / 100.0
+        print("           lift: %-40s median %.2f p90 %.2f us" % (nm, np.median(d), np.percentile(d, 90)))
+    print("           step body median %.2f p90 %.2f max %.2f us; slowest-of-16 median %.2f us" % (
+        np.median(body), np.percentile(body, 90), body.max(), np.median(body.reshape(-1, 16).max(1))))
 k0 = t[:, 0].min()
 print("launch span: %.2f us; wave start spread %.2f us" % ((t[:, 14].max() - k0) / 100.0, (t[:, 0].max() - k0) / 100.0))
 print("%-22s %8s %8s %8s   (us, per wave)" % ("segment", "median", "p90", "max"))
