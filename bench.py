@@ -116,25 +116,24 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- bring the GPU out of its idle power state on a scratch controller (does not touch the workload)
-    if args.spin_seconds > 0:
-        scratch = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev)
-        scratch.set_model(A0, B0, C0)
-        Xs = X.clone()
-        t_spin = time.perf_counter()
-        k_spin = 0
-        while time.perf_counter() - t_spin < args.spin_seconds:
-            scratch.rollout("duffing", Xs, r, 100, step0=k_spin)
-            torch.cuda.synchronize(dev)
-            k_spin += 100
-        del scratch, Xs
-
     # ---- warm-up (untimed), then EXACTLY --steps timed steps
     mpc.rollout("duffing", X, r, args.warmup, step0=0)
     torch.cuda.synchronize(dev)
     replay = args.steps <= 4096
-    if replay:  # snapshot so that the SAME steps can be replayed under HIP events afterwards
-        sd0, X0 = mpc.state_dict(), X.clone()
+    sd0, X0 = mpc.state_to(), X.clone()  # device-side snapshot of the state the timed region starts from
+    # ---- bring the GPU out of its idle power state: a scratch controller runs the timed region's own steps from
+    #      the snapshot (same launches as the timed one, so a rocprofv3 --stats average over the process is
+    #      comparable with the number reported below); it does not touch the workload's controller
+    if args.spin_seconds > 0:
+        scratch = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev)
+        Xs = X.clone()
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.spin_seconds:
+            scratch.state_from(sd0)
+            Xs.copy_(X0)
+            scratch.rollout("duffing", Xs, r, args.steps, step0=args.warmup)
+            torch.cuda.synchronize(dev)
+        del scratch, Xs
     sync_all()
     t0 = time.perf_counter()
     mpc.rollout("duffing", X, r, args.steps, step0=args.warmup)
@@ -150,9 +149,10 @@ def main():
     # ---- kernel durations for the roofline: the timed region's steps replayed from the snapshot (same
     #      states, same models, bitwise the same controls) with HIP events around every lift / step kernel on
     #      the launch stream.  Kept out of the timed pass itself: the event packets cost ~10 % of a step.
-    U_timed = mpc.U0.clone()
+    X_timed = X.clone()
+    fused = mpc.rollout_is_fused()
     if replay:
-        mpc.load_state_dict(sd0)
+        mpc.state_from(sd0)
         X.copy_(X0)
         step0 = args.warmup
         nprof = args.steps
@@ -164,12 +164,15 @@ def main():
     torch.cuda.synchronize(dev)
     pr = mpc.profile_read()
     mpc.profile(False)
-    if replay and not torch.equal(U_timed, mpc.U0):
-        sys.exit("bench.py: the replayed region did not reproduce the timed region's controls")
-    step_ms = pr["step_ms"] / max(1, pr["count"])
+    if replay and not torch.equal(X_timed, X):
+        sys.exit("bench.py: the replayed region did not reproduce the timed region's states")
+    # fused roll-out: ONE launch covers all nprof steps (lift inside); otherwise one lift + one step kernel per step
+    steps_per_launch = nprof if fused else 1
+    launch_ms = pr["step_ms"] / max(1, pr["count"]) * steps_per_launch
     lift_ms = pr["lift_ms"] / max(1, pr["count"])
     bytes_per_traj = mpc.algorithmic_bytes_per_step()
-    achieved = bytes_per_traj * B / (step_ms * 1e-3) / 1e9 if step_ms > 0 else 0.0
+    bytes_per_launch = bytes_per_traj * B * steps_per_launch
+    achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     x_ok = bool(torch.isfinite(X).all().item())
 
     if dist is not None:
@@ -180,11 +183,13 @@ def main():
     # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
     # own-pattern calibration): collected offline with tools/one_phase.py, committed in profiles/
     traffic, traffic_note = None, "not collected for this configuration"
-    tp = os.path.join(ROOT, "profiles", "r1_traffic.json")
+    tp = os.path.join(ROOT, "profiles", "r1_traffic_fused.json" if fused else "r1_traffic.json")
     if os.path.exists(tp) and (L, N, B, args.dtype) == (20, 20, 4096, "f64"):
         tj = json.load(open(tp))
-        traffic = tj["traffic_bytes_per_launch"]
-        traffic_note = "bytes per launch, rocprofv3 PMC passes recorded in profiles/r1_traffic.json (FETCH x %.3f own-pattern calibration + WRITE)" % tj["fetch_calibration"]
+        if not fused or tj.get("steps_per_launch") == steps_per_launch:
+            traffic = tj["traffic_bytes_per_launch"]
+            traffic_note = "bytes per launch, rocprofv3 PMC passes recorded in profiles/%s (FETCH x %.3f own-pattern calibration + WRITE)" % (
+                os.path.basename(tp), tj["fetch_calibration"])
 
     if rank == 0:
         total = B * world
@@ -214,7 +219,10 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "step_kernel (RLS + condense + QP), %d blocks x %d threads" % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64)),
+                "kernel": ("rollout_kernel (lift + RLS + condense + QP + plant, all %d steps in one launch), %d workgroups x 1024 threads"
+                           % (steps_per_launch, (B + 15) // 16)) if fused else
+                          ("step_kernel (RLS + condense + QP), %d blocks x %d threads"
+                           % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64))),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -222,7 +230,9 @@ def main():
                 "traffic": traffic,
                 "traffic_note": traffic_note,
                 "algorithmic_bytes_per_trajectory_step": bytes_per_traj,
-                "avg_kernel_ms": step_ms,
+                "algorithmic_bytes_per_launch": bytes_per_launch,
+                "steps_per_launch": steps_per_launch,
+                "avg_kernel_ms": launch_ms,
                 "avg_lift_kernel_ms": lift_ms,
             },
         }

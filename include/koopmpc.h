@@ -184,7 +184,11 @@ int kmpc_plant_step(kmpc_handle* h, int plant, void* X_dev, const void* U_dev, d
  * parameters once i >= switch_step (the reference switches at the end of iteration 101, i.e.
  * switch_step = 102; pass a negative value for "never").  Optional outputs: U_log_dev (steps x B),
  * X_log_dev (steps x n x B, the state AFTER each plant step), status_dev[B] (worst QP status of
- * each trajectory over the call), iters_dev[B] (its total number of Newton solves).            */
+ * each trajectory over the call), iters_dev[B] (its total number of Newton solves).
+ * For float64, single-wave configurations with a static instantiation (kmpc_rollout_is_fused) the whole
+ * call is ONE kernel launch: 16 trajectories per workgroup, the encoder evaluated inside on MFMA, no
+ * synchronisation between workgroups from the first step to the last.  Same results as the per-step
+ * launches up to the summation order of the encoder (1e-12 on the controls).                         */
 int kmpc_rollout(kmpc_handle* h, int plant, void* X_dev, const void* ref_dev, int ref_per_traj,
                  int steps, int step0, int switch_step, double hstep, void* U_log_dev, void* X_log_dev,
                  int32_t* status_dev, int32_t* iters_dev, void* stream);
@@ -198,9 +202,12 @@ int kmpc_state_import(kmpc_handle* h, const void* host_blob, int64_t bytes);
 /* ---- measurement ------------------------------------------------------------------------ */
 /* when enabled, kmpc_step brackets its kernels with HIP events on `stream`                  */
 int kmpc_profile_enable(kmpc_handle* h, int on);
-/* accumulated milliseconds since enable/reset: [0] lift kernel, [1] step kernel; count =
- * number of steps measured.  Synchronises the recorded events.                              */
+/* accumulated milliseconds since enable/reset: [0] lift kernel, [1] step kernel (fused roll-outs:
+ * [0] = 0, [1] = the roll-out kernel); count = number of control steps the recorded launches
+ * covered.  Synchronises the recorded events.                                               */
 int kmpc_profile_read(kmpc_handle* h, double* ms2, int64_t* count, int reset);
+/* 1 if kmpc_rollout runs as one fused kernel for this handle's configuration, else 0         */
+int kmpc_rollout_is_fused(const kmpc_handle* h);
 /* algorithmic bytes of one trajectory-step (SURVEY.md 8d formula) for this configuration   */
 int64_t kmpc_algorithmic_bytes_per_step(const kmpc_handle* h);
 

@@ -23,6 +23,7 @@ struct kmpc_handle {
   virtual int set_centres(const double* cx, int L, int n) = 0;
   virtual int set_model(const double* A, const double* B, const double* C) = 0;
   virtual int set_terminal_weight(const double* PN) = 0;
+  virtual int rollout_is_fused() const = 0;
   virtual int reset(hipStream_t s) = 0;
   virtual int lift(const void* X, void* Psi, int B, hipStream_t s) = 0;
   virtual int rls_update(const void* psi, const void* u, const void* psin, const void* xn, int B, hipStream_t s) = 0;
@@ -367,6 +368,7 @@ struct Impl : kmpc_handle {
     if (rec) {
       HIPCHK(hipEventRecord(e2, s));
       ev_used += 3;
+      prof_steps += 1;
     }
     if (have_prev) rls_fresh = false;
     have_prev = true;
@@ -386,8 +388,7 @@ struct Impl : kmpc_handle {
   // ---- fused roll-out (one launch for all the steps; rollout_kernel in step_kernel.hip) ----------------
   T *dWhp[2] = {nullptr, nullptr}, *dWop = nullptr;  // hidden / output weights as MFMA A-fragments
   bool packed_ok = false;
-  int fused_launches = 0;   // profiling: launches and steps covered by the recorded events
-  int64_t fused_steps = 0;
+  int64_t prof_steps = 0;   // profiling: control steps covered by the recorded events
   int pack_encoder(hipStream_t s) {
     if (packed_ok) return 0;
     const int KS = (cfg.hidden + 3) / 4;
@@ -401,6 +402,7 @@ struct Impl : kmpc_handle {
     packed_ok = true;
     return 0;
   }
+  int rollout_is_fused() const override { return fused_rollout_ok() ? 1 : 0; }
   bool fused_rollout_ok() const {
     static const bool off = getenv("KMPC_NO_FUSED_ROLLOUT") != nullptr;  // measurement aid: per-step launches
     return !off && n == 2 && rollout_fused_available<T>(n, L, N, q, threads, cfg.lift_kind != KMPC_LIFT_MLP);
@@ -445,8 +447,7 @@ struct Impl : kmpc_handle {
     if (rec) {
       HIPCHK(hipEventRecord(ev[ev_used + 2], s));
       ev_used += 3;
-      fused_launches += 1;
-      fused_steps += steps;
+      prof_steps += steps;
     }
     // the host-side flags follow the kernel's own bookkeeping
     if (steps >= 2 || (steps == 1 && have_prev)) rls_fresh = false;
@@ -619,13 +620,13 @@ struct Impl : kmpc_handle {
     if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_export: buffer too small");
     HIPCHK(hipDeviceSynchronize());
     BlobHeader hd{0x4b4d5043, cfg.dtype, n, L, N, B, have_prev ? 1 : 0, rls_fresh ? 1 : 0};
-    char* o = (char*)blob;
-    memcpy(o, &hd, sizeof(hd)); o += sizeof(hd);
+    char* o = (char*)blob;  // host or device memory (unified addressing)
+    HIPCHK(hipMemcpy(o, &hd, sizeof(hd), hipMemcpyDefault)); o += sizeof(hd);
     struct { const T* ptr; size_t cnt; } parts[] = {{dP, (size_t)sP * B}, {dK, (size_t)sK * B}, {dQ, (size_t)sQ * B},
                                                     {dC, (size_t)sC * B}, {dPsi[cur ^ 1], (size_t)L * B},
                                                     {dWarm, (size_t)N * B}, {dUprev, (size_t)B}};
     for (auto& pt : parts) {
-      HIPCHK(hipMemcpy(o, pt.ptr, pt.cnt * sizeof(T), hipMemcpyDeviceToHost));
+      HIPCHK(hipMemcpy(o, pt.ptr, pt.cnt * sizeof(T), hipMemcpyDefault));
       o += pt.cnt * sizeof(T);
     }
     return 0;
@@ -634,7 +635,7 @@ struct Impl : kmpc_handle {
     if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_import: buffer too small");
     BlobHeader hd;
     const char* o = (const char*)blob;
-    memcpy(&hd, o, sizeof(hd)); o += sizeof(hd);
+    HIPCHK(hipMemcpy(&hd, o, sizeof(hd), hipMemcpyDefault)); o += sizeof(hd);
     if (hd.magic != 0x4b4d5043 || hd.dtype != cfg.dtype || hd.n != n || hd.L != L || hd.N != N || hd.B != B)
       FAIL(-3, "kmpc_state_import: blob does not match this handle");
     HIPCHK(hipDeviceSynchronize());
@@ -642,7 +643,7 @@ struct Impl : kmpc_handle {
                                               {dC, (size_t)sC * B}, {dPsi[cur ^ 1], (size_t)L * B},
                                               {dWarm, (size_t)N * B}, {dUprev, (size_t)B}};
     for (auto& pt : parts) {
-      HIPCHK(hipMemcpy(pt.ptr, o, pt.cnt * sizeof(T), hipMemcpyHostToDevice));
+      HIPCHK(hipMemcpy(pt.ptr, o, pt.cnt * sizeof(T), hipMemcpyDefault));
       o += pt.cnt * sizeof(T);
     }
     have_prev = hd.have_prev != 0;
@@ -653,6 +654,7 @@ struct Impl : kmpc_handle {
   int profile_enable(int on) override {
     prof = on != 0;
     ev_used = 0;
+    prof_steps = 0;
     return 0;
   }
   int profile_read(double* ms2, int64_t* count, int reset_) override {
@@ -665,8 +667,8 @@ struct Impl : kmpc_handle {
       a0 += t0; a1 += t1;
     }
     if (ms2) { ms2[0] = a0; ms2[1] = a1; }
-    if (count) *count = (int64_t)(ev_used / 3);
-    if (reset_) ev_used = 0;
+    if (count) *count = prof_steps;  // control steps covered by the recorded launches
+    if (reset_) { ev_used = 0; prof_steps = 0; }
     return 0;
   }
 
@@ -708,6 +710,7 @@ int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W, const dou
 int kmpc_set_centres(kmpc_handle* h, const double* cx, int L, int n) { NN(h); return h->set_centres(cx, L, n); }
 int kmpc_set_model(kmpc_handle* h, const double* A, const double* B, const double* C) { NN(h); return h->set_model(A, B, C); }
 int kmpc_set_terminal_weight(kmpc_handle* h, const double* PN) { NN(h); return h->set_terminal_weight(PN); }
+int kmpc_rollout_is_fused(const kmpc_handle* h) { NN(h); return h->rollout_is_fused(); }
 int kmpc_reset(kmpc_handle* h, void* s) { NN(h); return h->reset((hipStream_t)s); }
 int kmpc_lift(kmpc_handle* h, const void* X, void* Psi, int B, void* s) { NN(h); return h->lift(X, Psi, B, (hipStream_t)s); }
 int kmpc_rls_update(kmpc_handle* h, const void* psi, const void* u, const void* psin, const void* xn, int B, void* s) { NN(h); return h->rls_update(psi, u, psin, xn, B, (hipStream_t)s); }

@@ -319,6 +319,19 @@ class KoopmanMPC:
         self._chk(self.lib.kmpc_state_export(self.h, C.c_void_p(buf.ctypes.data), nb), "kmpc_state_export")
         return {"blob": buf}
 
+    def state_to(self, blob=None):
+        """Snapshot into a uint8 tensor (host or device; allocated on the device when None) -- the blob of
+        state_dict() without the host round trip."""
+        nb = self.lib.kmpc_state_bytes(self.h)
+        if blob is None:
+            blob = torch.empty(nb, dtype=torch.uint8, device=self.device)
+        assert blob.dtype == torch.uint8 and blob.numel() >= nb and blob.is_contiguous()
+        self._chk(self.lib.kmpc_state_export(self.h, C.c_void_p(blob.data_ptr()), nb), "kmpc_state_export")
+        return blob
+
+    def state_from(self, blob):
+        self._chk(self.lib.kmpc_state_import(self.h, C.c_void_p(blob.data_ptr()), blob.numel()), "kmpc_state_import")
+
     def load_state_dict(self, sd):
         buf = np.ascontiguousarray(sd["blob"], dtype=np.uint8)
         self._chk(self.lib.kmpc_state_import(self.h, C.c_void_p(buf.ctypes.data), buf.size), "kmpc_state_import")
@@ -332,6 +345,10 @@ class KoopmanMPC:
         cnt = C.c_int64()
         self._chk(self.lib.kmpc_profile_read(self.h, ms, C.byref(cnt), int(reset)), "kmpc_profile_read")
         return {"lift_ms": ms[0], "step_ms": ms[1], "count": cnt.value}
+
+    def rollout_is_fused(self):
+        """True if rollout() runs as one fused kernel launch for this configuration."""
+        return bool(self.lib.kmpc_rollout_is_fused(self.h))
 
     def algorithmic_bytes_per_step(self):
         return int(self.lib.kmpc_algorithmic_bytes_per_step(self.h))
