@@ -152,15 +152,20 @@ def main():
     X_timed = X.clone()
     fused = mpc.rollout_is_fused()
     if replay:
-        mpc.state_from(sd0)
-        X.copy_(X0)
         step0 = args.warmup
         nprof = args.steps
     else:
         step0 = args.warmup + args.steps
         nprof = 1000
-    mpc.profile(True)
-    mpc.rollout("duffing", X, r, nprof, step0=step0)
+    # (the first replay follows host-side work -- status read-back, snapshot restore -- and runs at a lower
+    #  clock; it is discarded, the next two are averaged)
+    for rep in range(3 if replay else 1):
+        if replay:
+            mpc.state_from(sd0)
+            X.copy_(X0)
+        if rep == (1 if replay else 0):
+            mpc.profile(True)
+        mpc.rollout("duffing", X, r, nprof, step0=step0)
     torch.cuda.synchronize(dev)
     pr = mpc.profile_read()
     mpc.profile(False)

@@ -77,7 +77,8 @@ template <int TPB> __device__ __forceinline__ void block_sync() {
   }
 }
 template <int TPB> __device__ __forceinline__ int local_tid() {
-  int t = TPB == 64 ? (int)(threadIdx.x & 63u) : (int)threadIdx.x;
+  // (single wave: the lane index from mbcnt, so that no register has to keep threadIdx alive)
+  int t = TPB == 64 ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : (int)threadIdx.x;
   // opaque on purpose: inside the step loop of the fused roll-out every address and mask derived from the lane
   // index is loop-invariant, and hoisting them all out of the loop costs far more registers than recomputing
   asm volatile("" : "+v"(t));
@@ -93,6 +94,23 @@ template <typename T> struct StepVar {
   T* U0;
   T* x_next;  // fused roll-out: LDS slot that receives x_{k+1} for the workgroup's next lift (else null)
 };
+
+// e = tid, tid + TPB, ... < count.  With a compile-time COUNT the loop is fully unrolled, so that the loads of all
+// its iterations are in flight before the first one is waited for (as a run-time loop each iteration is a
+// complete memory round trip: 14 of them made up the 6 us the RLS phase spent fetching P and K).
+template <int TPB, int COUNT, typename F> __device__ __forceinline__ void for_strided(int tid, int count, F&& f) {
+  if constexpr (COUNT > 0) {
+    constexpr int IT = (COUNT + TPB - 1) / TPB;
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+      const int e = tid + i * TPB;
+      if (e < COUNT) f(e, i);
+    }
+  } else {
+    int i = 0;
+    for (int e = tid; e < count; e += TPB, ++i) f(e, i);
+  }
+}
 
 template <typename T> struct Tol;
 template <> struct Tol<double> {
@@ -836,11 +854,21 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         }
       }
     }
-    for (int e = tid; e < p * p; e += TPB) sX[e] = Pg[e];
-    if (sv.first_update) {
-      for (int e = tid; e < L * p; e += TPB) sK[e] = T(0);
+    constexpr int PP_ = L_ > 0 ? (L_ + 1) * (L_ + 1) : 0, LP_ = L_ > 0 ? L_ * (L_ + 1) : 0, LL_ = L_ * L_;
+    if constexpr (L_ > 0 && (PP_ + TPB - 1) / TPB <= 16) {
+      T pr[(PP_ + TPB - 1) / TPB], kr[(LP_ + TPB - 1) / TPB];
+      for_strided<TPB, PP_>(tid, p * p, [&](int e, int i) { pr[i] = Pg[e]; });
+      const bool fu = sv.first_update != 0;
+      for_strided<TPB, LP_>(tid, L * p, [&](int e, int i) { kr[i] = fu ? T(0) : Kg[e]; });
+      for_strided<TPB, PP_>(tid, p * p, [&](int e, int i) { sX[e] = pr[i]; });
+      for_strided<TPB, LP_>(tid, L * p, [&](int e, int i) { sK[e] = kr[i]; });
     } else {
-      for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
+      for (int e = tid; e < p * p; e += TPB) sX[e] = Pg[e];
+      if (sv.first_update) {
+        for (int e = tid; e < L * p; e += TPB) sK[e] = T(0);
+      } else {
+        for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
+      }
     }
     for (int i = tid; i < L; i += TPB) {
       sz[i] = sv.psi_prev[i * a.pp_sl + b * a.pp_sb];
@@ -868,10 +896,10 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 
     // P <- (P - Pz Pz' / d) / lam                                   duffing.py:931-932
     T* Pw = a.P + (size_t)b * a.strideP;
-    for (int e = tid; e < p * p; e += TPB) {
+    for_strided<TPB, PP_>(tid, p * p, [&](int e, int) {
       const int i = e / p, j = e - i * p;
       Pw[e] = (sX[e] - (sPz[i] * sPz[j]) * dinv) * linv;
-    }
+    });
     // innovation  y - K z
     for (int r = tid; r < L; r += TPB) {
       T acc = sy[r];
@@ -881,12 +909,12 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     }
     block_sync<TPB>();
     // K <- K + (y - K z) g',  g = Pz / d                            duffing.py:927-938
-    for (int e = tid; e < L * p; e += TPB) {
+    for_strided<TPB, LP_>(tid, L * p, [&](int e, int) {
       const int r = e / p, j = e - r * p;
       const T v = sK[e] + sE[r] * (sPz[j] * dinv);
       sK[e] = v;
       Kg[e] = v;
-    }
+    });
 
     KTRACE(3);
     if (a.out_kind == OUT_CX) {
@@ -933,10 +961,10 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       const T dc = a.lam + block_sum<T, TPB>(part2, red);
       const T dcinv = T(1) / dc;
       T* Qw = a.Qb + (size_t)b * a.strideQ;
-      for (int e = tid; e < L * L; e += TPB) {
+      for_strided<TPB, LL_>(tid, L * L, [&](int e, int) {
         const int i = e / L, j = e - i * L;
         Qw[e] = (sX[e] - (sPz[i] * sPz[j]) * dcinv) * linv;
-      }
+      });
       for (int e = tid; e < n * L; e += TPB) {
         const int r = e / L, j = e - r * L;
         const T v = (a.c_skip_first && sv.first_update) ? T(0) : sC[e] + sE[r] * (sPz[j] * dcinv);
@@ -1312,19 +1340,6 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
 
   bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
   int cur = ra.cur;
-  const int Hp = ra.Hp, KS = ra.KS, MTH = Hp >> 4, MTO = ra.Lp >> 4;
-  // hidden layers: wave (mg, kq) owns M tiles mg, mg+4 and the kq-th quarter of the k-steps
-  const int mg = wave & 3, kq = wave >> 2;
-  const int kch = (KS + 3) >> 2;
-  const int hks0 = kq * kch, hks1 = (hks0 + kch < KS) ? hks0 + kch : KS;
-  const bool t1ok = mg + 4 < MTH;
-  // output layer: tile to, k-chunk kc of nch
-  const int MTOp = MTO == 3 ? 4 : MTO, nch = RO_WAVES / MTOp;
-  const int to = wave % MTOp, kc = wave / MTOp;
-  const int och = (KS + nch - 1) / nch;
-  const int oks0 = kc * och, oks1 = (oks0 + och < KS) ? oks0 + och : KS;
-  const bool took = to < MTO;
-
   typedef const RolloutArgs<double> __attribute__((address_space(4))) * kernarg_ptr_t;
   for (int k = 0; k < ra.steps; ++k) {
     // The step arguments stay in the kernel-argument segment and are re-read where they are used: hoisted out
@@ -1333,9 +1348,12 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
     asm volatile("" : "+s"(kp));
     const RolloutArgs<double> __attribute__((address_space(4)))& R = *kp;
     const StepArgs<double>& a = *(const StepArgs<double>*)(&kp->s);  // psi strides (1, L), accumulate = 1: host
-    int tid = tid0;
-    asm volatile("" : "+v"(tid));  // (as local_tid: per-lane addresses are recomputed in the loop, not carried across it)
-    const int lane = tid & 63;
+    // (as local_tid: lane- and wave-derived addresses and the lift's tiling constants are recomputed in every
+    //  iteration instead of being carried across the step in registers)
+    int wv = wave;
+    asm volatile("" : "+s"(wv));
+    const int lane = local_tid<64>();
+    const int tid = wv * 64 + lane;
 #ifdef KMPC_TRACE
     if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 16] = wall_clock64();  // this wave is ready for step k
 #endif
@@ -1360,6 +1378,18 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
         }
       }
     } else {
+      const int Hp = R.Hp, KS = R.KS, MTH = Hp >> 4, MTO = R.Lp >> 4;
+      // hidden layers: wave (mg, kq) owns M tiles mg, mg+4 and the kq-th quarter of the k-steps
+      const int mg = wv & 3, kq = wv >> 2;
+      const int kch = (KS + 3) >> 2;
+      const int hks0 = kq * kch, hks1 = (hks0 + kch < KS) ? hks0 + kch : KS;
+      const bool t1ok = mg + 4 < MTH;
+      // output layer: tile to, k-chunk kc of nch
+      const int MTOp = MTO == 3 ? 4 : MTO, nch = RO_WAVES / MTOp;
+      const int to = wv % MTOp, kc = wv / MTOp;
+      const int och = (KS + nch - 1) / nch;
+      const int oks0 = kc * och, oks1 = (oks0 + och < KS) ? oks0 + och : KS;
+      const bool took = to < MTO;
       double af0[RO_KC], af1[RO_KC];
       if (R.nhh > 0) ro_load_afrags(R.Whp[0], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
       // first-layer rows of this thread's two outputs (Hp * 16 <= 2048 = 2 per thread); W1 is zero-padded to 4 columns
@@ -1408,7 +1438,7 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
             if (t1ok) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[i], bf, acc1, 0, 0, 0);
           }
         }
-        double* pw = sPart + (size_t)wave * 512;
+        double* pw = sPart + (size_t)wv * 512;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pw[r * 64 + lane] = acc0[r]; pw[256 + r * 64 + lane] = acc1[r]; }
         if (h == 0) KTRACE_RO(25);  // MFMAs of the first hidden layer issued and stored
@@ -1444,7 +1474,7 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
             if (oks0 + i < oks1)
               acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i], act[(oks0 + i) * 64 + lane], acc0, 0, 0, 0);
         }
-        double* pw = sPart + (size_t)wave * 512;
+        double* pw = sPart + (size_t)wv * 512;
 #pragma unroll
         for (int r = 0; r < 4; ++r) pw[r * 64 + lane] = acc0[r];
         __syncthreads();
@@ -1456,7 +1486,7 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
           sPsi[row * 16 + col] = sum + bopre;
         }
         __syncthreads();  // psi is outside the overlay: from here the waves go their own way
-        if (lane < L) psi_i = sPsi[lane * 16 + wave];
+        if (lane < L) psi_i = sPsi[lane * 16 + wv];
       }
     }
 
@@ -1465,7 +1495,7 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
     if (lane == 0 && b < 8192 && k == 0) kmpc_trace_buf[b * 32 + 19] = wall_clock64();
 #endif
     if (live) {
-      int woff = wave * R.wstride, bk = b;
+      int woff = wv * R.wstride, bk = b;
       asm volatile("" : "+s"(woff), "+s"(bk));  // (as local_tid: keeps the step's address arithmetic inside the loop)
       double* const wsm = smem + woff;
       double* const psi_now = R.psi[cur];
@@ -1478,7 +1508,7 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
       sv.first_update = fresh ? 1 : 0;
       sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
       sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
-      sv.x_next = R.lift_rbf ? nullptr : sXn + wave * 4;
+      sv.x_next = R.lift_rbf ? nullptr : sXn + wv * 4;
       step_body<double, 64, L_, N_, Q_>(a, sv, bk, wsm);
       if (R.X_log) {
         __threadfence_block();
