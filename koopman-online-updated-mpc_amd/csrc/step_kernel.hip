@@ -26,13 +26,8 @@ __device__ unsigned long long kmpc_trace_buf[8192 * 32];
 extern "C" int kmpc_trace_read(void* host, size_t bytes) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kmpc_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
 }
-#define KTRACE_RO(slot)                                                                                   \
-  do {                                                                                                    \
-    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + (slot)] = wall_clock64();                          \
-  } while (0)
 #else
 #define KTRACE(slot)
-#define KTRACE_RO(slot)
 #endif
 
 namespace kmpc {
@@ -1302,17 +1297,20 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
 // RBF lift: every wave lifts its own state, the waves of a workgroup never meet.
 // ---------------------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
-constexpr int RO_WAVES = 16;
-constexpr int RO_PART = RO_WAVES * 2 * 256;         // partial accumulator tiles [wave][slot][256]
+// NW = waves (= trajectories) per workgroup: 16 (one workgroup per CU) or 8 (two per CU: while one of them waits
+// for its slowest trajectory or runs its lift, the other one computes; MFMA tiles are then half empty).
 constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
-constexpr int RO_SCRATCH = RO_PART + 2 * RO_ACT;    // overlays the per-wave regions between two steps
-constexpr int RO_KEEP = 64 * 16 + RO_WAVES * 4;     // not overlaid: psi (Lp <= 64) x 16, x_{k+1} of the 16 trajectories
-constexpr int RO_KC = 8;                            // k-steps per wave and layer (KS <= 32, four K chunks)
+constexpr int ro_part(int NW) { return NW * 2 * 256; }             // partial accumulator tiles [wave][slot][256]
+constexpr int ro_scratch(int NW) { return ro_part(NW) + 2 * RO_ACT; }  // overlays the per-wave regions between two steps
+constexpr int ro_kc(int NW) { return 128 / NW; }                   // k-steps per wave and layer (KS <= 32, NW/4 K chunks)
+constexpr int RO_KB = 8;                                           // ... fetched and multiplied in batches of 8
+static int ro_keep(int Lp) { return Lp * 16 + 64; }  // not overlaid: psi (Lp x 16), x_{k+1} of the trajectories (16 x 4)
 
+template <int KC>
 __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int t0, bool t1ok, int ks0, int ks1,
-                                               int lane, double (&af0)[RO_KC], double (&af1)[RO_KC]) {
+                                               int lane, double (&af0)[KC], double (&af1)[KC]) {
 #pragma unroll
-  for (int i = 0; i < RO_KC; ++i) {
+  for (int i = 0; i < KC; ++i) {
     const int ks = ks0 + i;
     const bool ok = ks < ks1;
     af0[i] = ok ? Wp[((size_t)t0 * KS + ks) * 64 + lane] : 0.0;
@@ -1320,21 +1318,25 @@ __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int t0,
   }
 }
 
-template <int L_, int N_, int Q_>
-__global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArgs<double> ra) {
+template <int L_, int N_, int Q_, int NW>
+__global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double> ra) {
+  constexpr int KC = ro_kc(NW), NKQ = NW / 4;
+  constexpr int EPT = (128 * 16 + 64 * NW - 1) / (64 * NW);  // layer-1 / reduce outputs per thread (Hp <= 128)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* const smem = reinterpret_cast<double*>(smem_raw);
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave-uniform: trajectory index and LDS base stay scalar
   const int B = ra.s.B, n = ra.s.n, L = L_;
-  const int b0 = blockIdx.x * (int)(blockDim.x >> 6), b = b0 + wave;  // 16 waves (MLP lift); RBF: as many as fit in LDS
+  const int b0 = blockIdx.x * (int)(blockDim.x >> 6), b = b0 + wave;  // NW waves (MLP lift); RBF: as many as fit in LDS
   const bool live = b < B;
   // lift scratch (overlays the per-wave regions between two steps)
   double* const sPart = smem;
-  double* const sAct0 = smem + RO_PART;
+  double* const sAct0 = smem + ro_part(NW);
   double* const sAct1 = sAct0 + RO_ACT;
   double* const sPsi = smem + ra.keep_off;  // behind the per-wave regions: survives into the step
-  double* const sXn = sPsi + 64 * 16;
+  double* const sXn = sPsi + ra.Lp * 16;
+  if (!ra.lift_rbf && tid0 < 64) sXn[tid0] = 0.0;  // (columns of trajectories this workgroup does not have)
+  __syncthreads();
   if (!ra.lift_rbf && (tid0 & 63) < 4)
     sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? ra.s.X_rw[(size_t)(tid0 & 63) * B + b] : 0.0;
 
@@ -1381,33 +1383,32 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
       const int Hp = R.Hp, KS = R.KS, MTH = Hp >> 4, MTO = R.Lp >> 4;
       // hidden layers: wave (mg, kq) owns M tiles mg, mg+4 and the kq-th quarter of the k-steps
       const int mg = wv & 3, kq = wv >> 2;
-      const int kch = (KS + 3) >> 2;
+      const int kch = (KS + NKQ - 1) / NKQ;
       const int hks0 = kq * kch, hks1 = (hks0 + kch < KS) ? hks0 + kch : KS;
       const bool t1ok = mg + 4 < MTH;
       // output layer: tile to, k-chunk kc of nch
-      const int MTOp = MTO == 3 ? 4 : MTO, nch = RO_WAVES / MTOp;
+      const int MTOp = MTO == 3 ? 4 : MTO, nch = NW / MTOp;
       const int to = wv % MTOp, kc = wv / MTOp;
       const int och = (KS + nch - 1) / nch;
       const int oks0 = kc * och, oks1 = (oks0 + och < KS) ? oks0 + och : KS;
       const bool took = to < MTO;
-      double af0[RO_KC], af1[RO_KC];
+      double af0[RO_KB], af1[RO_KB];
       if (R.nhh > 0) ro_load_afrags(R.Whp[0], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
       // first-layer rows of this thread's two outputs (Hp * 16 <= 2048 = 2 per thread); W1 is zero-padded to 4 columns
-      double w1r[2][4], b1r[2];
+      double w1r[EPT][4], b1r[EPT];
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = tid + j * 64 * RO_WAVES;
+      for (int j = 0; j < EPT; ++j) {
+        const int e = tid + j * 64 * NW;
         const int row = e < Hp * 16 ? (e >> 4) : 0;
         b1r[j] = R.b1[row];
 #pragma unroll
         for (int i = 0; i < 4; ++i) w1r[j][i] = R.W1[4 * row + i];
       }
       __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all 16 is in sXn
-      KTRACE_RO(20);
       // ---- layer 1 (K = n <= 4) on the VALU, straight into B-fragment layout
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        const int e = tid + j * 64 * RO_WAVES;
+      for (int j = 0; j < EPT; ++j) {
+        const int e = tid + j * 64 * NW;
         if (e < Hp * 16) {
           const int row = e >> 4, col = e & 15;
           const double* xc = sXn + 4 * col;
@@ -1416,50 +1417,54 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
         }
       }
       __syncthreads();
-      KTRACE_RO(21);
       // ---- hidden -> hidden layers
       for (int h = 0; h < R.nhh; ++h) {
         const double* act = (h & 1) ? sAct1 : sAct0;
         double* actn = (h & 1) ? sAct0 : sAct1;
         // biases of the two outputs this thread reduces below: requested now, they arrive behind the MFMAs
-        double bpre[2];
+        double bpre[EPT];
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int e = tid + j * 64 * RO_WAVES;
+        for (int j = 0; j < EPT; ++j) {
+          const int e = tid + j * 64 * NW;
           const int rl = e & 255;
           bpre[j] = e < MTH * 256 ? R.bh[h][16 * (e >> 8) + ((rl & 63) >> 4) + 4 * (rl >> 6)] : 0.0;
         }
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int i = 0; i < RO_KC; ++i) {
-          if (hks0 + i < hks1) {
-            const double bf = act[(hks0 + i) * 64 + lane];
-            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i], bf, acc0, 0, 0, 0);
-            if (t1ok) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[i], bf, acc1, 0, 0, 0);
+        for (int bt = 0; bt < KC / RO_KB; ++bt) {
+          const int kb = hks0 + bt * RO_KB;
+          // the first batch was requested a layer ago; a second one (8 waves per workgroup) is fetched here
+          if (bt > 0 && kb < hks1) ro_load_afrags(R.Whp[h], KS, mg, t1ok, kb, hks1, lane, af0, af1);
+#pragma unroll
+          for (int i = 0; i < RO_KB; ++i) {
+            if (kb + i < hks1) {
+              const double bf = act[(kb + i) * 64 + lane];
+              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i], bf, acc0, 0, 0, 0);
+              if (t1ok) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[i], bf, acc1, 0, 0, 0);
+            }
           }
         }
         double* pw = sPart + (size_t)wv * 512;
 #pragma unroll
         for (int r = 0; r < 4; ++r) { pw[r * 64 + lane] = acc0[r]; pw[256 + r * 64 + lane] = acc1[r]; }
-        if (h == 0) KTRACE_RO(25);  // MFMAs of the first hidden layer issued and stored
         // the next layer's weights travel while the partial tiles are reduced
         if (h + 1 < R.nhh) ro_load_afrags(R.Whp[h + 1], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
         else if (took) ro_load_afrags(R.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int e = tid + j * 64 * RO_WAVES;
+        for (int j = 0; j < EPT; ++j) {
+          const int e = tid + j * 64 * NW;
           if (e < MTH * 256) {
             const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
             const double* pp = sPart + (size_t)(t & 3) * 512 + (size_t)(t >> 2) * 256 + rl;
-            const double sum = (pp[0] + pp[4 * 512]) + (pp[8 * 512] + pp[12 * 512]);  // kq = 0..3, fixed order
+            double sum = pp[0] + pp[4 * 512];  // K chunks in a fixed order
+            if constexpr (NKQ == 4) sum = sum + (pp[8 * 512] + pp[12 * 512]);
             const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
             const double v = sum + bpre[j];
             actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
           }
         }
         __syncthreads();
-        KTRACE_RO(22 + h);
       }
       // ---- output layer
       {
@@ -1470,7 +1475,7 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0};
         if (took) {
 #pragma unroll
-          for (int i = 0; i < RO_KC; ++i)
+          for (int i = 0; i < RO_KB; ++i)  // at most 8 k-steps per wave here (KS <= 32 over >= 4 chunks)
             if (oks0 + i < oks1)
               acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i], act[(oks0 + i) * 64 + lane], acc0, 0, 0, 0);
         }
@@ -1478,12 +1483,12 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
 #pragma unroll
         for (int r = 0; r < 4; ++r) pw[r * 64 + lane] = acc0[r];
         __syncthreads();
-        if (tid < MTO * 256) {  // MTO * 256 <= 1024 threads
-          const int t = tid >> 8, rl = orl, r = rl >> 6, l = rl & 63;
+        for (int e = tid; e < MTO * 256; e += 64 * NW) {
+          const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
           double sum = 0.0;
           for (int c = 0; c < nch; ++c) sum += sPart[(size_t)(c * MTOp + t) * 512 + rl];
           const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
-          sPsi[row * 16 + col] = sum + bopre;
+          sPsi[row * 16 + col] = sum + (e == tid ? bopre : R.bo[row]);
         }
         __syncthreads();  // psi is outside the overlay: from here the waves go their own way
         if (lane < L) psi_i = sPsi[lane * 16 + wv];
@@ -1524,47 +1529,78 @@ __global__ __launch_bounds__(64 * RO_WAVES) void rollout_kernel(const RolloutArg
   }
 }
 
-// waves (= trajectories) per workgroup of the fused roll-out: the MLP lift is written for 16; the RBF lift
-// needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.  0: does not fit.
-static int rollout_waves(int n, int L, int q, int N, bool rbf) {
-  const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr) + 15) & ~(size_t)15;
-  const int fit = (int)((160 * 1024) / per_wave);
-  if (!rbf) return (RO_WAVES * per_wave + RO_KEEP * sizeof(double) <= 160 * 1024) ? RO_WAVES : 0;
-  return fit >= RO_WAVES ? RO_WAVES : (fit >= 8 ? 8 : (fit >= 4 ? 4 : 0));
+// waves (= trajectories) per workgroup of the fused roll-out.  MLP lift: 16 (one workgroup per CU) or 8 (two per
+// CU); the RBF lift needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.
+// 0: does not fit.
+static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves, int Lp, int* wstride) {
+  const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr) / sizeof(double) + 1) & ~(size_t)1;
+  if (wstride) *wstride = (int)per_wave;
+  size_t elems = per_wave * waves;
+  if (rbf) return elems;
+  const size_t scratch = waves == 16 ? ro_scratch(16) : ro_scratch(8);
+  if (elems < scratch) elems = scratch;
+  return elems + ro_keep(Lp);
 }
-template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
-  RolloutArgs<double> k = a;
-  const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, a.lift_rbf != 0);
-  if (waves == 0) return hipErrorInvalidValue;
-  const size_t per_wave = step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2) / sizeof(double);
-  k.wstride = (int)((per_wave + 1) & ~(size_t)1);
-  size_t elems = (size_t)k.wstride * waves;
-  if (!a.lift_rbf && elems < (size_t)RO_SCRATCH) elems = RO_SCRATCH;
-  k.keep_off = (int)elems;
-  if (!a.lift_rbf) elems += RO_KEEP;
-  const size_t lds = elems * sizeof(double);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
+static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
+  const size_t cap = 160 * 1024 / sizeof(double);
+  if (!rbf) {
+    static const char* env = getenv("KMPC_ROLLOUT_WAVES");  // measurement aid: force 8 or 16
+    const bool fit16 = rollout_lds_elems(n, L, q, N, false, 16, Lp, nullptr) <= cap;
+    const bool fit8x2 = 2 * rollout_lds_elems(n, L, q, N, false, 8, Lp, nullptr) + 128 <= cap;
+    if (env && atoi(env) == 8) return rollout_lds_elems(n, L, q, N, false, 8, Lp, nullptr) <= cap ? 8 : 0;
+    if (env && atoi(env) == 16) return fit16 ? 16 : 0;
+    // batches that leave CUs without a 16-trajectory workgroup are spread as 8-trajectory ones (measured:
+    // B = 2048: 43.5 vs 35.7 M steps/s, B = 1024: 22.6 vs 18.4; at B = 4096 sixteen are faster, 72.0 vs 66.9)
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    if (fit8x2 && (B + 15) / 16 < cus) return 8;
+    if (fit16) return 16;
+    return fit8x2 ? 8 : 0;
+  }
+  for (int w = 16; w >= 4; w >>= 1)
+    if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
+  return 0;
+}
+template <int L_, int N_, int Q_, int NW>
+static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, size_t lds, hipStream_t s) {
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
-  const int grid = (a.s.B + waves - 1) / waves;
-  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_>), dim3(grid), dim3(64 * waves), lds, s, k);
+  const int grid = (k.s.B + waves - 1) / waves;
+  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW>), dim3(grid), dim3(64 * waves), lds, s, k);
   return hipGetLastError();
+}
+template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
+  RolloutArgs<double> k = a;
+  const bool rbf = a.lift_rbf != 0;
+  const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
+  if (waves == 0) return hipErrorInvalidValue;
+  step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2);
+  const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
+  k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp));
+  const size_t lds = elems * sizeof(double);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
+  if (!rbf && waves == 8) return launch_rollout_nw<L_, N_, Q_, 8>(k, waves, lds, s);
+  return launch_rollout_nw<L_, N_, Q_, 16>(k, waves, lds, s);
 }
 
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
   if (sizeof(T) != 8 || threads == 256 || n > 4) return false;
   const bool inst = (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
                     (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2);
-  return inst && rollout_waves(n, L, q, N, rbf) > 0;
+  return inst && rollout_waves(n, L, q, N, rbf, 64) > 0;  // (Lp <= 64)
 }
 template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
   if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
-  if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 4 * RO_KC || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
+  if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
     return hipErrorInvalidValue;
   if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
   if (a.s.L == 8 && a.s.N == 10 && a.s.q == 2) return launch_rollout_impl<8, 10, 2>(a, s);

@@ -51,11 +51,6 @@ if fused:  # roll-out kernel: one launch for all the steps; the per-step stamps 
     wait = (ready.max(1, keepdims=True) - ready).reshape(-1) / 100.0  # idle time before the lift barrier
     print("last step: wait for the slowest of 16  median %.2f p90 %.2f max %.2f us" % (np.median(wait), np.percentile(wait, 90), wait.max()))
     print("           lift (after the last wave arrived) median %.2f us" % np.median(((t[:, 17].reshape(-1, 16).min(1) - ready.max(1)) / 100.0)))
-    seg = [("all arrived -> layer 1 done", 20, 21), ("hidden layer 1: MFMA + partial store", 21, 25), ("hidden layer 1: barrier + reduce", 25, 22),
-           ("hidden layer 2", 22, 23), ("output layer + psi pick-up", 23, 17)]
-    for nm, i0, i1 in seg:
-        d = (t[:, i1] - t[:, i0]) / 100.0
-        print("           lift: %-40s median %.2f p90 %.2f us" % (nm, np.median(d), np.percentile(d, 90)))
     print("           step body median %.2f p90 %.2f max %.2f us; slowest-of-16 median %.2f us" % (
         np.median(body), np.percentile(body, 90), body.max(), np.median(body.reshape(-1, 16).max(1))))
 k0 = t[:, 0].min()
