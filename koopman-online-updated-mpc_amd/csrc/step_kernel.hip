@@ -1172,35 +1172,78 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     }
     // H[a][b] = Qw * S(b-a, N-1-b) (+Rw on the diagonal),  S(d,t) = sum_{s<=t} g_{s+d}.g_s
     KTRACE(6);
-    for (int d = tid; d < N; d += TPB) {
+    if constexpr (TPB == 64 && N_ > 0 && N_ <= 32 && Q_ > 0) {
+      // One pass for both: lane d < N walks diagonal d of H, lane 32 + a accumulates f[a].  Both are sums of
+      // g_t . w_{t+idx} with w = g (H) or e (f), so the two halves of the wave share one instruction stream.
+      const int hf = tid >> 5, idx = tid & 31;
+      const T* const wb = (hf ? sEr : sG) + idx * Q_;
+      const bool on = idx < N_;
+      const bool vec = ((Q_ & 1) == 0) && ((((int)(sG - sm)) & 1) == 0) && ((((int)(sEr - sm)) & 1) == 0);
       T acc = T(0);
+      auto pass = [&](auto dotq) {
 #pragma unroll
-      for (int t = 0; t < N; ++t) {
-        if (t + d < N) {
-          T s = T(0);
-#pragma unroll
-          for (int r = 0; r < q; ++r) s += sG[(t + d) * q + r] * sG[t * q + r];
-          acc += s;
-          const int bb = N - 1 - t, aa = bb - d;
-          const T hv = a.Qw * acc + (d == 0 ? a.Rw : T(0));
-          sH[aa * N + bb] = hv;
-          sH[bb * N + aa] = hv;
+        for (int t = 0; t < N_; ++t) {
+          if (on && t + idx < N_) {
+            acc += dotq(sG + t * Q_, wb + t * Q_);
+            if (!hf) {
+              const int bb = N_ - 1 - t, aa = bb - idx;
+              const T hv = a.Qw * acc + (idx == 0 ? a.Rw : T(0));
+              sH[aa * N_ + bb] = hv;
+              sH[bb * N_ + aa] = hv;
+            }
+          }
         }
+      };
+      if (vec) {  // 16-byte LDS reads (the layout is even for the shipped dimension sets)
+        typedef T T2 __attribute__((ext_vector_type(2)));
+        pass([](const T* x, const T* y) {
+          const T2* x2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(x, 2 * sizeof(T)));
+          const T2* y2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(y, 2 * sizeof(T)));
+          T s0 = T(0);
+#pragma unroll
+          for (int r = 0; r < Q_ / 2; ++r) { const T2 u = x2[r], w = y2[r]; s0 += u.x * w.x; s0 += u.y * w.y; }
+          return s0;
+        });
+      } else {
+        pass([](const T* x, const T* y) {
+          T s0 = T(0);
+#pragma unroll
+          for (int r = 0; r < Q_; ++r) s0 += x[r] * y[r];
+          return s0;
+        });
       }
-    }
-    // f on lanes 32.. so that it overlaps the H diagonals of lanes 0..N-1 when the wave has room
-    {
-      const int f0 = (TPB == 64 && N <= 32) ? 32 : 0;
-      for (int aa = tid - f0; aa < N; aa += TPB) {
-        if (aa < 0) continue;
+      if (hf && on) sf[idx] = T(2) * a.Qw * acc;
+    } else {
+    for (int d = tid; d < N; d += TPB) {
         T acc = T(0);
 #pragma unroll
-        for (int t = 0; t < N; ++t)
-          if (t + aa < N) {
+        for (int t = 0; t < N; ++t) {
+          if (t + d < N) {
+            T s = T(0);
 #pragma unroll
-            for (int r = 0; r < q; ++r) acc += sG[t * q + r] * sEr[(t + aa) * q + r];
+            for (int r = 0; r < q; ++r) s += sG[(t + d) * q + r] * sG[t * q + r];
+            acc += s;
+            const int bb = N - 1 - t, aa = bb - d;
+            const T hv = a.Qw * acc + (d == 0 ? a.Rw : T(0));
+            sH[aa * N + bb] = hv;
+            sH[bb * N + aa] = hv;
           }
-        sf[aa] = T(2) * a.Qw * acc;
+        }
+      }
+      // f on lanes 32.. so that it overlaps the H diagonals of lanes 0..N-1 when the wave has room
+      {
+        const int f0 = (TPB == 64 && N <= 32) ? 32 : 0;
+        for (int aa = tid - f0; aa < N; aa += TPB) {
+          if (aa < 0) continue;
+          T acc = T(0);
+#pragma unroll
+          for (int t = 0; t < N; ++t)
+            if (t + aa < N) {
+#pragma unroll
+              for (int r = 0; r < q; ++r) acc += sG[t * q + r] * sEr[(t + aa) * q + r];
+            }
+          sf[aa] = T(2) * a.Qw * acc;
+        }
       }
     }
     if (a.Wterm) {
