@@ -340,16 +340,20 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   }
   const T c0 = tclip(T(0), lb, ub);
 
-  T Tm[RM][RM], Hm[RM][RM];
+  // The tableau lives in registers; H itself stays in LDS (this lane's blocks at hb[r][c]) and is re-read for the
+  // few mat-vecs with H: a second register copy would cost 2 RM^2 VGPRs of the 128 that four waves per SIMD allow.
+  T Tm[RM][RM];
+  int hb[RM];    // LDS element offset of H(ti+8r, tj), or -1 beyond N
+  bool cok[RM];  // column tj+8c exists
+#pragma unroll
+  for (int r = 0; r < RM; ++r) hb[r] = (ti + 8 * r < N_) ? (ti + 8 * r) * N_ + tj : -1;
+#pragma unroll
+  for (int c = 0; c < RM; ++c) cok[c] = tj + 8 * c < N_;
+  auto Hel = [&](int r, int c) -> T { return (hb[r] >= 0 && cok[c]) ? sH[hb[r] + 8 * c] : T(0); };
 #pragma unroll
   for (int r = 0; r < RM; ++r)
 #pragma unroll
-    for (int c = 0; c < RM; ++c) {
-      const int i = ti + 8 * r, j = tj + 8 * c;
-      const T h = (i < N_ && j < N_) ? sH[i * N_ + j] : T(0);
-      Hm[r][c] = h;
-      Tm[r][c] = T(2) * h;
-    }
+    for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
   const T fi = own ? sf[myvar] : T(0);
   // row sums of H and |H| for the owner's variable: partial over my columns, 8-lane all-reduce,
   // the owner of variable ti + 8*tj picks block row r = tj
@@ -360,7 +364,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     for (int r = 0; r < RM; ++r) {
       T s0 = T(0), s1 = T(0);
 #pragma unroll
-      for (int c = 0; c < RM; ++c) { s0 += Hm[r][c]; s1 += tabs(Hm[r][c]); }
+      for (int c = 0; c < RM; ++c) { const T h = Hel(r, c); s0 += h; s1 += tabs(h); }
       ps[r] = allreduce8(s0);
       pa[r] = allreduce8(s1);
     }
@@ -380,7 +384,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     for (int r = 0; r < RM; ++r) {
       T s0 = T(0);
 #pragma unroll
-      for (int c = 0; c < RM; ++c) s0 += Hm[r][c] * xc[c];
+      for (int c = 0; c < RM; ++c) s0 += Hel(r, c) * xc[c];
       s0 = allreduce8(s0);
       if (tj == r) hx = s0;
     }
@@ -458,7 +462,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
 #pragma unroll
       for (int r = 0; r < RM; ++r)
 #pragma unroll
-        for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hm[r][c];
+        for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
       Smask = 0ull;
     }
     Fmask = Smask;
@@ -495,7 +499,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
       for (int r = 0; r < RM; ++r) {
         T s0 = T(0);
 #pragma unroll
-        for (int c = 0; c < RM; ++c) s0 += Hm[r][c] * xc[c];
+        for (int c = 0; c < RM; ++c) s0 += Hel(r, c) * xc[c];
         s0 = allreduce8(s0);
         if (tj == r) hxa = s0;
       }
