@@ -536,14 +536,21 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     if (sv.U0) sv.U0[b] = uout;
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
-      T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
+      // fused roll-out: x_k waits in the workgroup's LDS slot (no HBM round trip at the end of the step)
+      T x1 = sv.x_next ? sv.x_next[0] : a.X_rw[b], x2 = sv.x_next ? sv.x_next[1] : a.X_rw[(size_t)B + b];
       plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
       if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
     }
-    if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
-    if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+    if (sv.x_next) {  // ... and the status / iteration counters are accumulated next to it, written once at the end
+      int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
+      acc[0] = acc[0] > status ? acc[0] : status;
+      acc[1] += it;
+    } else {
+      if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
+      if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+    }
   }
   KTRACE(14);
   return false;
@@ -778,14 +785,21 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
     if (sv.U0) sv.U0[b] = uout;
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
-      T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
+      // fused roll-out: x_k waits in the workgroup's LDS slot (no HBM round trip at the end of the step)
+      T x1 = sv.x_next ? sv.x_next[0] : a.X_rw[b], x2 = sv.x_next ? sv.x_next[1] : a.X_rw[(size_t)B + b];
       plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
       if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
     }
-    if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
-    if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+    if (sv.x_next) {  // ... and the status / iteration counters are accumulated next to it, written once at the end
+      int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
+      acc[0] = acc[0] > status ? acc[0] : status;
+      acc[1] += it;
+    } else {
+      if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
+      if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+    }
   }
 }
 
@@ -1573,6 +1587,11 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
     if (have_prev) fresh = false;
     have_prev = true;
     cur ^= 1;
+  }
+  if (!ra.lift_rbf && live && (tid0 & 63) == 0) {  // (the host zeroed status / iters before the launch)
+    const int* const acc = reinterpret_cast<const int*>(sXn + wave * 4 + 2);
+    if (ra.s.status) ra.s.status[b] = acc[0];
+    if (ra.s.iters) ra.s.iters[b] = acc[1];
   }
 }
 
