@@ -1661,7 +1661,7 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
   if (sizeof(T) != 8 || threads == 256 || n > 4) return false;
   const bool inst = (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
-                    (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2);
+                    (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2) || (L == 10 && N == 20 && q == 1);
   return inst && rollout_waves(n, L, q, N, rbf, 64) > 0;  // (Lp <= 64)
 }
 template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
@@ -1673,6 +1673,7 @@ template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a
   if (a.s.L == 8 && a.s.N == 10 && a.s.q == 8) return launch_rollout_impl<8, 10, 8>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 8) return launch_rollout_impl<8, 30, 8>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);
+  if (a.s.L == 10 && a.s.N == 20 && a.s.q == 1) return launch_rollout_impl<10, 20, 1>(a, s);  // Tank_System.m dimensions
   return hipErrorInvalidValue;
 }
 template <> hipError_t launch_rollout_fused<float>(const RolloutArgs<float>&, hipStream_t) { return hipErrorInvalidValue; }

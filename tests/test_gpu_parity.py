@@ -741,6 +741,8 @@ def test_step_matches_separate_ops_bitwise(torch_mod, KM):
     ("mlp", 8, 10, "Cx", 33, 12),     # the reference's own dimensions
     ("rbf", 8, 30, "lift", 40, 8),    # RBF lift inside the roll-out kernel (cfg3 dimensions)
     ("mlp", 32, 40, "Cx", 20, 5),     # no fused instantiation: per-step launches
+    ("tank", 10, 20, "Cx", 24, 8),    # Tank_System.m: delta-u form, one output row, two hidden layers, tank plant
+    ("mlp", 20, 20, "Cx", 4096, 3),   # the bench's batch: 16 trajectories per workgroup (smaller batches use 8)
 ])
 def test_rollout_equals_step_plus_plant_loop(torch_mod, KM, lift, L, N, output, B, steps):
     """kmpc_rollout is the Python loop of step + plant_step, including the plant-parameter switch
@@ -752,20 +754,28 @@ def test_rollout_equals_step_plus_plant_loop(torch_mod, KM, lift, L, N, output, 
     from koopmpc.synth import random_mlp_weights
 
     rng = np.random.RandomState(4)
-    kw = dict(weights=random_mlp_weights(2, 100, 3, L, seed=3)) if lift == "mlp" else dict(lift="rbf", centres=4 * rng.rand(L, 2) - 2)
+    plant = "duffing"
+    if lift == "mlp":
+        kw = dict(weights=random_mlp_weights(2, 100, 3, L, seed=3))
+    elif lift == "tank":
+        plant = "tank"
+        kw = dict(weights=ko.load_mlp_weights(_load("weights_tank.npz")), layers=2, lb=-0.5, ub=0.5, umin=-8.0, umax=8.0,
+                  Qw=10.0, Rw=1e-3, P0=1e4, barQ0=1e4, delta_u=True, out_row0=1, out_rows=1, c_skip_first=True)
+    else:
+        kw = dict(lift="rbf", centres=4 * rng.rand(L, 2) - 2)
     A, Bm, Cm = _rand_model(rng, L, 2)
-    q = L if output == "lift" else 2
-    r = np.tile(np.array([[1.0], [0.0]]), (1, N)) if q == 2 else np.tile(rng.randn(q, 1), (1, N))
+    q = L if output == "lift" else (1 if lift == "tank" else 2)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N)) if q == 2 else (np.ones((1, N)) if q == 1 else np.tile(rng.randn(q, 1), (1, N)))
     m1 = KM(n=2, L=L, N=N, batch=B, output=output, **kw)
     m2 = KM(n=2, L=L, N=N, batch=B, output=output, **kw)
     m1.set_model(A, Bm, Cm); m2.set_model(A, Bm, Cm)
-    X0 = 4 * rng.rand(2, B) - 2
+    X0 = np.abs(rng.rand(2, B)) if lift == "tank" else 4 * rng.rand(2, B) - 2
     X1, X2 = _t(torch, X0), _t(torch, X0)
     s1 = steps // 2
-    Ul, Xl = m1.rollout("duffing", X1, r, s1, step0=98, switch_step=102, log=True) if s1 else (None, None)
+    Ul, Xl = m1.rollout(plant, X1, r, s1, step0=98, switch_step=102, log=True) if s1 else (None, None)
     it1 = m1.iters.clone() if s1 else 0
     st1 = m1.status.clone() if s1 else 0
-    Ul2, Xl2 = m1.rollout("duffing", X1, r, steps - s1, step0=98 + s1, switch_step=102, log=True)
+    Ul2, Xl2 = m1.rollout(plant, X1, r, steps - s1, step0=98 + s1, switch_step=102, log=True)
     its1 = it1 + m1.iters
     st1 = torch.maximum(st1, m1.status) if s1 else m1.status.clone()
     Ul = torch.cat([Ul, Ul2]) if s1 else Ul2
@@ -777,11 +787,11 @@ def test_rollout_equals_step_plus_plant_loop(torch_mod, KM, lift, L, N, output, 
         its += m2.iters
         st2 = torch.maximum(st2, m2.status)
         assert float((u - Ul[i]).abs().max()) < 1e-9, i
-        X2 = m2.plant_step("duffing", X2, u, switched=(98 + i >= 102))
+        X2 = m2.plant_step(plant, X2, u, switched=(98 + i >= 102))
         assert float((X2 - Xl[i]).abs().max()) < 1e-9, i
     assert float((X1 - X2).abs().max()) < 1e-9
     assert torch.equal(st1, st2)  # (the random model of the lifted-output case has a few degenerate QPs: status 1 on both sides)
-    if lift == "mlp":
+    if lift == "mlp" and B < 4096:
         assert int(st1.max().item()) == 0
     assert int((its1 - its)[st2 == 0].abs().max()) <= 2  # refinement solves may differ by rounding
     # the handles are in the same state: one more step agrees
