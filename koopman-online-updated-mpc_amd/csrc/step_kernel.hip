@@ -1352,37 +1352,32 @@ __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
 // synchronise with each other, so the launch no longer waits for the slowest QP of the whole batch at every
 // step (a per-step launch is one round of waves: it lasts as long as its slowest trajectory), only the 16
 // trajectories of a workgroup meet -- at the lift, which they compute together:
-//   MLP encoder on v_mfma_f64_16x16x4_f64 with the 16 trajectories as the N dimension; the 16 waves split
-//   the hidden rows (M tiles) and the K dimension, partial tiles are summed through LDS in a fixed order.
+//   MLP encoder on v_mfma_f64_16x16x4_f64 with the 16 trajectories as the N dimension; wave w owns hidden M
+//   tile w over the whole K range, bias + ReLU are applied on the accumulator registers and written straight
+//   into the next layer's B-fragment layout (one barrier per layer).  The weights are pre-packed A-fragments.
 //   The lift scratch overlays the per-wave LDS regions, which are dead between two steps.
 // RBF lift: every wave lifts its own state, the waves of a workgroup never meet.
 // ---------------------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
-// NW = waves (= trajectories) per workgroup: 16 (one workgroup per CU) or 8 (two per CU: while one of them waits
-// for its slowest trajectory or runs its lift, the other one computes; MFMA tiles are then half empty).
+// NW = waves (= trajectories) per workgroup: 16 (one workgroup per CU) or 8 (two per CU, MFMA tiles half empty:
+// used when the batch would otherwise leave CUs without a workgroup).
 constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
-constexpr int ro_part(int NW) { return NW * 2 * 256; }             // partial accumulator tiles [wave][slot][256]
-constexpr int ro_scratch(int NW) { return ro_part(NW) + 2 * RO_ACT; }  // overlays the per-wave regions between two steps
-constexpr int ro_kc(int NW) { return 128 / NW; }                   // k-steps per wave and layer (KS <= 32, NW/4 K chunks)
-constexpr int RO_KB = 8;                                           // ... fetched and multiplied in batches of 8
+constexpr int ro_scratch() { return 2 * RO_ACT; }     // overlays the per-wave regions between two steps
+constexpr int RO_KB2 = 16;                            // A-fragments are fetched and multiplied in batches of 16 k-steps
 static int ro_keep(int Lp) { return Lp * 16 + 64; }  // not overlaid: psi (Lp x 16), x_{k+1} of the trajectories (16 x 4)
 
-template <int KC>
-__device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int t0, bool t1ok, int ks0, int ks1,
-                                               int lane, double (&af0)[KC], double (&af1)[KC]) {
+// A-fragments of tile `tile`, k-steps ks0 .. ks0+15 (zero beyond KS)
+__device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int tile, int ks0, int lane, double (&af)[RO_KB2]) {
 #pragma unroll
-  for (int i = 0; i < KC; ++i) {
+  for (int i = 0; i < RO_KB2; ++i) {
     const int ks = ks0 + i;
-    const bool ok = ks < ks1;
-    af0[i] = ok ? Wp[((size_t)t0 * KS + ks) * 64 + lane] : 0.0;
-    af1[i] = (ok && t1ok) ? Wp[((size_t)(t0 + 4) * KS + ks) * 64 + lane] : 0.0;
+    af[i] = ks < KS ? Wp[((size_t)tile * KS + ks) * 64 + lane] : 0.0;
   }
 }
 
 template <int L_, int N_, int Q_, int NW>
 __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double> ra) {
-  constexpr int KC = ro_kc(NW), NKQ = NW / 4;
-  constexpr int EPT = (128 * 16 + 64 * NW - 1) / (64 * NW);  // layer-1 / reduce outputs per thread (Hp <= 128)
+  constexpr int EPT = (128 * 16 + 64 * NW - 1) / (64 * NW);  // first-layer outputs per thread (Hp <= 128)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* const smem = reinterpret_cast<double*>(smem_raw);
   const int tid0 = threadIdx.x;
@@ -1391,8 +1386,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
   const int b0 = blockIdx.x * (int)(blockDim.x >> 6), b = b0 + wave;  // NW waves (MLP lift); RBF: as many as fit in LDS
   const bool live = b < B;
   // lift scratch (overlays the per-wave regions between two steps)
-  double* const sPart = smem;
-  double* const sAct0 = smem + ro_part(NW);
+  double* const sAct0 = smem;
   double* const sAct1 = sAct0 + RO_ACT;
   double* const sPsi = smem + ra.keep_off;  // behind the per-wave regions: survives into the step
   double* const sXn = sPsi + ra.Lp * 16;
@@ -1441,21 +1435,16 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
         }
       }
     } else {
+      // Cooperative encoder.  Wave w < Hp/16 owns hidden M tile w for the whole K range (two alternating
+      // accumulator chains), so bias + ReLU are applied on the accumulator registers and the result is written
+      // straight into the next layer's B-fragment layout: one barrier per layer, no partial sums.  The other
+      // waves only take part in the first layer (VALU) and in the barriers.
       const int Hp = R.Hp, KS = R.KS, MTH = Hp >> 4, MTO = R.Lp >> 4;
-      // hidden layers: wave (mg, kq) owns M tiles mg, mg+4 and the kq-th quarter of the k-steps
-      const int mg = wv & 3, kq = wv >> 2;
-      const int kch = (KS + NKQ - 1) / NKQ;
-      const int hks0 = kq * kch, hks1 = (hks0 + kch < KS) ? hks0 + kch : KS;
-      const bool t1ok = mg + 4 < MTH;
-      // output layer: tile to, k-chunk kc of nch
-      const int MTOp = MTO == 3 ? 4 : MTO, nch = NW / MTOp;
-      const int to = wv % MTOp, kc = wv / MTOp;
-      const int och = (KS + nch - 1) / nch;
-      const int oks0 = kc * och, oks1 = (oks0 + och < KS) ? oks0 + och : KS;
-      const bool took = to < MTO;
-      double af0[RO_KB], af1[RO_KB];
-      if (R.nhh > 0) ro_load_afrags(R.Whp[0], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
-      // first-layer rows of this thread's two outputs (Hp * 16 <= 2048 = 2 per thread); W1 is zero-padded to 4 columns
+      const bool hid = wv < MTH, out = wv < MTO;
+      double af[RO_KB2];  // A-fragments of the first 16 k-steps of the coming layer (requested a layer ahead)
+      if (R.nhh > 0) { if (hid) ro_load_afrags(R.Whp[0], KS, wv, 0, lane, af); }
+      else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af);
+      // first-layer rows of this thread's outputs (W1 is zero-padded to 4 columns)
       double w1r[EPT][4], b1r[EPT];
 #pragma unroll
       for (int j = 0; j < EPT; ++j) {
@@ -1465,7 +1454,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
 #pragma unroll
         for (int i = 0; i < 4; ++i) w1r[j][i] = R.W1[4 * row + i];
       }
-      __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all 16 is in sXn
+      __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all trajectories is in sXn
       // ---- layer 1 (K = n <= 4) on the VALU, straight into B-fragment layout
 #pragma unroll
       for (int j = 0; j < EPT; ++j) {
@@ -1478,82 +1467,48 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
         }
       }
       __syncthreads();
-      // ---- hidden -> hidden layers
-      for (int h = 0; h < R.nhh; ++h) {
+      // ---- hidden -> hidden layers, then the output layer, all as: tile = wave, full K
+      for (int h = 0; h <= R.nhh; ++h) {
+        const bool last = h == R.nhh;
+        const bool mine = last ? out : hid;
         const double* act = (h & 1) ? sAct1 : sAct0;
         double* actn = (h & 1) ? sAct0 : sAct1;
-        // biases of the two outputs this thread reduces below: requested now, they arrive behind the MFMAs
-        double bpre[EPT];
+        const double* Wp = last ? R.Wop : R.Whp[h];
+        const double* bias = last ? R.bo : R.bh[h];
+        // accumulator register r of lane l holds row (l >> 4) + 4 r, column l & 15 of the tile
+        double bpre[4];
 #pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-          const int e = tid + j * 64 * NW;
-          const int rl = e & 255;
-          bpre[j] = e < MTH * 256 ? R.bh[h][16 * (e >> 8) + ((rl & 63) >> 4) + 4 * (rl >> 6)] : 0.0;
-        }
+        for (int r = 0; r < 4; ++r) bpre[r] = mine ? bias[16 * wv + (lane >> 4) + 4 * r] : 0.0;
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        if (mine) {
 #pragma unroll
-        for (int bt = 0; bt < KC / RO_KB; ++bt) {
-          const int kb = hks0 + bt * RO_KB;
-          // the first batch was requested a layer ago; a second one (8 waves per workgroup) is fetched here
-          if (bt > 0 && kb < hks1) ro_load_afrags(R.Whp[h], KS, mg, t1ok, kb, hks1, lane, af0, af1);
+          for (int bt = 0; bt < 2; ++bt) {  // KS <= 32 k-steps in two batches of 16
+            const int kb = bt * RO_KB2;
+            if (bt > 0 && kb < KS) ro_load_afrags(Wp, KS, wv, kb, lane, af);
 #pragma unroll
-          for (int i = 0; i < RO_KB; ++i) {
-            if (kb + i < hks1) {
-              const double bf = act[(kb + i) * 64 + lane];
-              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i], bf, acc0, 0, 0, 0);
-              if (t1ok) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af1[i], bf, acc1, 0, 0, 0);
+            for (int i = 0; i < RO_KB2; i += 2) {
+              if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], act[(kb + i) * 64 + lane], acc0, 0, 0, 0);
+              if (kb + i + 1 < KS)
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
             }
           }
-        }
-        double* pw = sPart + (size_t)wv * 512;
+          const int col = lane & 15;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) { pw[r * 64 + lane] = acc0[r]; pw[256 + r * 64 + lane] = acc1[r]; }
-        // the next layer's weights travel while the partial tiles are reduced
-        if (h + 1 < R.nhh) ro_load_afrags(R.Whp[h + 1], KS, mg, t1ok, hks0, hks1, lane, af0, af1);
-        else if (took) ro_load_afrags(R.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
-        __syncthreads();
-#pragma unroll
-        for (int j = 0; j < EPT; ++j) {
-          const int e = tid + j * 64 * NW;
-          if (e < MTH * 256) {
-            const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
-            const double* pp = sPart + (size_t)(t & 3) * 512 + (size_t)(t >> 2) * 256 + rl;
-            double sum = pp[0] + pp[4 * 512];  // K chunks in a fixed order
-            if constexpr (NKQ == 4) sum = sum + (pp[8 * 512] + pp[12 * 512]);
-            const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
-            const double v = sum + bpre[j];
-            actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wv + (lane >> 4) + 4 * r;
+            const double v = (acc0[r] + acc1[r]) + bpre[r];
+            if (last) sPsi[row * 16 + col] = v;
+            else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
           }
         }
-        __syncthreads();
-      }
-      // ---- output layer
-      {
-        const double* act = (R.nhh & 1) ? sAct1 : sAct0;
-        if (R.nhh == 0 && took) ro_load_afrags(R.Wop, KS, to, false, oks0, oks1, lane, af0, af1);
-        const int orl = tid & 255;
-        const double bopre = tid < MTO * 256 ? R.bo[16 * (tid >> 8) + ((orl & 63) >> 4) + 4 * (orl >> 6)] : 0.0;
-        d4_t acc0 = {0.0, 0.0, 0.0, 0.0};
-        if (took) {
-#pragma unroll
-          for (int i = 0; i < RO_KB; ++i)  // at most 8 k-steps per wave here (KS <= 32 over >= 4 chunks)
-            if (oks0 + i < oks1)
-              acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af0[i], act[(oks0 + i) * 64 + lane], acc0, 0, 0, 0);
+        // the next layer's first fragments travel across the barrier
+        if (!last) {
+          if (h + 1 < R.nhh) { if (hid) ro_load_afrags(R.Whp[h + 1], KS, wv, 0, lane, af); }
+          else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af);
         }
-        double* pw = sPart + (size_t)wv * 512;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) pw[r * 64 + lane] = acc0[r];
-        __syncthreads();
-        for (int e = tid; e < MTO * 256; e += 64 * NW) {
-          const int t = e >> 8, rl = e & 255, r = rl >> 6, l = rl & 63;
-          double sum = 0.0;
-          for (int c = 0; c < nch; ++c) sum += sPart[(size_t)(c * MTOp + t) * 512 + rl];
-          const int row = 16 * t + (l >> 4) + 4 * r, col = l & 15;
-          sPsi[row * 16 + col] = sum + (e == tid ? bopre : R.bo[row]);
-        }
-        __syncthreads();  // psi is outside the overlay: from here the waves go their own way
-        if (lane < L) psi_i = sPsi[lane * 16 + wv];
+        __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
       }
+      if (lane < L) psi_i = sPsi[lane * 16 + wv];
     }
 
 #ifdef KMPC_TRACE
@@ -1603,7 +1558,7 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
   if (wstride) *wstride = (int)per_wave;
   size_t elems = per_wave * waves;
   if (rbf) return elems;
-  const size_t scratch = waves == 16 ? ro_scratch(16) : ro_scratch(8);
+  const size_t scratch = ro_scratch();
   if (elems < scratch) elems = scratch;
   return elems + ro_keep(Lp);
 }
