@@ -340,16 +340,28 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   }
   const T c0 = tclip(T(0), lb, ub);
 
-  // The tableau lives in registers; H itself stays in LDS (this lane's blocks at hb[r][c]) and is re-read for the
-  // few mat-vecs with H: a second register copy would cost 2 RM^2 VGPRs of the 128 that four waves per SIMD allow.
-  T Tm[RM][RM];
+  // The tableau lives in registers.  N <= 24 (cfg1/2, reference dims): H itself stays in LDS (this lane's blocks at
+  // hb[r] + 8c) and is re-read for the few mat-vecs with H -- a second register copy costs 2 RM^2 VGPRs of the 128
+  // that four waves per SIMD allow, and the fused roll-out spilled because of it.  Longer horizons evaluate more
+  // line-search products per solve and keep the register copy (L = 8, N = 30: 209 vs 254 us per step).
+  constexpr bool HREG = N_ > 24;
+  T Tm[RM][RM], Hm[HREG ? RM : 1][HREG ? RM : 1];
   int hb[RM];    // LDS element offset of H(ti+8r, tj), or -1 beyond N
   bool cok[RM];  // column tj+8c exists
 #pragma unroll
   for (int r = 0; r < RM; ++r) hb[r] = (ti + 8 * r < N_) ? (ti + 8 * r) * N_ + tj : -1;
 #pragma unroll
   for (int c = 0; c < RM; ++c) cok[c] = tj + 8 * c < N_;
-  auto Hel = [&](int r, int c) -> T { return (hb[r] >= 0 && cok[c]) ? sH[hb[r] + 8 * c] : T(0); };
+  if constexpr (HREG) {
+#pragma unroll
+    for (int r = 0; r < RM; ++r)
+#pragma unroll
+      for (int c = 0; c < RM; ++c) Hm[r][c] = (hb[r] >= 0 && cok[c]) ? sH[hb[r] + 8 * c] : T(0);
+  }
+  auto Hel = [&](int r, int c) -> T {
+    if constexpr (HREG) return Hm[r][c];
+    else return (hb[r] >= 0 && cok[c]) ? sH[hb[r] + 8 * c] : T(0);
+  };
 #pragma unroll
   for (int r = 0; r < RM; ++r)
 #pragma unroll
