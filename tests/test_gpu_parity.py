@@ -802,6 +802,44 @@ def test_rollout_equals_step_plus_plant_loop(torch_mod, KM, lift, L, N, output, 
     assert float((A1 - A2).abs().max()) <= 1e-9 * max(1.0, float(A2.abs().max()))
 
 
+@pytest.mark.parametrize("L,N,B,steps", [(20, 20, 19, 14), (8, 10, 33, 20)])
+def test_fused_rollout_vs_oracle(torch_mod, KM, L, N, B, steps):
+    """The dominant kernel of the bench against the oracle directly: kmpc_rollout (one fused launch: encoder on
+    MFMA inside, RLS, condense, QP, RK4 plant, parameter switch) vs per-trajectory oracle controllers (gain-form RLS,
+    exact QP) driving the oracle's plant.  Inputs and states of every step within 1e-6 (north-star tolerance);
+    observed ~1e-9."""
+    torch = torch_mod
+    from koopmpc.synth import duffing_rk4, initial_states, offline_edmd, random_mlp_weights
+
+    w = random_mlp_weights(2, 100, 3, L, seed=5)
+    mpc = KM(n=2, L=L, N=N, batch=B, weights=w)
+    assert mpc.rollout_is_fused()
+    lift_fn = lambda x: ko.mlp_lift(w, x)
+    A0, B0, C0 = offline_edmd(lambda X: mpc.Encoder(X), plant=duffing_rk4)
+    mpc.set_model(A0, B0, C0)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X0 = initial_states(B, seed=3)
+    Xd = _t(torch, X0)
+    step0, sw = 97, 102
+    Ul, Xl = mpc.rollout("duffing", Xd, r, steps, step0=step0, switch_step=sw, log=True)
+    assert int(mpc.status.max().item()) == 0
+    Ul, Xl = Ul.cpu().numpy(), Xl.cpu().numpy()
+    worst_u, worst_x = 0.0, 0.0
+    for b in range(B):
+        ctl = ko.OracleController(lift_fn, L, 2, N, -2.0, 2.0, A0, B0, C0, rls="gain")
+        x = X0[:, b].copy()
+        for k in range(steps):
+            uo, _, _ = ctl.step(x, r)
+            worst_u = max(worst_u, abs(Ul[k, b] - uo))
+            # both sides regress on the input that was applied and continue from the GPU's state
+            ctl.prev = (ctl.prev[0], float(Ul[k, b]))
+            xo = ko.plant_step("duffing", x, float(Ul[k, b]), switched=(step0 + k >= sw))
+            worst_x = max(worst_x, float(np.abs(Xl[k, :, b] - xo).max()))
+            x = Xl[k, :, b].copy()
+    print("fused roll-out vs oracle L=%d N=%d: max |u - u_oracle| = %.2e, max |x - x_oracle| = %.2e" % (L, N, worst_u, worst_x))
+    assert worst_u < 1e-6 and worst_x < 1e-9
+
+
 def test_checkpoint_roundtrip(torch_mod, KM):
     torch = torch_mod
     from koopmpc.synth import random_mlp_weights
