@@ -840,6 +840,42 @@ def test_fused_rollout_vs_oracle(torch_mod, KM, L, N, B, steps):
     assert worst_u < 1e-6 and worst_x < 1e-9
 
 
+@pytest.mark.parametrize("B,per_traj,cold,term", [(1, False, False, False), (5, True, False, False), (21, False, True, False),
+                                                  (12, True, False, True)])
+def test_fused_rollout_options(torch_mod, KM, B, per_traj, cold, term):
+    """Options of the step inside the fused roll-out kernel: batches smaller than a workgroup (idle waves still take
+    part in the lift and its barriers), a reference per trajectory, cold starts, the terminal weight -- each against
+    the per-step path, then a checkpoint taken between two roll-outs continues identically on a second handle."""
+    torch = torch_mod
+    from koopmpc.synth import random_mlp_weights
+
+    rng = np.random.RandomState(B)
+    L, N = 20, 20
+    w = random_mlp_weights(2, 100, 3, L, seed=3)
+    A, Bm, Cm = _rand_model(rng, L, 2)
+    ms = [KM(n=2, L=L, N=N, batch=B, weights=w, cold_start=cold) for _ in range(3)]
+    for m in ms:
+        m.set_model(A, Bm, Cm)
+        if term:
+            m.set_terminal_weight(np.array([[700.0, 90.0], [90.0, 300.0]]))
+    assert ms[0].rollout_is_fused()
+    r = rng.randn(B, 2, N) if per_traj else np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X0 = 4 * rng.rand(2, B) - 2
+    X = [_t(torch, X0) for _ in range(3)]
+    ms[0].rollout("duffing", X[0], r, 4, step0=0)
+    for k in range(4):
+        X[1] = ms[1].plant_step("duffing", X[1], ms[1].step(X[1], r).clone())
+    assert float((X[0] - X[1]).abs().max()) < 1e-9
+    ms[2].load_state_dict(ms[0].state_dict())   # checkpoint after the first roll-out ...
+    X[2] = X[0].clone()
+    ms[0].rollout("duffing", X[0], r, 3, step0=4)
+    ms[2].rollout("duffing", X[2], r, 3, step0=4)  # ... continues bit for bit on another handle
+    assert torch.equal(X[0], X[2])
+    for k in range(3):
+        X[1] = ms[1].plant_step("duffing", X[1], ms[1].step(X[1], r).clone())
+    assert float((X[0] - X[1]).abs().max()) < 1e-9
+
+
 def test_checkpoint_roundtrip(torch_mod, KM):
     torch = torch_mod
     from koopmpc.synth import random_mlp_weights
