@@ -1,7 +1,8 @@
 // step_kernel.hip -- the per-trajectory hot path on gfx950: RLS-EDMD update -> condensed QP
-// build -> box-QP solve.  One workgroup (one 64-lane wave by default, four for large
-// dimensions) owns one trajectory; its covariance / model / KKT tiles live in LDS, the
-// persistent state streams HBM -> LDS -> HBM exactly once per step.
+// build -> box-QP solve (step_body), as a per-step kernel (one 64-lane wave per trajectory by default, four for
+// large dimensions) and inside the fused roll-out kernel (all steps of the closed loop in one launch, 16
+// trajectories per workgroup, encoder on MFMA; second half of this file).  Covariance / model / KKT tiles live in
+// LDS, the persistent state streams HBM -> LDS -> HBM exactly once per step.
 //
 // Reference arithmetic restated here (file:line under the reference root):
 //   RLS of [A B]  duffing.py:900, 927-938, 965-967 (lambda form Koopman_update.m:258-278)
