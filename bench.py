@@ -217,7 +217,7 @@ def main():
                             "RK4 plant on device, parameter switch at step 102" % (L, L, N, B, world),
                 "global_batch": total,
                 "parallelism": "trajectory-sharded x%d, no collective on the step path" % world,
-                "qp": "exact box-QP (projected Newton), warm start from the previous minimiser as the reference; mean Newton solves/step %.2f, worst trajectory total %d"
+                "qp": "exact box-QP (projected Newton), each solve started at the previous minimiser (the reference restarts at zeros: same minimiser, more work); mean Newton solves/step %.2f, worst trajectory total %d"
                       % (newton_per_step, newton_max),
                 "worst_qp_status": worst_status,
                 "finite": x_ok,

@@ -65,9 +65,9 @@ typedef struct kmpc_config {
   int32_t out_row0;    /* KMPC_OUT_CX: outputs are rows out_row0 .. out_row0+out_rows-1 of C x   */
   int32_t out_rows;    /*   (Cy = [0 1] -> out_row0 = 1, out_rows = 1, Tank_System.m:113); 0 -> all n rows */
   int32_t c_skip_first;/* 1: the first C update only downdates bar_Q (Tank_System.m:252-254)     */
-  int32_t cold_start;  /* 0: kmpc_step / kmpc_rollout start each solve at the previous minimiser, as the
-                          reference does (pastRes_loc, duffing.py:857-865); 1: always at clip(0).  The
-                          minimiser is unique, so this only changes the work, not the answer          */
+  int32_t cold_start;  /* 0: kmpc_step / kmpc_rollout start each solve at the previous minimiser; 1: always at
+                          clip(0), the reference's start (its pastRes_loc stays zeros, duffing.py:634-635, 859).
+                          The minimiser is unique, so this only changes the work, not the answer        */
   int32_t reserved0;   /* keeps the doubles 8-byte aligned; must be 0                              */
   double lambda;       /* RLS forgetting factor (1.0; Koopman_update.m:258)                */
   double P0;           /* inv_K_G init scale (1e4 duffing.py:929-930; 1e5 vanderpol.py:874)*/

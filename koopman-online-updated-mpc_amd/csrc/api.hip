@@ -76,7 +76,7 @@ struct Impl : kmpc_handle {
   T *dP = nullptr, *dK = nullptr, *dQ = nullptr, *dC = nullptr;
   T *dPsi[2] = {nullptr, nullptr};  // [B][L] trajectory-major: [cur], [prev]
   T* dUprev = nullptr;
-  T* dWarm = nullptr;  // [N][B] last minimiser = start of the next solve (pastRes_loc, duffing.py:865)
+  T* dWarm = nullptr;  // [N][B] last minimiser = start of the next solve (the reference restarts at zeros, duffing.py:634-635)
   int cur = 0;
   bool have_prev = false;  // a previous (psi, u) exists -> next step runs the RLS update
   bool rls_fresh = true;   // next RLS update starts from K_A = 0, bar_X = 0
@@ -233,7 +233,7 @@ struct Impl : kmpc_handle {
     if (dGram) HIPCHK(hipMemsetAsync(dGram, 0, sizeof(double) * (size_t)gram_elems(), s));
     shared_has_samples = false;
     HIPCHK(launch_fill_state<T>(dP, sP, p, (T)cfg.P0, dQ, sQ, L, (T)cfg.barQ0, nullptr, sK, nullptr, sC, n, B, s));
-    HIPCHK(hipMemsetAsync(dWarm, 0, sizeof(T) * (size_t)N * B, s));  // pastRes_loc = zeros (duffing.py:634)
+    HIPCHK(hipMemsetAsync(dWarm, 0, sizeof(T) * (size_t)N * B, s));  // first solve starts at clip(0) like the reference's (duffing.py:634-635)
     have_prev = false;
     rls_fresh = true;
     cur = 0;

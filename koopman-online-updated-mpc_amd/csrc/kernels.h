@@ -50,7 +50,8 @@ struct StepArgs {
   T* U0;             // [B] or null
   T* u_store;        // [B] handle copy of u_k for the next RLS update, or null
   int32_t* status; int32_t* iters;
-  T* x_warm;       // [N][B] previous minimiser: start of the next solve (pastRes_loc, duffing.py:857-865), or null
+  T* x_warm;       // [N][B] previous minimiser = start of the next solve, or null: start at clip(0) as the reference
+                   // does (its pastRes_loc stays zeros, duffing.py:634-635, 859); same minimiser, less work
   const T* Wterm;  // q x q, PN - Qw I: terminal block of Q_bar (Koopman_update.m:381), or null
   T lam, Qw, Rw, lb, ub;
 };

@@ -385,8 +385,9 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     for (int r = 0; r < RM; ++r) if (tj == r) { rs = ps[r]; ra = pa[r]; }
   }
   const T gs = tabs(fi) + T(2) * ra * xmaxb;
-  // start: the previous minimiser like the reference (pastRes_loc, duffing.py:857-865) when the handle keeps
-  // one, else clip(0) (duffing.py:634-635).  The minimiser is unique: the start only changes the work.
+  // start: the previous minimiser when the handle keeps one, else clip(0) -- the reference's start (its
+  // pastRes_loc is never updated: zeros at every step, duffing.py:634-635, 859).  The minimiser is unique: the
+  // start only changes the work.
   T x = own ? (a.x_warm ? tclip(a.x_warm[(size_t)myvar * a.B + b], lb, ub) : c0) : T(0);
   T hx = T(0);  // H x at the start (x need not be uniform: the first variable's box may differ)
   {

@@ -653,9 +653,10 @@ def test_tank_delta_u_closed_loop(torch_mod, KM, lift, threads, N):
     (8, 30, "Cx", "mlp", 0, 1e-6),  # long horizon, cond(H) up to ~2e6 in this loop: the north-star tolerance
 ])
 def test_warm_start_is_the_same_minimiser_with_less_work(torch_mod, KM, L, N, output, lift, threads, tol):
-    """The reference starts each solve at the previous result (pastRes_loc, duffing.py:857-865); kmpc_step does
-    the same by default.  The QP is strictly convex, so warm and cold starts give the same minimiser (to the
-    KKT tolerance) -- only the number of Newton solves differs."""
+    """The reference starts every solve at zeros (its pastRes_loc is never updated, duffing.py:634-635, 859);
+    kmpc_step starts at the previous minimiser by default, cold_start=1 at clip(0) like the reference.  The QP is
+    strictly convex, so both give the same minimiser (to the KKT tolerance) -- only the number of Newton solves
+    differs."""
     torch = torch_mod
     from koopmpc.synth import duffing_rk4, initial_states, offline_data, random_mlp_weights, vdp_rk4
 
