@@ -73,6 +73,8 @@ def main():
     ap.add_argument("--N", type=int, default=20)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--cold-start", action="store_true",
+                    help="start every QP at clip(0) like the reference instead of at the previous minimiser")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--spin-seconds", type=float, default=1.0,
                     help="untimed GPU activity on a scratch copy of the workload before the warm-up, so that the "
@@ -102,7 +104,8 @@ def main():
     L, N, B = args.L, args.N, args.batch
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     weights = random_mlp_weights(2, 100, 3, L, seed=2024)
-    mpc = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev)
+    mpc = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev,
+                     cold_start=args.cold_start)
     # one-off offline EDMD fit (duffing.py:152-177) on the device: lift, MFMA Gram sums, p x p solve; identical on
     # every rank; the fitted model is handed to every trajectory
     A0, B0, C0 = [t.cpu().numpy() for t in mpc.offline_fit(*offline_data())]
@@ -125,7 +128,8 @@ def main():
     #      the snapshot (same launches as the timed one, so a rocprofv3 --stats average over the process is
     #      comparable with the number reported below); it does not touch the workload's controller
     if args.spin_seconds > 0:
-        scratch = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev)
+        scratch = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev,
+                             cold_start=args.cold_start)
         Xs = X.clone()
         t_spin = time.perf_counter()
         while time.perf_counter() - t_spin < args.spin_seconds:
@@ -217,8 +221,10 @@ def main():
                             "RK4 plant on device, parameter switch at step 102" % (L, L, N, B, world),
                 "global_batch": total,
                 "parallelism": "trajectory-sharded x%d, no collective on the step path" % world,
-                "qp": "exact box-QP (projected Newton), each solve started at the previous minimiser (the reference restarts at zeros: same minimiser, more work); mean Newton solves/step %.2f, worst trajectory total %d"
-                      % (newton_per_step, newton_max),
+                "qp": "exact box-QP (projected Newton), %s; mean Newton solves/step %.2f, worst trajectory total %d"
+                      % ("each solve started at clip(0) like the reference" if args.cold_start else
+                         "each solve started at the previous minimiser (the reference restarts at zeros: same minimiser, more work)",
+                         newton_per_step, newton_max),
                 "worst_qp_status": worst_status,
                 "finite": x_ok,
             },
