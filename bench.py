@@ -218,7 +218,8 @@ def main():
             "config": {
                 "workload": "BASELINE cfg2: Duffing closed loop, %d-dim MLP lift (2-100-100-100-%d, random init seed 2024), "
                             "horizon N=%d, box +-2, %d trajectories per GPU x %d GPU(s), per-trajectory RLS, "
-                            "RK4 plant on device, parameter switch at step 102" % (L, L, N, B, world),
+                            "RK4 plant on device, parameter switch at step 102; arithmetic in %s (the config line names fp32; the "
+                            "reference computes in float64 and the 1e-6 bar on u needs it, DESIGN.md 4.1)" % (L, L, N, B, world, args.dtype),
                 "global_batch": total,
                 "parallelism": "trajectory-sharded x%d, no collective on the step path" % world,
                 "qp": "exact box-QP (projected Newton), %s; mean Newton solves/step %.2f, worst trajectory total %d"
