@@ -536,6 +536,9 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + 15] = (unsigned long long)it;
 #endif
 
+  // non-finite problem data (status 2): the point handed back is the feasible start clip(0), never a NaN -- the
+  // plant state and the next warm start stay finite and the caller sees the status
+  if (status == 2) x = own ? c0 : T(0);
   if (status == 3) {  // hand the current point to the active-set solver
     if (own) qx_out[myvar] = x;
     return true;
@@ -787,6 +790,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
     J0 = Ja;
     ++it;
   }
+  if (status == 2) x = c0;  // (see qp_regs: non-finite data never leaves as a NaN input)
   if (mine) qx[tid] = x;
   block_sync<TPB>();
 

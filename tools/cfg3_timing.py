@@ -11,13 +11,14 @@ from koopmpc.synth import initial_states, offline_data, vdp_rk4
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 out = sys.argv[3] if len(sys.argv) > 3 else "lift"
+storage = not (len(sys.argv) > 4 and sys.argv[4] == "restart")  # restart: first update from K_A = 0 (duffing.py)
 L, N = 8, 30
 rng = np.random.RandomState(0)
 X, Y, U = offline_data(plant=vdp_rk4)
 # centres: a k-means-free stand-in (vanderpol_RBF.py:44-46 uses KMeans on the data): 8 data points
 cx = X[:, rng.choice(X.shape[1], L, replace=False)].T.copy()
 m = KoopmanMPC(n=2, L=L, N=N, batch=B, lift="rbf", centres=cx, output=out, lb=-6.0, ub=6.0, P0=1e5, barQ0=1e5)
-m.offline_fit(X, Y, U, ridge=1e-9, init_rls=True)  # 'storage' semantics of vanderpol_RBF.py:434-438
+m.offline_fit(X, Y, U, ridge=1e-9, init_rls=storage)  # storage semantics of vanderpol_RBF.py:434-438
 lr = m.rbf(np.array([[1.0], [0.0]]))
 lr = lr.cpu().numpy() if hasattr(lr, "cpu") else np.asarray(lr)
 r = np.tile(np.reshape(lr, (L, 1)), (1, N)) if out == "lift" else np.tile(np.array([[1.0], [0.0]]), (1, N))
@@ -27,7 +28,7 @@ t0 = time.time()
 while time.time() - t0 < 1.0:
     m.rollout("vdp", Xd, r, 20)
     torch.cuda.synchronize()
-m.reset(); m.offline_fit(X, Y, U, ridge=1e-9, init_rls=True)
+m.reset(); m.offline_fit(X, Y, U, ridge=1e-9, init_rls=storage)
 Xd.copy_(torch.tensor(initial_states(B), dtype=torch.float64, device="cuda:0"))
 m.rollout("vdp", Xd, r, 20)
 torch.cuda.synchronize()
