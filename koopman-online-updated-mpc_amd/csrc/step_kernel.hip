@@ -310,6 +310,19 @@ __device__ __forceinline__ void sweep_regs(T (&Tm)[(N_ + 7) / 8][(N_ + 7) / 8], 
     for (int c = 0; c < RM; ++c) Tm[r][c] -= ct[r] * rt[c];
 }
 
+// (kr is a constant after unrolling: the switch folds to one call)
+template <typename T, int N_>
+__device__ __forceinline__ void sweep_regs_at(T (&Tm)[(N_ + 7) / 8][(N_ + 7) / 8], int kr, int kt, bool rev, T d, int ti, int tj) {
+  constexpr int RM = (N_ + 7) / 8;
+  switch (kr) {
+    case 0: sweep_regs<T, N_, 0>(Tm, kt, rev, d, ti, tj); break;
+    case 1: if constexpr (RM > 1) sweep_regs<T, N_, 1>(Tm, kt, rev, d, ti, tj); break;
+    case 2: if constexpr (RM > 2) sweep_regs<T, N_, 2>(Tm, kt, rev, d, ti, tj); break;
+    case 3: if constexpr (RM > 3) sweep_regs<T, N_, 3>(Tm, kt, rev, d, ti, tj); break;
+    default: if constexpr (RM > 4) sweep_regs<T, N_, 4>(Tm, kt, rev, d, ti, tj); break;
+  }
+}
+
 template <typename T> __device__ __forceinline__ T wave_max_x(T v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
@@ -448,28 +461,30 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
 
     bool broke = false;
     for (int pass = 0; pass < 2; ++pass) {
-      unsigned long long diff = Smask ^ Fmask;
-      while (diff) {
-        const int kl = __ffsll((long long)diff) - 1;  // owner lane of the variable: (k&7)*8 + (k>>3)
-        diff &= diff - 1ull;
-        const int kt = kl >> 3, kr = kl & 7;
-        const bool rev = (Smask >> kl) & 1ull;
-        T d = T(0);
+      const unsigned long long diff = Smask ^ Fmask;
+      // One straight-line block per variable, in owner-lane order ((k&7)*8 + (k>>3), the order of the bit scan):
+      // with k a compile-time constant the block index, the pivot lane and the owner tests fold, and the tableau
+      // stays in the same registers from block to block (a run-time switch over the block index cost ~20 register
+      // moves per sweep).  Blocks of variables that do not change sides are skipped by a uniform branch.
 #pragma unroll
-        for (int r = 0; r < RM; ++r) if (kr == r) d = lane_bcast(Tm[r][r], kt * 9);
-        if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
-          broke = true;
-          if (pass == 1) Fmask &= ~(1ull << kl);
-          continue;
+      for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+        for (int kr = 0; kr < RM; ++kr) {
+          if (kt + 8 * kr < N_) {
+            const int kl = kt * 8 + kr;
+            if ((diff >> kl) & 1ull) {
+              const bool rev = (Smask >> kl) & 1ull;
+              const T d = lane_bcast(Tm[kr][kr], kt * 9);
+              if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
+                broke = true;
+                if (pass == 1) Fmask &= ~(1ull << kl);
+              } else {
+                sweep_regs_at<T, N_>(Tm, kr, kt, rev, d, ti, tj);
+                Smask ^= (1ull << kl);
+              }
+            }
+          }
         }
-        switch (kr) {
-          case 0: sweep_regs<T, N_, 0>(Tm, kt, rev, d, ti, tj); break;
-          case 1: if constexpr (RM > 1) sweep_regs<T, N_, 1>(Tm, kt, rev, d, ti, tj); break;
-          case 2: if constexpr (RM > 2) sweep_regs<T, N_, 2>(Tm, kt, rev, d, ti, tj); break;
-          case 3: if constexpr (RM > 3) sweep_regs<T, N_, 3>(Tm, kt, rev, d, ti, tj); break;
-          default: if constexpr (RM > 4) sweep_regs<T, N_, 4>(Tm, kt, rev, d, ti, tj); break;
-        }
-        Smask ^= (1ull << kl);
       }
       if (!broke || pass == 1) break;
       ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
@@ -1381,7 +1396,7 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // used when the batch would otherwise leave CUs without a workgroup).
 constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
 constexpr int ro_scratch() { return 2 * RO_ACT; }     // overlays the per-wave regions between two steps
-constexpr int RO_KB2 = 16;                            // A-fragments are fetched and multiplied in batches of 16 k-steps
+constexpr int RO_KB2 = 8;                             // A-fragments are fetched and multiplied in batches of 8 k-steps
 static int ro_keep(int Lp) { return Lp * 16 + 64; }  // not overlaid: psi (Lp x 16), x_{k+1} of the trajectories (16 x 4)
 
 // A-fragments of tile `tile`, k-steps ks0 .. ks0+15 (zero beyond KS)
@@ -1459,7 +1474,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
       // waves only take part in the first layer (VALU) and in the barriers.
       const int Hp = R.Hp, KS = R.KS, MTH = Hp >> 4, MTO = R.Lp >> 4;
       const bool hid = wv < MTH, out = wv < MTO;
-      double af[RO_KB2];  // A-fragments of the first 16 k-steps of the coming layer (requested a layer ahead)
+      double af[RO_KB2];  // A-fragments of the first k-steps of the coming layer (requested a layer ahead)
       if (R.nhh > 0) { if (hid) ro_load_afrags(R.Whp[0], KS, wv, 0, lane, af); }
       else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af);
       // first-layer rows of this thread's outputs (W1 is zero-padded to 4 columns)
@@ -1500,7 +1515,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
         if (mine) {
 #pragma unroll
-          for (int bt = 0; bt < 2; ++bt) {  // KS <= 32 k-steps in two batches of 16
+          for (int bt = 0; bt < 32 / RO_KB2; ++bt) {  // KS <= 32 k-steps in batches
             const int kb = bt * RO_KB2;
             if (bt > 0 && kb < KS) ro_load_afrags(Wp, KS, wv, kb, lane, af);
 #pragma unroll
