@@ -1068,16 +1068,23 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         // broadcast LDS reads of the version below kept the LDS pipe of the CU busy for the whole recursion.
         double v0, v1;
         half_gather(isA ? (double)(half ? sW[t] : sV[t]) : 0.0, v0, v1);
-        for (int j = 0; j <= N; ++j) {
+        double* const ocol = half ? sEr - q + (t - L) : sG + (t - L);  // output column of an isC lane
+#pragma unroll
+        for (int j = 0; j <= N_; ++j) {  // (unrolled: the step-dependent store conditions and LDS offsets fold)
           double ac4[4] = {0.0, 0.0, 0.0, 0.0};
           chain_dot<L_>(ac4, v0, v1, row);
           const double acc = ((ac4[0] + ac4[1]) + (ac4[2] + ac4[3])) + (isA ? bs : 0.0);
-          if (half == 0) {
-            if (isA && !cx && j + 1 < N) sG[(j + 1) * q + t] = acc;  // g_{j+1} = v_{j+1}
-            if (isC && j < N) sG[j * q + (t - L)] = acc;             // g_j = Co v_j
+          if (cx) {
+            // g_j = Co v_j (half 0, j < N) and e_j = Co w_j - r_{j-1} (half 1, j >= 1; sEr holds -r) in ONE masked
+            // region: both are "element j of this lane's output column"
+            if (isC && (half ? j >= 1 : j < N_)) {
+              const double old = ocol[j * q];
+              ocol[j * q] = half ? acc + old : acc;
+            }
+          } else if (half == 0) {
+            if (isA && j + 1 < N) sG[(j + 1) * q + t] = acc;  // g_{j+1} = v_{j+1}
           } else {
-            if (isA && !cx && j < N) sEr[j * q + t] += acc;          // e_{j+1} = w_{j+1} - r_j
-            if (isC && j >= 1) sEr[(j - 1) * q + (t - L)] += acc;    // e_j = Co w_j - r_{j-1}
+            if (isA && j < N) sEr[j * q + t] += acc;          // e_{j+1} = w_{j+1} - r_j
           }
           half_gather(acc, v0, v1);  // v_{j+1} / w_{j+1} (lanes >= L are never read back)
         }
