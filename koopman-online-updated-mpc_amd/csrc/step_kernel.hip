@@ -100,7 +100,7 @@ template <int TPB, int COUNT, typename F> __device__ __forceinline__ void for_st
 #pragma unroll
     for (int i = 0; i < IT; ++i) {
       const int e = tid + i * TPB;
-      if (e < COUNT) f(e, i);
+      if ((i + 1) * TPB <= COUNT || e < COUNT) f(e, i);  // only the last round needs the lane test (tid < TPB)
     }
   } else {
     int i = 0;
