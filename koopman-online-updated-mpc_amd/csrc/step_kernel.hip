@@ -1238,17 +1238,20 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       const bool on = idx < N_;
       const bool vec = ((Q_ & 1) == 0) && ((((int)(sG - sm)) & 1) == 0) && ((((int)(sEr - sm)) & 1) == 0);
       T acc = T(0);
+      // H lanes store H(aa, bb) and H(bb, aa) with bb = N-1-t, aa = bb - idx: element offsets bb (N+1) - idx N and
+      // bb (N+1) - idx; the f lanes take part in the same stores with a scratch slot as target (no second mask)
+      T* const h1 = hf ? red + 14 : sH - idx * N_;
+      T* const h2 = hf ? red + 15 : sH - idx;
+      const int hstep = hf ? 0 : N_ + 1;
+      const T rdiag = (idx == 0 && !hf) ? a.Rw : T(0);
       auto pass = [&](auto dotq) {
 #pragma unroll
         for (int t = 0; t < N_; ++t) {
           if (on && t + idx < N_) {
             acc += dotq(sG + t * Q_, wb + t * Q_);
-            if (!hf) {
-              const int bb = N_ - 1 - t, aa = bb - idx;
-              const T hv = a.Qw * acc + (idx == 0 ? a.Rw : T(0));
-              sH[aa * N_ + bb] = hv;
-              sH[bb * N_ + aa] = hv;
-            }
+            const T hv = a.Qw * acc + rdiag;
+            h1[(N_ - 1 - t) * hstep] = hv;
+            h2[(N_ - 1 - t) * hstep] = hv;
           }
         }
       };
