@@ -381,21 +381,20 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
 #pragma unroll
     for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
   const T fi = own ? sf[myvar] : T(0);
-  // row sums of H and |H| for the owner's variable: partial over my columns, 8-lane all-reduce,
+  // row sums of |H| for the owner's variable: partial over my columns, 8-lane all-reduce,
   // the owner of variable ti + 8*tj picks block row r = tj
-  T rs = T(0), ra = T(0);
+  T ra = T(0);
   {
-    T ps[RM], pa[RM];
+    T pa[RM];
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
-      T s0 = T(0), s1 = T(0);
+      T s1 = T(0);
 #pragma unroll
-      for (int c = 0; c < RM; ++c) { const T h = Hel(r, c); s0 += h; s1 += tabs(h); }
-      ps[r] = allreduce8(s0);
+      for (int c = 0; c < RM; ++c) s1 += tabs(Hel(r, c));
       pa[r] = allreduce8(s1);
     }
 #pragma unroll
-    for (int r = 0; r < RM; ++r) if (tj == r) { rs = ps[r]; ra = pa[r]; }
+    for (int r = 0; r < RM; ++r) if (tj == r) ra = pa[r];
   }
   const T gs = tabs(fi) + T(2) * ra * xmaxb;
   // start: the previous minimiser when the handle keeps one, else clip(0) -- the reference's start (its
@@ -417,7 +416,6 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     }
     if (!own) hx = T(0);
   }
-  (void)rs;
   T p0 = own ? x * (hx + fi) : T(0);
   T J0 = wave_sum(p0);
   const unsigned long long ownmask = __ballot(own);
