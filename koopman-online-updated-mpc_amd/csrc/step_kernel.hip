@@ -1416,7 +1416,10 @@ __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int til
   }
 }
 
-template <int L_, int N_, int Q_, int NW>
+// KS_ > 0: k-steps of the encoder's hidden width fixed at compile time (25 = the reference's 100 hidden units): the
+// fragment loads and the MFMAs become straight-line code (with a run-time count every one of them sat behind its own
+// uniform branch and waited for its own LDS read); 0: run-time width.
+template <int L_, int N_, int Q_, int NW, int KS_>
 __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double> ra) {
   constexpr int EPT = (128 * 16 + 64 * NW - 1) / (64 * NW);  // first-layer outputs per thread (Hp <= 128)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -1480,7 +1483,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
       // accumulator chains), so bias + ReLU are applied on the accumulator registers and the result is written
       // straight into the next layer's B-fragment layout: one barrier per layer, no partial sums.  The other
       // waves only take part in the first layer (VALU) and in the barriers.
-      const int Hp = R.Hp, KS = R.KS, MTH = Hp >> 4, MTO = R.Lp >> 4;
+      const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
       const bool hid = wv < MTH, out = wv < MTO;
       double af[RO_KB2];  // A-fragments of the first k-steps of the coming layer (requested a layer ahead)
       if (R.nhh > 0) { if (hid) ro_load_afrags(R.Whp[0], KS, wv, 0, lane, af); }
@@ -1626,17 +1629,17 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
   return 0;
 }
-template <int L_, int N_, int Q_, int NW>
+template <int L_, int N_, int Q_, int NW, int KS_>
 static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, size_t lds, hipStream_t s) {
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW, KS_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
   const int grid = (k.s.B + waves - 1) / waves;
-  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW>), dim3(grid), dim3(64 * waves), lds, s, k);
+  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_>), dim3(grid), dim3(64 * waves), lds, s, k);
   return hipGetLastError();
 }
 template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
@@ -1650,8 +1653,9 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   const size_t lds = elems * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
-  if (!rbf && waves == 8) return launch_rollout_nw<L_, N_, Q_, 8>(k, waves, lds, s);
-  return launch_rollout_nw<L_, N_, Q_, 16>(k, waves, lds, s);
+  const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
+  if (!rbf && waves == 8) return ks25 ? launch_rollout_nw<L_, N_, Q_, 8, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 8, 0>(k, waves, lds, s);
+  return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0>(k, waves, lds, s);
 }
 
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
