@@ -743,6 +743,8 @@ def test_step_matches_separate_ops_bitwise(torch_mod, KM):
     ("rbf", 8, 30, "lift", 40, 8),    # RBF lift inside the roll-out kernel (cfg3 dimensions)
     ("mlp", 32, 40, "Cx", 20, 5),     # no fused instantiation: per-step launches
     ("tank", 10, 20, "Cx", 24, 8),    # Tank_System.m: delta-u form, one output row, two hidden layers, tank plant
+    ("mlp64", 20, 20, "Cx", 18, 6),   # 64 hidden units: the run-time-width variant of the in-kernel encoder
+    ("mlp128", 8, 10, "Cx", 9, 6),    # 128 hidden units (H_p = 128, eight M tiles)
     ("mlp", 20, 20, "Cx", 4096, 3),   # the bench's batch: 16 trajectories per workgroup (smaller batches use 8)
 ])
 def test_rollout_equals_step_plus_plant_loop(torch_mod, KM, lift, L, N, output, B, steps):
@@ -758,6 +760,9 @@ def test_rollout_equals_step_plus_plant_loop(torch_mod, KM, lift, L, N, output, 
     plant = "duffing"
     if lift == "mlp":
         kw = dict(weights=random_mlp_weights(2, 100, 3, L, seed=3))
+    elif lift in ("mlp64", "mlp128"):
+        hid = int(lift[3:])
+        kw = dict(weights=random_mlp_weights(2, hid, 3, L, seed=3), hidden=hid)
     elif lift == "tank":
         plant = "tank"
         kw = dict(weights=ko.load_mlp_weights(_load("weights_tank.npz")), layers=2, lb=-0.5, ub=0.5, umin=-8.0, umax=8.0,
