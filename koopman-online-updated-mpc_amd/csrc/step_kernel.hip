@@ -841,6 +841,9 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
 template <typename T, int TPB, int L_, int N_, int Q_>
 __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>& sv, const int b, T* const sm) {
   const int tid = local_tid<TPB>();
+  // y = C x has q = rows of C <= n < L outputs, y = psi has q = L: with static dimensions the output kind is known
+  // at compile time and the other variant's code disappears (Q_ == L_ only in the lifted-output instantiations)
+  const bool out_cx = (Q_ > 0 && L_ > 0) ? (Q_ != L_) : (a.out_kind == OUT_CX);
   const int n = a.n, L = L_ ? L_ : a.L, p = L + 1, q = Q_ ? Q_ : a.q, N = N_ ? N_ : a.N, B = a.B;
 
   T* const sX = sm;            // P / bar_Q / H
@@ -883,7 +886,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     constexpr bool PREFETCH = (L_ > 0) && (QPRE <= 16);
     T qpre[PREFETCH ? QPRE : 1], cpre[PREFETCH ? 2 : 1];
     if constexpr (PREFETCH) {
-      if (a.out_kind == OUT_CX) {
+      if (out_cx) {
         const T* Qg0 = a.Qb + (size_t)b * a.strideQ;
         const T* Cg0 = a.C + (size_t)b * a.strideC;
 #pragma unroll
@@ -961,7 +964,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     });
 
     KTRACE(3);
-    if (a.out_kind == OUT_CX) {
+    if (out_cx) {
       // ---- C = bar_X bar_Q, target x_{k+1}, regressor psi(x_k)      duffing.py:943-953
       const T* Qg = a.Qb + (size_t)b * a.strideQ;
       T* Cg = a.C + (size_t)b * a.strideC;
@@ -1021,7 +1024,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   } else if (sv.phases & PH_CONDENSE) {
     const T* Kg = a.K + (size_t)b * a.strideK;
     for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
-    if (a.out_kind == OUT_CX) {
+    if (out_cx) {
       const T* Cg = a.C + (size_t)b * a.strideC;
       for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
     }
@@ -1034,7 +1037,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   // =====================================================================================
   if (sv.phases & PH_CONDENSE) {
     const T* ref = a.ref + (a.ref_per_traj ? (size_t)b * q * N : 0);
-    const bool cx = (a.out_kind == OUT_CX);
+    const bool cx = out_cx;
     for (int i = tid; i < L; i += TPB) {
       sV[i] = sK[i * p + L];  // v_0 = B
       sW[i] = sy[i];          // w_0 = psi(x_k)
@@ -1701,6 +1704,8 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
 template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
   if (threads == 256) return launch_impl<T, 256, 0, 0, 0>(a, s);
+  // (the static instantiations take the output kind from q: y = C x has q <= n <= 4 < 8 <= L rows, y = psi has q = L)
+  if ((a.q == a.L) != (a.out_kind == OUT_LIFT)) return launch_impl<T, 64, 0, 0, 0>(a, s);
   // compile-time specialisations: BASELINE cfg1/cfg2 (L=20, N=20, y = Cx) and the reference's own
   // dimensions (L=8, N=10; y = Cx duffing.py, y = lifted state vanderpol.py)
   if (a.L == 20 && a.N == 20 && a.q == 2) return launch_impl<T, 64, 20, 20, 2>(a, s);
