@@ -1408,7 +1408,9 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
 constexpr int ro_scratch() { return 2 * RO_ACT; }     // overlays the per-wave regions between two steps
 constexpr int RO_KB2 = 8;                             // A-fragments are fetched and multiplied in batches of 8 k-steps
-static int ro_keep(int Lp) { return Lp * 16 + 64; }  // not overlaid: psi (Lp x 16), x_{k+1} of the trajectories (16 x 4)
+// not overlaid: psi (Lp x columns), x_{k+1} of the trajectories (columns x 4); 16 MFMA columns for 8 / 16 waves, 4 for 4
+static int ro_cols(int waves) { return waves == 4 ? 4 : 16; }
+static int ro_keep(int Lp, int waves) { return Lp * ro_cols(waves) + 4 * ro_cols(waves); }
 
 // A-fragments of tile `tile`, k-steps ks0 .. ks0+15 (zero beyond KS)
 __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int tile, int ks0, int lane, double (&af)[RO_KB2]) {
@@ -1419,14 +1421,17 @@ __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int til
   }
 }
 
+// KS_ < 0: RBF lift (no cooperation between the waves; the MLP code and its registers are not in that kernel, and the
+// log / sqrt constants of the RBF not in the MLP kernels).
 // KS_ > 0: k-steps of the encoder's hidden width fixed at compile time (25 = the reference's 100 hidden units): the
 // fragment loads and the MFMAs become straight-line code (with a run-time count every one of them sat behind its own
 // uniform branch and waited for its own LDS read); 0: run-time width.
 template <int L_, int N_, int Q_, int NW, int KS_>
 __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double> ra) {
-  constexpr int EPT = (128 * 16 + 64 * NW - 1) / (64 * NW);  // first-layer outputs per thread (Hp <= 128)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* const smem = reinterpret_cast<double*>(smem_raw);
+  constexpr int NC = NW == 4 ? 4 : 16;  // trajectory columns of the cooperative encoder
+  constexpr bool RBF = KS_ < 0;         // the lift kind is a compile-time property (KS_ = -1: thin-plate RBF, per wave)
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave-uniform: trajectory index and LDS base stay scalar
   const int B = ra.s.B, n = ra.s.n, L = L_;
@@ -1436,10 +1441,10 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
   double* const sAct0 = smem;
   double* const sAct1 = sAct0 + RO_ACT;
   double* const sPsi = smem + ra.keep_off;  // behind the per-wave regions: survives into the step
-  double* const sXn = sPsi + ra.Lp * 16;
-  if (!ra.lift_rbf && tid0 < 64) sXn[tid0] = 0.0;  // (columns of trajectories this workgroup does not have)
+  double* const sXn = sPsi + ra.Lp * NC;
+  if (!RBF && tid0 < 4 * NC) sXn[tid0] = 0.0;  // (columns of trajectories this workgroup does not have)
   __syncthreads();
-  if (!ra.lift_rbf && (tid0 & 63) < 4)
+  if (!RBF && (tid0 & 63) < 4)
     sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? ra.s.X_rw[(size_t)(tid0 & 63) * B + b] : 0.0;
 
   bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
@@ -1462,7 +1467,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
     if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 16] = wall_clock64();  // this wave is ready for step k
 #endif
     double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
-    if (R.lift_rbf) {
+    if constexpr (RBF) {
       if (live && lane < L) {
         double x[4];
 #pragma unroll
@@ -1481,36 +1486,112 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
           psi_i = d * d * log(d + R.eps);
         }
       }
+    } else if constexpr (NW == 4) {
+      // Four trajectories per workgroup (four workgroups per CU, which drift apart: a SIMD then holds waves in
+      // different phases of the step, and a barrier only makes four trajectories wait for each other).  Encoder on
+      // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction = 16 output rows x 4 trajectories x
+      // 4 k.  Operand lanes (probed, tools/ubench/mfma_f64_4x4.hip): A lane 16k + 4blk + i, B lane 16k + 4blk + j,
+      // D lane 16i + 4blk + j -- so the A-fragments are the SAME packed tiles the 16x16x4 path reads (lane = 16k + row
+      // in tile), B is the activation (k, j) replicated over the blocks (broadcast LDS read), and a tile's output comes
+      // back as row 4blk + i, column j.  On gfx950 this shape runs at the same flop rate as the 16x16x4 one, so the
+      // lift costs the same f64 pipe time per trajectory as with 16 columns.  Wave w owns hidden tiles w and w + 4
+      // (two tiles x two k-parities = four independent accumulator chains), the output tiles go to the waves from
+      // the top (wave 3 has one hidden tile when Hp = 112).
+      const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
+      const int boff = (lane >> 4) * 4 + (lane & 3);          // B operand: element (k, j) of a k-step
+      const int drow = ((lane >> 2) & 3) * 4 + (lane >> 4);   // D: row within the tile
+      const int dcol = lane & 3;
+      const int th0 = wv, th1 = wv + 4;                       // hidden tiles of this wave
+      const bool vh0 = th0 < MTH, vh1 = th1 < MTH;
+      const int to0 = 3 - wv;                                 // output tile of this wave
+      const bool vo0 = to0 < MTO;
+      double af[2][RO_KB2];  // double-buffered batches of A-fragments (one tile at a time: registers are scarce here)
+      // first layer: one k-step (K = n <= 4, W1 zero-padded to 4 columns), bias as the accumulator input
+      double a1[2] = {0.0, 0.0}, c1[2] = {0.0, 0.0};
+      if (vh0) { a1[0] = R.W1[4 * (16 * th0 + (lane & 15)) + (lane >> 4)]; c1[0] = R.b1[16 * th0 + drow]; }
+      if (vh1) { a1[1] = R.W1[4 * (16 * th1 + (lane & 15)) + (lane >> 4)]; c1[1] = R.b1[16 * th1 + drow]; }
+      if (R.nhh > 0) { if (vh0) ro_load_afrags(R.Whp[0], KS, th0, 0, lane, af[0]); }
+      else if (vo0) ro_load_afrags(R.Wop, KS, to0, 0, lane, af[0]);
+      __syncthreads();  // every wave is done with its LDS region (previous step); x_k of the four trajectories is in sXn
+      {
+        const double xb = sXn[(lane & 3) * 4 + (lane >> 4)];
+        if (vh0) {
+          const double v = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[0], xb, c1[0], 0, 0, 0);
+          sAct0[(16 * th0 + drow) * 4 + dcol] = v > 0.0 ? v : 0.0;
+        }
+        if (vh1) {
+          const double v = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[1], xb, c1[1], 0, 0, 0);
+          sAct0[(16 * th1 + drow) * 4 + dcol] = v > 0.0 ? v : 0.0;
+        }
+      }
+      __syncthreads();
+      for (int h = 0; h <= R.nhh; ++h) {
+        const bool last = h == R.nhh;
+        const int t0 = last ? to0 : th0, t1 = th1;
+        const bool v0 = last ? vo0 : vh0, v1 = last ? false : vh1;
+        const double* act = (h & 1) ? sAct1 : sAct0;
+        double* actn = (h & 1) ? sAct0 : sAct1;
+        const double* Wp = last ? R.Wop : R.Whp[h & 1];
+        const double* bias = last ? R.bo : R.bh[h & 1];
+        double acc[2][2] = {{v0 ? bias[16 * t0 + drow] : 0.0, 0.0}, {v1 ? bias[16 * t1 + drow] : 0.0, 0.0}};
+        constexpr int NB = 32 / RO_KB2;  // batches per tile (KS <= 32 k-steps)
+#pragma unroll
+        for (int g = 0; g < 2 * NB; ++g) {  // batch g: tile g / NB, k-steps (g % NB) * 8 ..; batch g + 1 is requested first
+          const int tl = g / NB, kb = (g % NB) * RO_KB2;
+          if (g + 1 < 2 * NB) {
+            const int tl2 = (g + 1) / NB, kb2 = ((g + 1) % NB) * RO_KB2;
+            if ((tl2 ? v1 : v0) && kb2 < KS) ro_load_afrags(Wp, KS, tl2 ? t1 : t0, kb2, lane, af[(g + 1) & 1]);
+          }
+          if ((tl ? v1 : v0) && kb < KS) {
+#pragma unroll
+            for (int i = 0; i < RO_KB2; ++i)
+              if (kb + i < KS)
+                acc[tl][i & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g & 1][i], act[(kb + i) * 16 + boff], acc[tl][i & 1], 0, 0, 0);
+          }
+        }
+        if (v0) {
+          const double v = acc[0][0] + acc[0][1];
+          if (last) sPsi[(16 * t0 + drow) * 4 + dcol] = v;
+          else actn[(16 * t0 + drow) * 4 + dcol] = v > 0.0 ? v : 0.0;
+        }
+        if (v1) {
+          const double v = acc[1][0] + acc[1][1];
+          actn[(16 * t1 + drow) * 4 + dcol] = v > 0.0 ? v : 0.0;
+        }
+        // the next layer's first fragments travel across the barrier
+        if (!last) {
+          if (h + 1 < R.nhh) { if (vh0) ro_load_afrags(R.Whp[h + 1], KS, th0, 0, lane, af[0]); }
+          else if (vo0) ro_load_afrags(R.Wop, KS, to0, 0, lane, af[0]);
+        }
+        __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
+      }
+      if (lane < L) psi_i = sPsi[lane * 4 + wv];
     } else {
       // Cooperative encoder.  Wave w < Hp/16 owns hidden M tile w for the whole K range (two alternating
       // accumulator chains), so bias + ReLU are applied on the accumulator registers and the result is written
       // straight into the next layer's B-fragment layout: one barrier per layer, no partial sums.  The other
-      // waves only take part in the first layer (VALU) and in the barriers.
+      // waves only take part in the barriers.
       const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
       const bool hid = wv < MTH, out = wv < MTO;
       double af[RO_KB2];  // A-fragments of the first k-steps of the coming layer (requested a layer ahead)
       if (R.nhh > 0) { if (hid) ro_load_afrags(R.Whp[0], KS, wv, 0, lane, af); }
       else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af);
-      // first-layer rows of this thread's outputs (W1 is zero-padded to 4 columns)
-      double w1r[EPT][4], b1r[EPT];
+      // ---- layer 1 (K = n <= 4: one k-step, W1 zero-padded to 4 columns): one MFMA per hidden tile, bias as the
+      //      accumulator input, straight into B-fragment layout.  Operands are requested before the barrier.
+      double a1 = 0.0;
+      d4_t c1 = {0.0, 0.0, 0.0, 0.0};
+      if (hid) {
+        a1 = R.W1[4 * (16 * wv + (lane & 15)) + (lane >> 4)];
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) {
-        const int e = tid + j * 64 * NW;
-        const int row = e < Hp * 16 ? (e >> 4) : 0;
-        b1r[j] = R.b1[row];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) w1r[j][i] = R.W1[4 * row + i];
+        for (int r = 0; r < 4; ++r) c1[r] = R.b1[16 * wv + (lane >> 4) + 4 * r];
       }
       __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all trajectories is in sXn
-      // ---- layer 1 (K = n <= 4) on the VALU, straight into B-fragment layout
+      if (hid) {
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sXn[4 * (lane & 15) + (lane >> 4)], c1, 0, 0, 0);
 #pragma unroll
-      for (int j = 0; j < EPT; ++j) {
-        const int e = tid + j * 64 * NW;
-        if (e < Hp * 16) {
-          const int row = e >> 4, col = e & 15;
-          const double* xc = sXn + 4 * col;
-          const double v = b1r[j] + ((w1r[j][0] * xc[0] + w1r[j][1] * xc[1]) + (w1r[j][2] * xc[2] + w1r[j][3] * xc[3]));
-          sAct0[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * wv + (lane >> 4) + 4 * r;
+          sAct0[(row >> 2) * 64 + ((row & 3) << 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
         }
       }
       __syncthreads();
@@ -1520,13 +1601,14 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
         const bool mine = last ? out : hid;
         const double* act = (h & 1) ? sAct1 : sAct0;
         double* actn = (h & 1) ? sAct0 : sAct1;
-        const double* Wp = last ? R.Wop : R.Whp[h];
-        const double* bias = last ? R.bo : R.bh[h];
+        const double* Wp = last ? R.Wop : R.Whp[h & 1];
+        const double* bias = last ? R.bo : R.bh[h & 1];
         // accumulator register r of lane l holds row (l >> 4) + 4 r, column l & 15 of the tile
-        double bpre[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) bpre[r] = mine ? bias[16 * wv + (lane >> 4) + 4 * r] : 0.0;
         d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        if (mine) {  // the bias is the accumulator input of the first chain
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc0[r] = bias[16 * wv + (lane >> 4) + 4 * r];
+        }
         if (mine) {
 #pragma unroll
           for (int bt = 0; bt < 32 / RO_KB2; ++bt) {  // KS <= 32 k-steps in batches
@@ -1539,11 +1621,13 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
                 acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
             }
           }
+        }
+        if (mine) {
           const int col = lane & 15;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * wv + (lane >> 4) + 4 * r;
-            const double v = (acc0[r] + acc1[r]) + bpre[r];
+            const double v = acc0[r] + acc1[r];
             if (last) sPsi[row * 16 + col] = v;
             else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
           }
@@ -1576,7 +1660,7 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
       sv.first_update = fresh ? 1 : 0;
       sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
       sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
-      sv.x_next = R.lift_rbf ? nullptr : sXn + wv * 4;
+      sv.x_next = RBF ? nullptr : sXn + wv * 4;
       step_body<double, 64, L_, N_, Q_>(a, sv, bk, wsm);
       if (R.X_log) {
         __threadfence_block();
@@ -1584,13 +1668,20 @@ __global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double>
       }
     }
 #ifdef KMPC_TRACE
-    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 18] = wall_clock64();  // step k done
+    if (lane == 0 && b < 8192) {
+      const unsigned long long t18 = wall_clock64();
+      kmpc_trace_buf[b * 32 + 18] = t18;  // step k done
+      // whole-launch sums: barrier wait + lift, step body (k == 0 resets)
+      const unsigned long long dl = kmpc_trace_buf[b * 32 + 17] - kmpc_trace_buf[b * 32 + 16], db = t18 - kmpc_trace_buf[b * 32 + 17];
+      kmpc_trace_buf[b * 32 + 20] = (k == 0 ? 0ull : kmpc_trace_buf[b * 32 + 20]) + dl;
+      kmpc_trace_buf[b * 32 + 21] = (k == 0 ? 0ull : kmpc_trace_buf[b * 32 + 21]) + db;
+    }
 #endif
     if (have_prev) fresh = false;
     have_prev = true;
     cur ^= 1;
   }
-  if (!ra.lift_rbf && live && (tid0 & 63) == 0) {  // (the host zeroed status / iters before the launch)
+  if (!RBF && live && (tid0 & 63) == 0) {  // (the host zeroed status / iters before the launch)
     const int* const acc = reinterpret_cast<const int*>(sXn + wave * 4 + 2);
     if (ra.s.status) ra.s.status[b] = acc[0];
     if (ra.s.iters) ra.s.iters[b] = acc[1];
@@ -1605,16 +1696,19 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
   if (wstride) *wstride = (int)per_wave;
   size_t elems = per_wave * waves;
   if (rbf) return elems;
-  const size_t scratch = ro_scratch();
+  const size_t scratch = waves == 4 ? RO_ACT + 128 * 4 : ro_scratch();  // (sAct1 sits RO_ACT behind sAct0)
   if (elems < scratch) elems = scratch;
-  return elems + ro_keep(Lp);
+  return elems + ro_keep(Lp, waves);
 }
 static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
   const size_t cap = 160 * 1024 / sizeof(double);
   if (!rbf) {
-    static const char* env = getenv("KMPC_ROLLOUT_WAVES");  // measurement aid: force 8 or 16
+    static const char* env = getenv("KMPC_ROLLOUT_WAVES");  // measurement aid: force 4, 8 or 16
     const bool fit16 = rollout_lds_elems(n, L, q, N, false, 16, Lp, nullptr) <= cap;
     const bool fit8x2 = 2 * rollout_lds_elems(n, L, q, N, false, 8, Lp, nullptr) + 128 <= cap;
+    // four workgroups of four trajectories per CU (LDS is handed out in 512-byte granules)
+    const bool fit4x4 = 4 * ((rollout_lds_elems(n, L, q, N, false, 4, Lp, nullptr) + 63) & ~(size_t)63) <= cap;
+    if (env && atoi(env) == 4) return rollout_lds_elems(n, L, q, N, false, 4, Lp, nullptr) <= cap ? 4 : 0;
     if (env && atoi(env) == 8) return rollout_lds_elems(n, L, q, N, false, 8, Lp, nullptr) <= cap ? 8 : 0;
     if (env && atoi(env) == 16) return fit16 ? 16 : 0;
     // batches that leave CUs without a 16-trajectory workgroup are spread as 8-trajectory ones (measured:
@@ -1624,6 +1718,7 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
+    (void)fit4x4;
     if (fit8x2 && (B + 15) / 16 < cus) return 8;
     if (fit16) return 16;
     return fit8x2 ? 8 : 0;
@@ -1652,11 +1747,13 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   if (waves == 0) return hipErrorInvalidValue;
   step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2);
   const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
-  k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp));
+  k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp, waves));
   const size_t lds = elems * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
   const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
+  if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1>(k, waves, lds, s);
+  if (!rbf && waves == 4) return ks25 ? launch_rollout_nw<L_, N_, Q_, 4, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 4, 0>(k, waves, lds, s);
   if (!rbf && waves == 8) return ks25 ? launch_rollout_nw<L_, N_, Q_, 8, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 8, 0>(k, waves, lds, s);
   return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0>(k, waves, lds, s);
 }
@@ -1672,11 +1769,13 @@ template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a
   if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
     return hipErrorInvalidValue;
   if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
+#ifndef KMPC_DEV_CFG2_ONLY  // (development builds compile the cfg2 instantiations only)
   if (a.s.L == 8 && a.s.N == 10 && a.s.q == 2) return launch_rollout_impl<8, 10, 2>(a, s);
   if (a.s.L == 8 && a.s.N == 10 && a.s.q == 8) return launch_rollout_impl<8, 10, 8>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 8) return launch_rollout_impl<8, 30, 8>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);
   if (a.s.L == 10 && a.s.N == 20 && a.s.q == 1) return launch_rollout_impl<10, 20, 1>(a, s);  // Tank_System.m dimensions
+#endif
   return hipErrorInvalidValue;
 }
 template <> hipError_t launch_rollout_fused<float>(const RolloutArgs<float>&, hipStream_t) { return hipErrorInvalidValue; }
@@ -1709,6 +1808,7 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
   // compile-time specialisations: BASELINE cfg1/cfg2 (L=20, N=20, y = Cx) and the reference's own
   // dimensions (L=8, N=10; y = Cx duffing.py, y = lifted state vanderpol.py)
   if (a.L == 20 && a.N == 20 && a.q == 2) return launch_impl<T, 64, 20, 20, 2>(a, s);
+#ifndef KMPC_DEV_CFG2_ONLY
   if (a.L == 8 && a.N == 10 && a.q == 2) return launch_impl<T, 64, 8, 10, 2>(a, s);
   if (a.L == 8 && a.N == 10 && a.q == 8) return launch_impl<T, 64, 8, 10, 8>(a, s);
   // BASELINE cfg3: Van der Pol tracking, 8 RBF / MLP observables, N = 30, y = lifted state
@@ -1718,6 +1818,7 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
   if (a.L == 8 && a.N == 30 && a.q == 8) return launch_impl<T, 64, 8, 30, 8>(a, s);
   if (a.L == 8 && a.N == 30 && a.q == 2) return launch_impl<T, 64, 8, 30, 2>(a, s);
   if (a.L == 20 && a.N == 30 && a.q == 2) return launch_impl<T, 64, 20, 30, 2>(a, s);
+#endif
   return launch_impl<T, 64, 0, 0, 0>(a, s);
 }
 

@@ -13,6 +13,7 @@ from koopmpc.synth import random_mlp_weights, initial_states, offline_data
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 60
 L, N = 20, 20
+G = int(os.environ.get("KMPC_ROLLOUT_WAVES", "16"))  # trajectories per workgroup
 cold = len(sys.argv) > 3 and sys.argv[3] == "cold"
 m = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=random_mlp_weights(2, 100, 3, L), cold_start=cold)
 m.offline_fit(*offline_data())
@@ -44,15 +45,15 @@ fused = bool((t[:, 17] > 0).any())
 if fused:  # roll-out kernel: one launch for all the steps; the per-step stamps are those of the LAST step
     total = (t[:, 18].max() - t[:, 19].min()) / 100.0
     print("fused roll-out: %d steps in %.1f us after the first lift => %.2f us/step" % (steps, total, total / max(1, steps - 1)))
-    wg = (np.arange(nb) // 16)
+    wg = (np.arange(nb) // G)
     lift = (t[:, 17] - t[:, 16]) / 100.0      # wait for the workgroup's slowest wave + cooperative lift
     body = (t[:, 18] - t[:, 17]) / 100.0
-    ready = t[:, 16].reshape(-1, 16)
+    ready = t[:, 16].reshape(-1, G)
     wait = (ready.max(1, keepdims=True) - ready).reshape(-1) / 100.0  # idle time before the lift barrier
-    print("last step: wait for the slowest of 16  median %.2f p90 %.2f max %.2f us" % (np.median(wait), np.percentile(wait, 90), wait.max()))
-    print("           lift (after the last wave arrived) median %.2f us" % np.median(((t[:, 17].reshape(-1, 16).min(1) - ready.max(1)) / 100.0)))
-    print("           step body median %.2f p90 %.2f max %.2f us; slowest-of-16 median %.2f us" % (
-        np.median(body), np.percentile(body, 90), body.max(), np.median(body.reshape(-1, 16).max(1))))
+    print("last step: wait for the slowest of the workgroup  median %.2f p90 %.2f max %.2f us" % (np.median(wait), np.percentile(wait, 90), wait.max()))
+    print("           lift (after the last wave arrived) median %.2f us" % np.median(((t[:, 17].reshape(-1, G).min(1) - ready.max(1)) / 100.0)))
+    print("           step body median %.2f p90 %.2f max %.2f us; slowest-of-workgroup median %.2f us" % (
+        np.median(body), np.percentile(body, 90), body.max(), np.median(body.reshape(-1, G).max(1))))
 k0 = t[:, 0].min()
 print("launch span: %.2f us; wave start spread %.2f us" % ((t[:, 14].max() - k0) / 100.0, (t[:, 0].max() - k0) / 100.0))
 print("%-22s %8s %8s %8s   (us, per wave)" % ("segment", "median", "p90", "max"))
@@ -71,3 +72,17 @@ fin = np.sort((t[:, 14] - k0) / 100.0)
 print("finish-time quantiles (us since first wave start): 50%% %.1f  90%% %.1f  99%% %.1f  99.9%% %.1f  max %.1f" % tuple(
     fin[[int(nb * f) - 1 for f in (0.5, 0.9, 0.99, 0.999, 1.0)]]))
 print("iters: mean %.2f max %d" % (float(m.iters.double().mean()) / (steps + 0.0), int(m.iters.max())))
+if fused:
+    s0 = (t[:, 19] - t[:, 19].min()) / 100.0
+    print("first-step lift-done stamp since the earliest one (us): 50%% %.1f 75%% %.1f 90%% %.1f max %.1f  (late starters = workgroups that were not resident at launch)"
+          % tuple(np.percentile(s0, [50, 75, 90, 100])))
+if fused:
+    sl, sb = t[:, 20] / 100.0 / steps, t[:, 21] / 100.0 / steps
+    print("whole launch, per wave and step: wait+lift mean %.2f (median %.2f) us, body mean %.2f (median %.2f, p90 %.2f) us"
+          % (sl.mean(), np.median(sl), sb.mean(), np.median(sb), np.percentile(sb, 90)))
+    fin = (t[:, 18] - t[:, 19].min()) / 100.0
+    order = np.argsort(fin)
+    for lo, hi in ((0, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)):
+        sel = order[int(lo * nb):int(hi * nb)]
+        print("  waves finishing in quartile %.2f-%.2f: finish %.0f-%.0f us, wait+lift %.2f, body %.2f us/step"
+              % (lo, hi, fin[sel].min(), fin[sel].max(), sl[sel].mean(), sb[sel].mean()))
