@@ -208,6 +208,11 @@ int kmpc_profile_enable(kmpc_handle* h, int on);
 int kmpc_profile_read(kmpc_handle* h, double* ms2, int64_t* count, int reset);
 /* 1 if kmpc_rollout runs as one fused kernel for this handle's configuration, else 0         */
 int kmpc_rollout_is_fused(const kmpc_handle* h);
+/* Trajectories per workgroup of the fused roll-out kernel (MLP lift): 4, 8 or 16; 0 = automatic (most
+ * trajectories per CU, ties to the larger workgroup).  Process-wide tuning / test knob: every
+ * trajectory's arithmetic is the same for every choice, only the scheduling differs.
+ * Returns -1 for any other value.                                                            */
+int kmpc_set_rollout_workgroup(int trajectories);
 /* algorithmic bytes of one trajectory-step (SURVEY.md 8d formula) for this configuration   */
 int64_t kmpc_algorithmic_bytes_per_step(const kmpc_handle* h);
 

@@ -711,6 +711,11 @@ int kmpc_set_centres(kmpc_handle* h, const double* cx, int L, int n) { NN(h); re
 int kmpc_set_model(kmpc_handle* h, const double* A, const double* B, const double* C) { NN(h); return h->set_model(A, B, C); }
 int kmpc_set_terminal_weight(kmpc_handle* h, const double* PN) { NN(h); return h->set_terminal_weight(PN); }
 int kmpc_rollout_is_fused(const kmpc_handle* h) { NN(h); return h->rollout_is_fused(); }
+int kmpc_set_rollout_workgroup(int trajectories) {
+  if (trajectories != 0 && trajectories != 4 && trajectories != 8 && trajectories != 16) return -1;
+  kmpc::set_rollout_workgroup(trajectories);
+  return 0;
+}
 int kmpc_reset(kmpc_handle* h, void* s) { NN(h); return h->reset((hipStream_t)s); }
 int kmpc_lift(kmpc_handle* h, const void* X, void* Psi, int B, void* s) { NN(h); return h->lift(X, Psi, B, (hipStream_t)s); }
 int kmpc_rls_update(kmpc_handle* h, const void* psi, const void* u, const void* psin, const void* xn, int B, void* s) { NN(h); return h->rls_update(psi, u, psin, xn, B, (hipStream_t)s); }

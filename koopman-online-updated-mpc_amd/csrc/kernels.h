@@ -108,6 +108,7 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
 // true if (T, n, L, N, q, threads, lift kind) has a fused roll-out instantiation that fits in LDS
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf);
 template <typename T> hipError_t launch_rollout_fused(const RolloutArgs<T>& a, hipStream_t s);
+void set_rollout_workgroup(int trajectories);  // 0 = automatic, else 4 / 8 / 16 (process-wide)
 template <typename T> hipError_t launch_pack_afrag(const T* src, int Mp, int Hp, int KS, T* dst, hipStream_t s);
 template <typename T> hipError_t launch_lift_mlp(const LiftArgs<T>& a, hipStream_t s);
 template <typename T> hipError_t launch_lift_rbf(const LiftArgs<T>& a, hipStream_t s);

@@ -36,24 +36,24 @@ namespace kmpc {
 // ---------------------------------------------------------------------------------------
 // host-side LDS sizing (shared with the launcher)
 // ---------------------------------------------------------------------------------------
-static inline int imax(int a, int b) { return a > b ? a : b; }
+static constexpr int imax(int a, int b) { return a > b ? a : b; }
 
-static inline int vec_elems(int n, int L, int q, int N) {
+static constexpr int vec_elems(int n, int L, int q, int N) {
   const int p = L + 1;
   const int setA = 2 * p + 6 * L + n + 2 * N * q;  // sz sPz | sy sE sV(2) sW(2) | sx | sG sEr
   const int setB = 3 * N;                          // qx qxa qg
   return imax(setA, setB) + N /*sf*/ + 16 /*reduction scratch*/;
 }
 
+static constexpr int step_region1(int L, int N) { return (imax(imax((L + 1) * (L + 1), L * L), N * N) + 1) & ~1; }
+static constexpr int step_region2(int n, int L, int N) { return (imax(L * (L + 1) + n * L, N * N) + 1) & ~1; }
+static constexpr size_t step_lds_elems(int n, int L, int q, int N) {
+  return (size_t)step_region1(L, N) + step_region2(n, L, N) + vec_elems(n, L, q, N);
+}
 size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2) {
-  const int p = L + 1;
-  int a = imax(imax(p * p, L * L), N * N);
-  int b = imax(L * p + n * L, N * N);
-  a = (a + 1) & ~1;
-  b = (b + 1) & ~1;
-  if (r1) *r1 = a;
-  if (r2) *r2 = b;
-  return (size_t)(a + b + vec_elems(n, L, q, N)) * elem;
+  if (r1) *r1 = step_region1(L, N);
+  if (r2) *r2 = step_region2(n, L, N);
+  return step_lds_elems(n, L, q, N) * elem;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1426,8 +1426,16 @@ __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int til
 // KS_ > 0: k-steps of the encoder's hidden width fixed at compile time (25 = the reference's 100 hidden units): the
 // fragment loads and the MFMAs become straight-line code (with a run-time count every one of them sat behind its own
 // uniform branch and waited for its own LDS read); 0: run-time width.
+// Register budget: the LDS decides how many trajectories (= waves) a CU holds; up to four waves per SIMD get 128
+// VGPRs each (cfg2: 16 trajectories per CU), dimension sets with large per-trajectory regions leave room for more.
+template <int L_, int N_, int Q_, int NW> constexpr int ro_max_threads() {
+  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
+  constexpr size_t wgs = cap / (pw * NW);
+  constexpr size_t waves = wgs * NW > 16 ? 16 : (wgs * NW < (size_t)NW ? (size_t)NW : wgs * NW);
+  return waves > 8 ? 1024 : (waves > 4 ? 512 : 256);  // 4 / 2 / 1 waves per SIMD
+}
 template <int L_, int N_, int Q_, int NW, int KS_>
-__global__ __launch_bounds__(1024) void rollout_kernel(const RolloutArgs<double> ra) {
+__global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_kernel(const RolloutArgs<double> ra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* const smem = reinterpret_cast<double*>(smem_raw);
   constexpr int NC = NW == 4 ? 4 : 16;  // trajectory columns of the cooperative encoder
@@ -1700,28 +1708,35 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
   if (elems < scratch) elems = scratch;
   return elems + ro_keep(Lp, waves);
 }
+static int g_rollout_workgroup = 0;  // kmpc_set_rollout_workgroup
+void set_rollout_workgroup(int trajectories) { g_rollout_workgroup = trajectories; }
 static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
   const size_t cap = 160 * 1024 / sizeof(double);
   if (!rbf) {
     static const char* env = getenv("KMPC_ROLLOUT_WAVES");  // measurement aid: force 4, 8 or 16
-    const bool fit16 = rollout_lds_elems(n, L, q, N, false, 16, Lp, nullptr) <= cap;
-    const bool fit8x2 = 2 * rollout_lds_elems(n, L, q, N, false, 8, Lp, nullptr) + 128 <= cap;
-    // four workgroups of four trajectories per CU (LDS is handed out in 512-byte granules)
-    const bool fit4x4 = 4 * ((rollout_lds_elems(n, L, q, N, false, 4, Lp, nullptr) + 63) & ~(size_t)63) <= cap;
-    if (env && atoi(env) == 4) return rollout_lds_elems(n, L, q, N, false, 4, Lp, nullptr) <= cap ? 4 : 0;
-    if (env && atoi(env) == 8) return rollout_lds_elems(n, L, q, N, false, 8, Lp, nullptr) <= cap ? 8 : 0;
-    if (env && atoi(env) == 16) return fit16 ? 16 : 0;
-    // batches that leave CUs without a 16-trajectory workgroup are spread as 8-trajectory ones (measured:
-    // B = 2048: 43.5 vs 35.7 M steps/s, B = 1024: 22.6 vs 18.4; at B = 4096 sixteen are faster, 72.0 vs 66.9)
+    // workgroups of w trajectories that fit on one CU (LDS is handed out in 512-byte granules; 16 waves per CU)
+    auto wgs = [&](int w) -> int {
+      const size_t e = (rollout_lds_elems(n, L, q, N, false, w, Lp, nullptr) + 63) & ~(size_t)63;
+      const int k = (int)(cap / e);
+      return k * w > 16 ? 16 / w : k;
+    };
+    if (g_rollout_workgroup) return wgs(g_rollout_workgroup) > 0 ? g_rollout_workgroup : 0;
+    if (env && (atoi(env) == 4 || atoi(env) == 8 || atoi(env) == 16)) return wgs(atoi(env)) > 0 ? atoi(env) : 0;
     static int cus = 0;
     if (!cus) {
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
     }
-    (void)fit4x4;
-    if (fit8x2 && (B + 15) / 16 < cus) return 8;
-    if (fit16) return 16;
-    return fit8x2 ? 8 : 0;
+    // Most trajectories per CU wins; ties go to the larger workgroup (cfg2 at B = 4096: 91.3 / 89.0 / 84.5 M steps/s
+    // with 16 / 8 / 4 trajectories per workgroup).  Batches that leave CUs without a 16-trajectory workgroup are
+    // spread as smaller ones (B = 2048: 43.5 vs 35.7 M steps/s with 8, B = 1024: 22.6 vs 18.4).
+    int best = 0, best_traj = 0;
+    for (int w = 16; w >= 4; w >>= 1) {
+      const int t = wgs(w) * w;
+      if (t > best_traj) { best = w; best_traj = t; }
+    }
+    if (best == 16 && wgs(8) * 8 >= 16 && (B + 15) / 16 < cus) return 8;
+    return best;
   }
   for (int w = 16; w >= 4; w >>= 1)
     if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
@@ -1753,15 +1768,22 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
   const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
   if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1>(k, waves, lds, s);
-  if (!rbf && waves == 4) return ks25 ? launch_rollout_nw<L_, N_, Q_, 4, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 4, 0>(k, waves, lds, s);
-  if (!rbf && waves == 8) return ks25 ? launch_rollout_nw<L_, N_, Q_, 8, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 8, 0>(k, waves, lds, s);
-  return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0>(k, waves, lds, s);
+  // (workgroup sizes whose per-wave regions alone exceed the LDS are not instantiated)
+  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
+  if constexpr (4 * pw <= cap)
+    if (waves == 4) return ks25 ? launch_rollout_nw<L_, N_, Q_, 4, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 4, 0>(k, waves, lds, s);
+  if constexpr (8 * pw <= cap)
+    if (waves == 8) return ks25 ? launch_rollout_nw<L_, N_, Q_, 8, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 8, 0>(k, waves, lds, s);
+  if constexpr (16 * pw <= cap)
+    if (waves == 16) return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0>(k, waves, lds, s);
+  return hipErrorInvalidValue;
 }
 
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
   if (sizeof(T) != 8 || threads == 256 || n > 4) return false;
   const bool inst = (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
-                    (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2) || (L == 10 && N == 20 && q == 1);
+                    (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2) || (L == 10 && N == 20 && q == 1) ||
+                    (L == 20 && N == 30 && q == 2) || (L == 32 && N == 40 && q == 2) || (L == 32 && N == 40 && q == 1);
   return inst && rollout_waves(n, L, q, N, rbf, 64) > 0;  // (Lp <= 64)
 }
 template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
@@ -1775,6 +1797,9 @@ template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 8) return launch_rollout_impl<8, 30, 8>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);
   if (a.s.L == 10 && a.s.N == 20 && a.s.q == 1) return launch_rollout_impl<10, 20, 1>(a, s);  // Tank_System.m dimensions
+  if (a.s.L == 20 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<20, 30, 2>(a, s);  // BASELINE cfg3 sizes, y = Cx
+  if (a.s.L == 32 && a.s.N == 40 && a.s.q == 2) return launch_rollout_impl<32, 40, 2>(a, s);  // BASELINE cfg4 sizes
+  if (a.s.L == 32 && a.s.N == 40 && a.s.q == 1) return launch_rollout_impl<32, 40, 1>(a, s);
 #endif
   return hipErrorInvalidValue;
 }

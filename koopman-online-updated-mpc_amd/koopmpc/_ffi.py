@@ -44,6 +44,7 @@ SIGNATURES = {
     "kmpc_set_model": (_I, [_VP, _DP, _DP, _DP]),
     "kmpc_set_terminal_weight": (_I, [_VP, _DP]),
     "kmpc_rollout_is_fused": (_I, [_VP]),
+    "kmpc_set_rollout_workgroup": (_I, [_I]),
     "kmpc_reset": (_I, [_VP, _VP]),
     "kmpc_lift": (_I, [_VP, _VP, _VP, _I, _VP]),
     "kmpc_rls_update": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),

@@ -741,7 +741,9 @@ def test_step_matches_separate_ops_bitwise(torch_mod, KM):
     ("mlp", 20, 20, "Cx", 16, 1),     # a single step: the RLS flags must come out like kmpc_step's
     ("mlp", 8, 10, "Cx", 33, 12),     # the reference's own dimensions
     ("rbf", 8, 30, "lift", 40, 8),    # RBF lift inside the roll-out kernel (cfg3 dimensions)
-    ("mlp", 32, 40, "Cx", 20, 5),     # no fused instantiation: per-step launches
+    ("mlp", 32, 40, "Cx", 20, 5),     # cfg4 sizes: 29 KB of LDS per trajectory, four trajectories per workgroup
+    ("mlp", 8, 30, "Cx", 24, 6),      # cfg3 sizes with the MLP lift: 19 KB of LDS per trajectory, 8 per CU
+    ("mlp", 20, 30, "Cx", 21, 6),     # cfg3 horizon with the 20-dim lift
     ("tank", 10, 20, "Cx", 24, 8),    # Tank_System.m: delta-u form, one output row, two hidden layers, tank plant
     ("mlp64", 20, 20, "Cx", 18, 6),   # 64 hidden units: the run-time-width variant of the in-kernel encoder
     ("mlp128", 8, 10, "Cx", 9, 6),    # 128 hidden units (H_p = 128, eight M tiles)
@@ -808,7 +810,7 @@ def test_rollout_equals_step_plus_plant_loop(torch_mod, KM, lift, L, N, output, 
     assert float((A1 - A2).abs().max()) <= 1e-9 * max(1.0, float(A2.abs().max()))
 
 
-@pytest.mark.parametrize("L,N,B,steps", [(20, 20, 19, 14), (8, 10, 33, 20)])
+@pytest.mark.parametrize("L,N,B,steps", [(20, 20, 19, 14), (8, 10, 33, 20), (20, 30, 9, 8), (32, 40, 6, 6)])
 def test_fused_rollout_vs_oracle(torch_mod, KM, L, N, B, steps):
     """The dominant kernel of the bench against the oracle directly: kmpc_rollout (one fused launch: encoder on
     MFMA inside, RLS, condense, QP, RK4 plant, parameter switch) vs per-trajectory oracle controllers (gain-form RLS,
@@ -844,6 +846,45 @@ def test_fused_rollout_vs_oracle(torch_mod, KM, L, N, B, steps):
             x = Xl[k, :, b].copy()
     print("fused roll-out vs oracle L=%d N=%d: max |u - u_oracle| = %.2e, max |x - x_oracle| = %.2e" % (L, N, worst_u, worst_x))
     assert worst_u < 1e-6 and worst_x < 1e-9
+
+
+@pytest.mark.parametrize("wg", [4, 8, 16])
+def test_fused_rollout_workgroup_sizes(torch_mod, KM, wg):
+    """kmpc_set_rollout_workgroup: 4 trajectories per workgroup (encoder on v_mfma_f64_4x4x4_4b_f64, four workgroups
+    per CU), 8 or 16 (v_mfma_f64_16x16x4_f64).  Every choice is the same closed loop as the per-step path, and the
+    lifted state the kernel leaves behind is the stand-alone encoder's."""
+    torch = torch_mod
+    from koopmpc import _ffi
+    from koopmpc.synth import random_mlp_weights
+
+    lib = _ffi.load()
+    assert lib.kmpc_set_rollout_workgroup(5) == -1
+    rng = np.random.RandomState(40 + wg)
+    L, N, B, steps = 20, 20, 37, 7
+    w = random_mlp_weights(2, 100, 3, L, seed=6)
+    A, Bm, Cm = _rand_model(rng, L, 2)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X0 = 4 * rng.rand(2, B) - 2
+    m1, m2 = KM(n=2, L=L, N=N, batch=B, weights=w), KM(n=2, L=L, N=N, batch=B, weights=w)
+    m1.set_model(A, Bm, Cm); m2.set_model(A, Bm, Cm)
+    X1, X2 = _t(torch, X0), _t(torch, X0)
+    try:
+        assert lib.kmpc_set_rollout_workgroup(wg) == 0
+        assert m1.rollout_is_fused()
+        Ul, Xl = m1.rollout("duffing", X1, r, steps, step0=99, switch_step=102, log=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.kmpc_set_rollout_workgroup(0)
+    assert int(m1.status.max().item()) == 0
+    for i in range(steps):
+        u = m2.step(X2, r).clone()
+        assert float((u - Ul[i]).abs().max()) < 1e-9, (wg, i)
+        X2 = m2.plant_step("duffing", X2, u, switched=(99 + i >= 102))
+        assert float((X2 - Xl[i]).abs().max()) < 1e-9, (wg, i)
+    A1, B1, C1 = m1.get_model()
+    A2, B2, C2 = m2.get_model()
+    assert float((A1 - A2).abs().max()) <= 1e-9 * max(1.0, float(A2.abs().max()))
+    assert float((C1 - C2).abs().max()) <= 1e-9 * max(1.0, float(C2.abs().max()))
 
 
 @pytest.mark.parametrize("B,per_traj,cold,term", [(1, False, False, False), (5, True, False, False), (21, False, True, False),
