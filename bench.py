@@ -17,7 +17,8 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (step_kernel
 (SURVEY.md 8d formula, kmpc_algorithmic_bytes_per_step) x trajectories per launch / its average
 duration measured with HIP events on the launch stream.  `cpu_baseline` times the NumPy oracle run the
 way the reference runs (per-trajectory Python loop, SciPy L-BFGS-B on the shooting cost,
-duffing.py:857-859) on a bounded sample of the same workload, one core.
+duffing.py:857-859) on a bounded sample of the same workload: one worker process per host core of the
+box's CPU share (16), forked before the GPU is touched; the single-core figure is reported beside it.
 """
 import argparse
 import json
@@ -36,31 +37,59 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def cpu_baseline(weights, A0, B0, C0, x0s, L, N, budget_s):
-    """The reference's path on the host, one core: per-trajectory loop, lift -> L-BFGS-B solve -> plant ->
-    RLS (duffing.py:823-1012 order) through the oracle.  Bounded: stops after `budget_s` seconds."""
+def _cpu_worker(args):
+    """One host core: per-trajectory loop, lift -> solve -> plant -> RLS in the reference's order (duffing.py:823-1012)
+    through the oracle, for `budget_s` seconds.  Returns (trajectory-steps done, seconds)."""
+    os.environ["OMP_NUM_THREADS"] = "1"  # (one core means one core: no BLAS threads behind the loop)
+    weights, A0, B0, C0, x0s, L, N, budget_s, solver, steps_per_traj = args
     from oracle import koopman_oracle as ko
 
+    try:
+        import threadpoolctl
+
+        threadpoolctl.threadpool_limits(1)
+    except Exception:
+        pass
     lift = lambda x: ko.mlp_lift(weights, x)
     r = np.tile(np.array([[1.0], [0.0]]), (1, N))
-    steps_per_traj = 8
-    out = {}
-    for solver in ("lbfgsb", "exact"):
-        t0 = time.perf_counter()
-        done = 0
-        lim = budget_s if solver == "lbfgsb" else budget_s / 3.0
-        for t in range(x0s.shape[1]):
-            ctl = ko.OracleController(lift, L, 2, N, -2.0, 2.0, A0, B0, C0, solver=solver)
-            x = x0s[:, t].copy()
-            for k in range(steps_per_traj):
-                u, _, _ = ctl.step(x, r)
-                x = ko.plant_step("duffing", x, u)
-                done += 1
-            if time.perf_counter() - t0 > lim:
-                break
-        dt = time.perf_counter() - t0
-        out[solver] = (done / dt, done, dt)
-    return out, steps_per_traj
+    t0 = time.perf_counter()
+    done = 0
+    for t in range(x0s.shape[1]):
+        ctl = ko.OracleController(lift, L, 2, N, -2.0, 2.0, A0, B0, C0, solver=solver)
+        x = x0s[:, t].copy()
+        for k in range(steps_per_traj):
+            u, _, _ = ctl.step(x, r)
+            x = ko.plant_step("duffing", x, u)
+            done += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    return done, time.perf_counter() - t0
+
+
+def cpu_baseline(weights, x0s, L, N, budget_s):
+    """The reference's path on the host cores, timed BEFORE this process touches the GPU (the workers are forked):
+    the NumPy oracle run the way the reference runs -- per-trajectory Python loop, SciPy L-BFGS-B on the shooting cost
+    (duffing.py:857-859) -- on one core and on the box's CPU share (one trajectory stream per core, trajectories are
+    independent); the exact-QP variant of the oracle on one core beside it.  Bounded by `budget_s` per leg."""
+    import multiprocessing as mp
+
+    from koopmpc.synth import offline_edmd
+    from oracle import koopman_oracle as ko
+
+    A0, B0, C0 = offline_edmd(lambda X: ko.mlp_lift(weights, X))  # the reference's one-off fit (duffing.py:152-177)
+    spt = 8
+    cores = max(1, min(16, os.cpu_count() or 1))  # a one-GPU box comes with 16 host cores
+    one = _cpu_worker((weights, A0, B0, C0, x0s, L, N, budget_s / 3.0, "lbfgsb", spt))
+    exact = _cpu_worker((weights, A0, B0, C0, x0s, L, N, budget_s / 3.0, "exact", spt))
+    per = max(1, x0s.shape[1] // cores)
+    jobs = [(weights, A0, B0, C0, x0s[:, i * per:(i + 1) * per], L, N, budget_s, "lbfgsb", spt) for i in range(cores)]
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    wall = time.perf_counter() - t0
+    done = sum(d for d, _ in res)
+    return {"all": (done / wall, done, wall, cores), "one": (one[0] / one[1], one[0], one[1]),
+            "exact": (exact[0] / exact[1], exact[0], exact[1]), "spt": spt}
 
 
 def main():
@@ -88,7 +117,15 @@ def main():
         if args.gpus > 1:
             sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d "
                      "(WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+    # ---- CPU baseline first (rank 0 at N = 1 only): its worker processes are forked before anything touches the GPU
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0:
+        from koopmpc.synth import initial_states as _init, random_mlp_weights as _rw
+
+        cpu = cpu_baseline(_rw(2, 100, 3, args.L, seed=2024), _init(args.batch, seed=101), args.L, args.N, args.cpu_seconds)
     if not torch.cuda.is_available():
+        if cpu is not None:
+            print("cpu_baseline (no GPU here, nothing else measured): %s" % json.dumps(cpu), file=sys.stderr)
         sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -248,19 +285,22 @@ def main():
                 "avg_lift_kernel_ms": lift_ms,
             },
         }
-        if world == 1 and args.cpu_seconds > 0:
-            res, spt = cpu_baseline(weights, A0, B0, C0, x0, L, N, args.cpu_seconds)
-            v, done, secs = res["lbfgsb"]
-            ve, donee, secse = res["exact"]
+        if cpu is not None:
+            v, done, secs, cores = cpu["all"]
+            v1, done1, secs1 = cpu["one"]
+            ve, donee, secse = cpu["exact"]
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "steps/s",
-                "cores": 1,
+                "cores": cores,
                 "kind": "port",
-                "sample": "first %d trajectories x %d closed-loop steps of the same workload (%d trajectory-steps, %.1f s), "
-                          "NumPy oracle with SciPy L-BFGS-B exactly as duffing.py:857-859; host has %d cores"
-                          % (done // spt, spt, done, secs, os.cpu_count()),
-                "exact_qp_variant_value": ve,
+                "sample": "%d worker processes (one per core), each the first trajectories of its slice of the same workload x %d "
+                          "closed-loop steps: %d trajectory-steps in %.1f s; NumPy oracle with SciPy L-BFGS-B exactly as "
+                          "duffing.py:857-859, one BLAS thread per worker; host reports %d cores"
+                          % (cores, cpu["spt"], done, secs, os.cpu_count()),
+                "single_core_value": v1,
+                "single_core_sample": "%d trajectory-steps in %.1f s" % (done1, secs1),
+                "exact_qp_variant_single_core_value": ve,
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

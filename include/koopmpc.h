@@ -193,6 +193,26 @@ int kmpc_rollout(kmpc_handle* h, int plant, void* X_dev, const void* ref_dev, in
                  int steps, int step0, int switch_step, double hstep, void* U_log_dev, void* X_log_dev,
                  int32_t* status_dev, int32_t* iters_dev, void* stream);
 
+/* ---- terminal ingredients ------------------------------------------- */
+/* The reference's Riccati iteration and LQR gain, batched over nb models on the device, float64:
+ *   solve_DARE(A, B, Q, R)  duffing.py:583-598:  X0 = Q, X <- A'XA - A'XB (R + B'XB)^+ B'XA + Q until
+ *                           max|X_new - X| < eps (the reference uses eps = 0.01) or maxiter (500)
+ *   dlqr(A, B, Q, R)        duffing.py:600-613:  K = (B'XB + R)^+ B'XA
+ * A [nb][L][L], B [nb][L] (one input), P [nb][L][L], K [nb][L] or null, iters [nb] or null are device
+ * pointers; Q (L x L) is a host pointer.  L <= 64.  Synchronises the stream.                          */
+int kmpc_solve_dare(const void* A, const void* B, const double* Q, double R, int maxiter, double eps, int nb,
+                    int L, void* P, void* K, int32_t* iters, void* stream);
+/* Terminal block of Q_bar from that iteration on the handle's own model(s) (replaces the MATLAB
+ * controller's LMI terminal cost by its LQR stand-in): P = solve_DARE(A, B, Q, R), P_N = Co P Co'
+ * (Koopman_update.m:381; Co = the output rows of C, or I for y = psi).  per_trajectory = 0: the model of
+ * trajectory 0 (every trajectory holds it after kmpc_set_model / kmpc_offline_fit) gives one block for
+ * the batch; 1: every trajectory's current [A B], C gives its own block (call it as often as the
+ * terminal ingredients should follow the online model; Koopman_update.m:215 does so every step).
+ * PN_out (host, [1 or B][q*q]) and iters_out (host, [1 or B]) may be null.  float64 handles only.
+ * kmpc_set_terminal_weight(h, PN or NULL) replaces / removes the block again.                    */
+int kmpc_terminal_from_dare(kmpc_handle* h, const double* Q, double R, int maxiter, double eps,
+                            int per_trajectory, double* PN_out, int32_t* iters_out, void* stream);
+
 /* ---- state hand-over / checkpoint ------------------------------------------------------ */
 /* bytes of the persistent state blob (P, K, bar_Q, C, psi_prev, u_prev, flags)              */
 int64_t kmpc_state_bytes(const kmpc_handle* h);

@@ -23,6 +23,8 @@ struct kmpc_handle {
   virtual int set_centres(const double* cx, int L, int n) = 0;
   virtual int set_model(const double* A, const double* B, const double* C) = 0;
   virtual int set_terminal_weight(const double* PN) = 0;
+  virtual int terminal_from_dare(const double* Qh, double R, int maxiter, double eps, int per_traj, double* PN_out,
+                                 int32_t* iters_out, hipStream_t s) = 0;
   virtual int rollout_is_fused() const = 0;
   virtual int reset(hipStream_t s) = 0;
   virtual int lift(const void* X, void* Psi, int B, hipStream_t s) = 0;
@@ -149,7 +151,8 @@ struct Impl : kmpc_handle {
     for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev, (void*)dWarm,
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
-                      (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop})
+                      (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
+                      (void*)dDareP, (void*)dDareIt, (void*)dWtB})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -219,6 +222,7 @@ struct Impl : kmpc_handle {
   }
 
   int set_terminal_weight(const double* PN) override {
+    wterm_from_dare = false;
     if (!PN) { have_wterm = false; return 0; }
     std::vector<T> w((size_t)q * q);
     for (int r = 0; r < q; ++r)
@@ -227,6 +231,70 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMemcpy(dWt, w.data(), w.size() * sizeof(T), hipMemcpyHostToDevice));
     have_wterm = true;
     return 0;
+  }
+
+  // Terminal block from the Riccati iteration of the reference (solve_DARE, duffing.py:583-598) on this handle's
+  // model(s): P = DARE(A, B, Q_lift, R), Q_bar(end) = Co P Co' (Koopman_update.m:381).  per_traj = 0: the model of
+  // trajectory 0 (after kmpc_set_model / kmpc_offline_fit every trajectory holds that one) gives ONE block for the
+  // batch; per_traj = 1: every trajectory's current [A B], C gives its own block (the MATLAB controller recomputes
+  // its terminal ingredients with the updated model, Koopman_update.m:215, 276-281).
+  int terminal_from_dare(const double* Qh, double R, int maxiter, double eps, int per_traj, double* PN_out,
+                         int32_t* iters_out, hipStream_t s) override {
+    if constexpr (sizeof(T) != 8) {
+      FAIL(-2, "kmpc_terminal_from_dare: float64 handles only (the reference's Riccati iteration is float64)");
+    } else {
+      if (!Qh || maxiter < 1) FAIL(-3, "kmpc_terminal_from_dare: bad arguments");
+      const int nb = per_traj ? B : 1;
+      if (nb == 0) return 0;
+      double* dQl = nullptr;
+      HIPCHK(hipMalloc(&dQl, sizeof(double) * (size_t)L * L));
+      HIPCHK(hipMemcpyAsync(dQl, Qh, sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice, s));
+      if (dare_cap < nb) {
+        if (dDareP) (void)hipFree(dDareP);
+        if (dDareIt) (void)hipFree(dDareIt);
+        if (dWtB) (void)hipFree(dWtB);
+        dDareP = nullptr; dDareIt = nullptr; dWtB = nullptr;
+        HIPCHK(hipMalloc(&dDareP, sizeof(double) * (size_t)nb * L * L));
+        HIPCHK(hipMalloc(&dDareIt, sizeof(int32_t) * (size_t)nb));
+        HIPCHK(hipMalloc(&dWtB, sizeof(double) * (size_t)nb * q * q));
+        dare_cap = nb;
+      }
+      // y = psi (lifted output): Co = I, the block is P itself; y = C x: rows cy0 .. cy0+q-1 of C
+      const bool lift_out = cfg.output_kind == KMPC_OUT_LIFT;
+      double* dEye = nullptr;
+      if (lift_out) {
+        std::vector<double> eye((size_t)L * L, 0.0);
+        for (int i = 0; i < L; ++i) eye[(size_t)i * L + i] = 1.0;
+        HIPCHK(hipMalloc(&dEye, sizeof(double) * (size_t)L * L));
+        HIPCHK(hipMemcpyAsync(dEye, eye.data(), sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice, s));
+        HIPCHK(hipStreamSynchronize(s));  // (the host vector goes out of scope)
+      }
+      DareArgs d{};
+      d.nb = nb; d.L = L; d.q = q; d.maxiter = maxiter; d.shared_model = 0;
+      d.A = (const double*)dK; d.strideA = sK; d.ldA = p;
+      d.B = (const double*)dK + L; d.strideB = sK; d.incB = p;
+      d.Q = dQl; d.R = R; d.eps = eps;
+      d.Co = lift_out ? dEye : (const double*)dC + (size_t)cfg.out_row0 * L;
+      d.strideC = lift_out ? 0 : sC;
+      d.P = dDareP; d.K = nullptr; d.PN = dWtB; d.pn_sub_diag = cfg.Qw; d.iters = dDareIt;
+      HIPCHK(launch_dare(d, s));
+      if (PN_out || iters_out) {
+        HIPCHK(hipStreamSynchronize(s));
+        if (PN_out) {
+          HIPCHK(hipMemcpy(PN_out, dWtB, sizeof(double) * (size_t)nb * q * q, hipMemcpyDeviceToHost));
+          for (int m = 0; m < nb; ++m)
+            for (int r = 0; r < q; ++r) PN_out[((size_t)m * q + r) * q + r] += cfg.Qw;  // hand back P_N, not P_N - Qw I
+        }
+        if (iters_out) HIPCHK(hipMemcpy(iters_out, dDareIt, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost));
+      }
+      HIPCHK(hipStreamSynchronize(s));
+      (void)hipFree(dQl);
+      if (dEye) (void)hipFree(dEye);
+      wterm_per_traj = per_traj != 0;
+      wterm_from_dare = true;
+      have_wterm = true;
+      return 0;
+    }
   }
 
   int reset(hipStream_t s) override {
@@ -279,7 +347,8 @@ struct Impl : kmpc_handle {
     a.out_kind = cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX;
     a.max_iter = cfg.qp_max_iter > 0 ? cfg.qp_max_iter : 8 * N + 40;
     a.P = dP; a.strideP = sP; a.K = dK; a.strideK = sK; a.Qb = dQ; a.strideQ = sQ; a.C = dC; a.strideC = sC;
-    a.Wterm = have_wterm ? dWt : nullptr;
+    a.Wterm = have_wterm ? (wterm_from_dare ? (T*)dWtB : dWt) : nullptr;
+    a.wterm_per_traj = (have_wterm && wterm_from_dare && wterm_per_traj) ? 1 : 0;
     a.lam = (T)cfg.lambda; a.Qw = (T)cfg.Qw; a.Rw = (T)cfg.Rw; a.lb = (T)cfg.lb; a.ub = (T)cfg.ub;
     a.du_mode = cfg.delta_u ? 1 : 0;
     a.cy0 = cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0;
@@ -492,6 +561,10 @@ struct Impl : kmpc_handle {
   T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr;
   T* dWt = nullptr;  // PN - Qw I (terminal block of Q_bar)
   bool have_wterm = false;
+  // kmpc_terminal_from_dare: Riccati workspace and the block(s) it produced ([1] or [B][q*q], PN - Qw I)
+  double* dDareP = nullptr; int32_t* dDareIt = nullptr; double* dWtB = nullptr;
+  int dare_cap = 0;
+  bool wterm_from_dare = false, wterm_per_traj = false;
   bool shared_has_samples = false;
   static constexpr int GRAM_BLOCKS = 256;
   int64_t gram_elems() const override { return (int64_t)(p + L + n) * p; }
@@ -546,7 +619,7 @@ struct Impl : kmpc_handle {
     }
     HIPCHK(launch_shared_condense<T>(dKs, dCs, (const T*)ref, L, n, q, N,
                                      cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX, cfg.Qw, cfg.Rw, dHs, dFs,
-                                     df0s, s, have_wterm ? dWt : nullptr));
+                                     df0s, s, (have_wterm && !wterm_from_dare) ? dWt : nullptr));
     StepArgs<T> a = base_args(B);
     a.phases = PH_QP;
     a.H_in = dHs; a.h_shared = 1; a.F_in = dFs; a.f0_in = df0s;
@@ -710,6 +783,30 @@ int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W, const dou
 int kmpc_set_centres(kmpc_handle* h, const double* cx, int L, int n) { NN(h); return h->set_centres(cx, L, n); }
 int kmpc_set_model(kmpc_handle* h, const double* A, const double* B, const double* C) { NN(h); return h->set_model(A, B, C); }
 int kmpc_set_terminal_weight(kmpc_handle* h, const double* PN) { NN(h); return h->set_terminal_weight(PN); }
+int kmpc_terminal_from_dare(kmpc_handle* h, const double* Q, double R, int maxiter, double eps, int per_trajectory,
+                            double* PN_out, int32_t* iters_out, void* s) {
+  NN(h);
+  return h->terminal_from_dare(Q, R, maxiter, eps, per_trajectory, PN_out, iters_out, (hipStream_t)s);
+}
+int kmpc_solve_dare(const void* A, const void* B, const double* Q, double R, int maxiter, double eps, int nb, int L,
+                    void* P, void* K, int32_t* iters, void* s) {
+  if (nb == 0) return 0;
+  if (!A || !B || !Q || !P || nb < 0 || L < 1 || L > 64 || maxiter < 1) return -3;
+  double* dQl = nullptr;
+  if (hipMalloc(&dQl, sizeof(double) * (size_t)L * L) != hipSuccess) return -1001;
+  int rc = 0;
+  if (hipMemcpyAsync(dQl, Q, sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice, (hipStream_t)s) != hipSuccess) rc = -1002;
+  DareArgs d{};
+  d.nb = nb; d.L = L; d.q = 0; d.maxiter = maxiter; d.shared_model = 0;
+  d.A = (const double*)A; d.strideA = (long)L * L; d.ldA = L;
+  d.B = (const double*)B; d.strideB = L; d.incB = 1;
+  d.Q = dQl; d.R = R; d.eps = eps; d.Co = nullptr; d.strideC = 0;
+  d.P = (double*)P; d.K = (double*)K; d.PN = nullptr; d.pn_sub_diag = 0.0; d.iters = iters;
+  if (!rc && launch_dare(d, (hipStream_t)s) != hipSuccess) rc = -1003;
+  if (hipStreamSynchronize((hipStream_t)s) != hipSuccess && !rc) rc = -1004;
+  (void)hipFree(dQl);
+  return rc;
+}
 int kmpc_rollout_is_fused(const kmpc_handle* h) { NN(h); return h->rollout_is_fused(); }
 int kmpc_set_rollout_workgroup(int trajectories) {
   if (trajectories != 0 && trajectories != 4 && trajectories != 8 && trajectories != 16) return -1;

@@ -53,6 +53,7 @@ struct StepArgs {
   T* x_warm;       // [N][B] previous minimiser = start of the next solve, or null: start at clip(0) as the reference
                    // does (its pastRes_loc stays zeros, duffing.py:634-635, 859); same minimiser, less work
   const T* Wterm;  // q x q, PN - Qw I: terminal block of Q_bar (Koopman_update.m:381), or null
+  int wterm_per_traj;  // Wterm is [B][q*q]: every trajectory its own block (kmpc_terminal_from_dare)
   T lam, Qw, Rw, lb, ub;
 };
 
@@ -101,6 +102,23 @@ template <typename T> struct GramArgs {
 template <typename T> struct PlantArgs {
   int B, plant, switched; T h; T* X; const T* U;
 };
+
+// Batched Riccati iteration (dare_kernel.hip): model m has A at A + m*strideA (row stride ldA), B at B + m*strideB
+// (element stride incB), Co at Co + m*strideC; shared_model: one model for every block (strides ignored).
+struct DareArgs {
+  int nb, L, q, maxiter, shared_model;
+  const double* A; long strideA; int ldA;
+  const double* B; long strideB; int incB;
+  const double* Q;                 // L x L, shared
+  double R, eps;
+  const double* Co; long strideC;  // q x L rows of C, or null
+  double* P;                       // [nb][L*L]
+  double* K;                       // [nb][L] or null
+  double* PN;                      // [nb][q*q] or null
+  double pn_sub_diag;              // subtracted from the diagonal of PN (the step kernel takes PN - Qw I)
+  int32_t* iters;                  // [nb] or null
+};
+hipError_t launch_dare(const DareArgs& a, hipStream_t s);
 
 size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2);
 

@@ -1312,13 +1312,14 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       // terminal block of Q_bar is PN instead of Qw I (Koopman_update.m:381); Wterm = PN - Qw I:
       //   H[a][b] += g_{N-1-a}' sym(W) g_{N-1-b},   f[a] += 2 g_{N-1-a}' W e_N
       block_sync<TPB>();
+      const T* const Wt = a.Wterm + (a.wterm_per_traj ? (size_t)b * q * q : (size_t)0);
       for (int e = tid; e < N * N; e += TPB) {
         const int aa = e / N, bb = e - aa * N;
         const T* ga = sG + (N - 1 - aa) * q;
         const T* gb = sG + (N - 1 - bb) * q;
         T acc = T(0);
         for (int r = 0; r < q; ++r)
-          for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * (T(0.5) * (a.Wterm[r * q + s2] + a.Wterm[s2 * q + r])) * gb[s2];
+          for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * (T(0.5) * (Wt[r * q + s2] + Wt[s2 * q + r])) * gb[s2];
         sH[e] += acc;
       }
       for (int aa = tid; aa < N; aa += TPB) {
@@ -1326,7 +1327,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         const T* eN = sEr + (N - 1) * q;
         T acc = T(0);
         for (int r = 0; r < q; ++r)
-          for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * a.Wterm[r * q + s2] * eN[s2];
+          for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * Wt[r * q + s2] * eN[s2];
         sf[aa] += T(2) * acc;
       }
     }
@@ -1470,7 +1471,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
     int wv = wave;
     asm volatile("" : "+s"(wv));
     const int lane = local_tid<64>();
-    const int tid = wv * 64 + lane;
+    (void)wv;
 #ifdef KMPC_TRACE
     if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 16] = wall_clock64();  // this wave is ready for step k
 #endif

@@ -9,8 +9,8 @@ from .sharding import shard_range, max_over_ranks  # noqa: F401
 def __getattr__(name):
     # KoopmanMPC pulls in torch + the HIP library; import it lazily so host-only helpers
     # (sharding, the ctypes signature table) stay importable on a machine without a GPU.
-    if name == "KoopmanMPC":
-        from .api import KoopmanMPC
+    if name in ("KoopmanMPC", "solve_DARE", "dlqr"):
+        from . import api
 
-        return KoopmanMPC
+        return getattr(api, name)
     raise AttributeError(name)

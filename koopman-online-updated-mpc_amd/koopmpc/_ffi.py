@@ -43,6 +43,8 @@ SIGNATURES = {
     "kmpc_set_centres": (_I, [_VP, _DP, _I, _I]),
     "kmpc_set_model": (_I, [_VP, _DP, _DP, _DP]),
     "kmpc_set_terminal_weight": (_I, [_VP, _DP]),
+    "kmpc_solve_dare": (_I, [_VP, _VP, _DP, _D, _I, _D, _I, _I, _VP, _VP, _VP, _VP]),
+    "kmpc_terminal_from_dare": (_I, [_VP, _DP, _D, _I, _D, _I, _DP, C.POINTER(C.c_int32), _VP]),
     "kmpc_rollout_is_fused": (_I, [_VP]),
     "kmpc_set_rollout_workgroup": (_I, [_I]),
     "kmpc_reset": (_I, [_VP, _VP]),

@@ -8,6 +8,7 @@ vanderpol_RBF.py:348-526); the names below are the ones those loops use:
     "Update LTV-Model" block  duffing.py:900-967  ->  KoopmanMPC.Koopman_update(xlift, u, ylift, x_next)
     costFunction + minimize   duffing.py:857-861  ->  KoopmanMPC.mpc_solve(psi, r)  (condense + exact box-QP)
     one loop iteration        duffing.py:847-984  ->  KoopmanMPC.step(x, r)
+    solve_DARE / dlqr         duffing.py:583-613  ->  solve_DARE(A, B, Q, R), dlqr(A, B, Q, R) (batched, device)
 
 Everything runs in hand-written HIP kernels through libkoopmpc.so (ctypes); torch only owns
 the device buffers and the stream.  batch = 1 with NumPy inputs reproduces the reference's
@@ -25,6 +26,49 @@ from . import _ffi
 
 def _dptr(a):
     return np.ascontiguousarray(a, dtype=np.float64).ctypes.data_as(C.POINTER(C.c_double))
+
+
+def solve_DARE(A, B, Q, R, maxiter=500, eps=0.01, device="cuda:0", return_iters=False):
+    """The reference's Riccati iteration (duffing.py:583-598; its constants maxiter = 500, eps = 0.01 are the
+    defaults) on the device, batched: A (L, L) or (nb, L, L), B (L,), (L, 1) or (nb, L[, 1]), Q (L, L), R scalar.
+    Returns P as a float64 device tensor of A's shape (and the iteration counts when asked)."""
+    P, K, it = _dare(A, B, Q, R, maxiter, eps, device, want_gain=False)
+    return (P, it) if return_iters else P
+
+
+def dlqr(A, B, Q, R, maxiter=500, eps=0.01, device="cuda:0"):
+    """K = (B'XB + R)^+ B'XA with X = solve_DARE(A, B, Q, R)  (duffing.py:600-613): (1, L) or (nb, 1, L)."""
+    P, K, it = _dare(A, B, Q, R, maxiter, eps, device, want_gain=True)
+    return K
+
+
+def _dare(A, B, Q, R, maxiter, eps, device, want_gain):
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("solve_DARE runs on the HIP device only")
+    At = torch.as_tensor(np.asarray(A, dtype=np.float64) if not torch.is_tensor(A) else A).to(device=dev, dtype=torch.float64)
+    single = At.dim() == 2
+    At = At.reshape(-1, At.shape[-1], At.shape[-1]).contiguous()
+    nb, L = At.shape[0], At.shape[-1]
+    Bt = torch.as_tensor(np.asarray(B, dtype=np.float64) if not torch.is_tensor(B) else B).to(device=dev, dtype=torch.float64)
+    Bt = Bt.reshape(nb, L).contiguous()
+    Qh = np.ascontiguousarray(Q, dtype=np.float64)
+    if Qh.shape != (L, L):
+        raise ValueError("Q must be (%d, %d)" % (L, L))
+    P = torch.empty(nb, L, L, dtype=torch.float64, device=dev)
+    K = torch.empty(nb, L, dtype=torch.float64, device=dev) if want_gain else None
+    it = torch.zeros(nb, dtype=torch.int32, device=dev)
+    lib = _ffi.load()
+    with torch.cuda.device(dev):
+        rc = lib.kmpc_solve_dare(C.c_void_p(At.data_ptr()), C.c_void_p(Bt.data_ptr()), _dptr(Qh), float(np.ravel(R)[0]),
+                                 int(maxiter), float(eps), nb, L, C.c_void_p(P.data_ptr()),
+                                 C.c_void_p(K.data_ptr()) if want_gain else None, C.c_void_p(it.data_ptr()),
+                                 C.c_void_p(torch.cuda.current_stream(dev).cuda_stream))
+    if rc != 0:
+        raise RuntimeError("kmpc_solve_dare failed with code %d" % rc)
+    if single:
+        return P[0], (K[0].reshape(1, L) if want_gain else None), it[0]
+    return P, (K.reshape(nb, 1, L) if want_gain else None), it
 
 
 class KoopmanMPC:
@@ -131,6 +175,23 @@ class KoopmanMPC:
         if PN.shape != (self.q, self.q):
             raise ValueError("PN must be (%d, %d)" % (self.q, self.q))
         self._chk(self.lib.kmpc_set_terminal_weight(self.h, _dptr(PN)), "kmpc_set_terminal_weight")
+
+    def terminal_from_dare(self, Q=None, R=0.01, per_trajectory=False, maxiter=500, eps=0.01):
+        """Terminal block from the reference's Riccati iteration on this controller's own model(s): P =
+        solve_DARE(A, B, Q, R) (duffing.py:583-598; Q defaults to the reference's 10 I, R to its 0.01,
+        duffing.py:667-668), Q_bar(end) = Co P Co' (Koopman_update.m:381).  per_trajectory=False: one block from
+        trajectory 0's model (the shared one after set_model / offline_fit); True: every trajectory's current model
+        gives its own block.  Returns (PN, iterations) as NumPy arrays ((q, q) or (B, q, q))."""
+        Qh = np.ascontiguousarray(10.0 * np.eye(self.L) if Q is None else Q, dtype=np.float64)
+        if Qh.shape != (self.L, self.L):
+            raise ValueError("Q must be (%d, %d)" % (self.L, self.L))
+        nb = self.B if per_trajectory else 1
+        PN = np.zeros((nb, self.q, self.q))
+        it = np.zeros(nb, dtype=np.int32)
+        self._chk(self.lib.kmpc_terminal_from_dare(self.h, _dptr(Qh), float(R), int(maxiter), float(eps), 1 if per_trajectory else 0,
+                                                   PN.ctypes.data_as(C.POINTER(C.c_double)), it.ctypes.data_as(C.POINTER(C.c_int32)),
+                                                   self._stream()), "kmpc_terminal_from_dare")
+        return (PN, it) if per_trajectory else (PN[0], int(it[0]))
 
     def offline_fit(self, X, Y, U, ridge=0.0, init_rls=False):
         """K_hat = PHIY pinv([PHIX; U]), C = X pinv(PHIX) (duffing.py:152-177) on the device in Gram form

@@ -240,6 +240,37 @@ def condense(A, B, Co, psi, r, N, Qw=100.0, Rw=1e-4, PN=None):
 # ----------------------------------------------------------------------------------------
 
 
+def solve_dare(A, B, Q, R, maxiter=500, eps=0.01):
+    """duffing.py:583-598: X = Q; X <- A'XA - A'XB pinv(R + B'XB) B'XA + Q, stop after the first iterate with
+    max|X_new - X| < eps (returned) or after maxiter.  Also returns the number of iterations done."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64).reshape(A.shape[0], -1)
+    X = np.asarray(Q, dtype=np.float64)
+    R = np.atleast_2d(np.asarray(R, dtype=np.float64))
+    Xn, it = X, 0
+    for it in range(1, maxiter + 1):
+        Xn = A.T @ X @ A - A.T @ X @ B @ np.linalg.pinv(R + B.T @ X @ B) @ B.T @ X @ A + Q
+        if np.abs(Xn - X).max() < eps:
+            break
+        X = Xn
+    return Xn, it
+
+
+def dlqr(A, B, Q, R, maxiter=500, eps=0.01):
+    """duffing.py:600-613: K = pinv(B'XB + R) (B'XA), X = solve_DARE(A, B, Q, R)."""
+    A = np.asarray(A, dtype=np.float64)
+    B = np.asarray(B, dtype=np.float64).reshape(A.shape[0], -1)
+    X, _ = solve_dare(A, B, Q, R, maxiter, eps)
+    R = np.atleast_2d(np.asarray(R, dtype=np.float64))
+    return np.linalg.pinv(B.T @ X @ B + R) @ (B.T @ X @ A)
+
+
+def terminal_block(Co, P):
+    """Q_bar(end-n+1:end, end-n+1:end) = C*P*C'   (Koopman_update.m:381)."""
+    Co = np.asarray(Co, dtype=np.float64)
+    return Co @ np.asarray(P, dtype=np.float64) @ Co.T
+
+
 def qp_exact(H, f, lb, ub, tol=1e-11, max_iter=None):
     """Exact minimiser of u'Hu + f'u over the box lb <= u <= ub (H SPD): primal active set.
 

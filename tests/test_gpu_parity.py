@@ -185,6 +185,94 @@ def test_condense_matches_oracle(torch_mod, KM, L, N, output, threads):
         assert np.abs(f2[b] - fo).max() <= 1e-10 * max(1.0, np.abs(fo).max())
 
 
+def test_solve_dare_and_dlqr_match_reference_vectors(torch_mod):
+    """kmpc_solve_dare (batched Riccati iteration on the device) against the values the reference's own solve_DARE /
+    dlqr computed (tests/golden/dare.npz) and against the oracle's iteration counts.  Converged cases: P within 1e-9
+    relative; the two cases the reference leaves unconverged after 500 iterations (the offline L = 8 model with
+    Q = 10 I and with Q_Lift) are compared after the same 500 iterations, where rounding has been amplified: 1e-6."""
+    torch = torch_mod
+    from koopmpc import dlqr, solve_DARE
+
+    g = _load("dare.npz")
+    for k in range(int(g["n"])):
+        A, B, Q, R = g["A%d" % k], g["B%d" % k], g["Q%d" % k], float(g["R%d" % k])
+        P, it = solve_DARE(A, B, Q, R, return_iters=True)
+        Po, ito = ko.solve_dare(A, B, Q, R)
+        tol = 1e-6 if ito == 500 else 1e-9
+        assert int(it.item()) == ito, (k, int(it.item()), ito)
+        assert np.abs(P.cpu().numpy() - g["P%d" % k]).max() <= tol * np.abs(g["P%d" % k]).max(), k
+        K = dlqr(A, B, Q, R).cpu().numpy()
+        assert K.shape == (1, A.shape[0])
+        assert np.abs(K - g["K%d" % k]).max() <= tol * max(1.0, np.abs(g["K%d" % k]).max()), k
+    # a batch of models in one call (one workgroup each), L = 20
+    rng = np.random.RandomState(2)
+    nb, L = 70, 20
+    As = rng.randn(nb, L, L)
+    for m in range(nb):
+        As[m] *= (0.5 + 0.45 * rng.rand()) / np.abs(np.linalg.eigvals(As[m])).max()
+    Bs = rng.randn(nb, L)
+    Q = np.diag(1.0 + rng.rand(L))
+    P, it = solve_DARE(As, Bs, Q, 0.3, eps=1e-9, return_iters=True)
+    K = dlqr(As, Bs, Q, 0.3, eps=1e-9).cpu().numpy()
+    P = P.cpu().numpy()
+    for m in range(nb):
+        Po, ito = ko.solve_dare(As[m], Bs[m], Q, 0.3, eps=1e-9)
+        assert abs(int(it[m].item()) - ito) <= 1, m  # (the stop test sits at 1e-9: rounding may move it by one)
+        assert np.abs(P[m] - Po).max() <= 1e-8 * np.abs(Po).max(), m
+        assert np.abs(K[m] - ko.dlqr(As[m], Bs[m], Q, 0.3, eps=1e-9)).max() <= 1e-8 * max(1.0, np.abs(K[m]).max()), m
+    assert solve_DARE(np.zeros((0, L, L)), np.zeros((0, L)), Q, 0.3).shape == (0, L, L)  # empty batch
+
+
+@pytest.mark.parametrize("L,N,output", [(20, 20, "Cx"), (8, 10, "lift")])
+def test_terminal_from_dare(torch_mod, KM, L, N, output):
+    """kmpc_terminal_from_dare: P_N = Co solve_DARE(A, B, Q, R) Co' (Koopman_update.m:381 with the LQR stand-in) from
+    the shared model, then per trajectory from online-updated models; the condensed QP carries the block(s) and the
+    closed loop solves with them."""
+    torch = torch_mod
+    rng = np.random.RandomState(L)
+    B = 6
+    q = L if output == "lift" else 2
+    mpc = KM(n=2, L=L, N=N, batch=B, lift="rbf", centres=rng.rand(L, 2), output=output)
+    A, Bm, Cm = _rand_model(rng, L, 2)
+    mpc.set_model(A, Bm, Cm)
+    Q = 10.0 * np.eye(L)
+    PN, it = mpc.terminal_from_dare(Q, 0.01)
+    Po, ito = ko.solve_dare(A, Bm, Q, 0.01)
+    Co = np.eye(L) if output == "lift" else Cm
+    PNo = ko.terminal_block(Co, Po)
+    assert it == ito
+    assert np.abs(PN - PNo).max() <= 1e-9 * np.abs(PNo).max()
+    psi = rng.randn(L, B)
+    r = rng.randn(q, N)
+    H, f = [t.cpu().numpy() for t in mpc.condense(psi, r)]
+    for b in range(B):
+        _, _, Ho, fo, _ = ko.condense(A, Bm, None if output == "lift" else Cm, psi[:, b], r, N, PN=PNo)
+        assert np.abs(H[b] - Ho).max() <= 1e-9 * np.abs(Ho).max()
+        assert np.abs(f[b] - fo).max() <= 1e-9 * max(1.0, np.abs(fo).max())
+    # per trajectory: a few online updates make the models differ, every trajectory gets its own block
+    for k in range(3):  # (contractive data: the fitted models are stable, the Riccati iteration converges)
+        mpc.Koopman_update(rng.randn(L, B), rng.randn(B), 0.3 * rng.randn(L, B), rng.randn(2, B))
+    PNb, itb = mpc.terminal_from_dare(Q, 0.01, per_trajectory=True)
+    Ab, Bb, Cb = [t.cpu().numpy() if t is not None else None for t in mpc.get_model()]
+    H, f = [t.cpu().numpy() for t in mpc.condense(psi, r)]
+    for b in range(B):
+        Pb, itob = ko.solve_dare(Ab[b], Bb[b], Q, 0.01)
+        Cob = np.eye(L) if output == "lift" else Cb[b]
+        PNob = ko.terminal_block(Cob, Pb)
+        tol = 1e-6 if itob == 500 else 1e-9
+        assert abs(int(itb[b]) - itob) <= (0 if itob == 500 else 1), (b, itb[b], itob)
+        assert np.abs(PNb[b] - PNob).max() <= tol * max(1.0, np.abs(PNob).max()), b
+        _, _, Ho, fo, _ = ko.condense(Ab[b], Bb[b], None if output == "lift" else Cb[b], psi[:, b], r, N, PN=PNb[b])
+        assert np.abs(H[b] - Ho).max() <= 1e-9 * np.abs(Ho).max(), b
+        assert np.abs(f[b] - fo).max() <= 1e-9 * max(1.0, np.abs(fo).max()), b
+    U, st, _ = mpc.qp_solve(H, f)
+    assert int(st.max().item()) <= 1
+    mpc.set_terminal_weight(None)  # back to Qw I
+    H0, _ = [t.cpu().numpy() for t in mpc.condense(psi, r)]
+    _, _, Hplain, _, _ = ko.condense(Ab[0], Bb[0], None if output == "lift" else Cb[0], psi[:, 0], r, N)
+    assert np.abs(H0[0] - Hplain).max() <= 1e-10 * np.abs(Hplain).max()
+
+
 @pytest.mark.parametrize("L,N,output,threads", [(20, 20, "Cx", 64), (8, 30, "lift", 64), (64, 50, "Cx", 256)])
 def test_condense_with_terminal_weight(torch_mod, KM, L, N, output, threads):
     """Q_bar(end-n+1:end, end-n+1:end) = C*P*C' (Koopman_update.m:381): a q x q terminal block instead of Qw*I;

@@ -263,3 +263,21 @@ def test_nn_encoder_mat_prefix_is_a_vdp_trajectory():
         if np.abs(xn - X[:, k + 1]).max() > 1e-9:
             pytest.skip("log layout of NN_Encoder.mat differs from (x_k, u_k) -> x_{k+1}; kept as data only")
     assert np.all(np.abs(U) <= 6.0 + 1e-12)
+
+
+def test_dare_and_dlqr_are_the_reference_functions():
+    """solve_DARE / dlqr (duffing.py:583-613) evaluated by the reference's own functions on its own call (offline
+    model, Q = 10 I, R = 0.01, duffing.py:667-671), on online-updated models of the golden loop and on seeded random
+    models (tests/golden/make_golden_dare.py): the restatement reproduces P and K bit for bit, including the two
+    cases the reference leaves unconverged after its 500 iterations."""
+    g = _load("dare.npz")
+    for k in range(int(g["n"])):
+        A, B, Q, R = g["A%d" % k], g["B%d" % k], g["Q%d" % k], float(g["R%d" % k])
+        P, it = ko.solve_dare(A, B, Q, R)
+        assert 1 <= it <= 500
+        assert np.array_equal(P, g["P%d" % k]), k
+        assert np.array_equal(ko.dlqr(A, B, Q, R), g["K%d" % k]), k
+    # the terminal block is what the MATLAB controller writes into Q_bar (Koopman_update.m:381)
+    Co = np.array([[1.0, 2.0, 0.0], [0.0, 1.0, -1.0]])
+    P = np.diag([1.0, 2.0, 3.0])
+    assert np.allclose(ko.terminal_block(Co, P), Co @ P @ Co.T)
