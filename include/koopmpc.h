@@ -105,6 +105,15 @@ int kmpc_set_terminal_weight(kmpc_handle* h, const double* PN);
 /* re-initialise the online state: K_A = 0, inv_K_G = P0 I, bar_X = 0, bar_Q = barQ0 I and
  * forget the previous transition (duffing.py:927-930, 944-946)                              */
 int kmpc_reset(kmpc_handle* h, void* stream);
+/* the same start with other scales than the configuration's (1e4 / 100 duffing.py:929-930, 946; 1e5 / 1e5
+ * vanderpol.py:875, 888; 1e4 / 1e4 Tank_System.m:240, 255)                                      */
+int kmpc_state_init(kmpc_handle* h, double P0_scale, double barQ0_scale, void* stream);
+/* every trajectory continues from given reference-form accumulators (the MATLAB start from the offline
+ * Gram, Koopman_update.m:264-265): K_A0 (L x p), inv_K_G = P0 (p x p), bar_X0 (n x L, NULL for y = psi),
+ * bar_Q0 (L x L); host, row-major.  The handle keeps the algebraically identical gain form: [A B] =
+ * K_A0 P0 (duffing.py:938), C = bar_X0 bar_Q0 (duffing.py:953); the first online update refines them.  */
+int kmpc_state_init_from(kmpc_handle* h, const double* K_A0, const double* P0, const double* barX0,
+                         const double* barQ0, void* stream);
 
 /* ---- the hot path, one call per reference statement --------------------------------- */
 /* Psi = lift(X): net.Encoder(x) duffing.py:847 / rbf(x, cx) vanderpol_RBF.py:372.

@@ -27,6 +27,8 @@ struct kmpc_handle {
                                  int32_t* iters_out, hipStream_t s) = 0;
   virtual int rollout_is_fused() const = 0;
   virtual int reset(hipStream_t s) = 0;
+  virtual int state_init(double P0, double barQ0, hipStream_t s) = 0;
+  virtual int state_init_from(const double* KA0, const double* P0m, const double* barX0, const double* barQ0m, hipStream_t s) = 0;
   virtual int lift(const void* X, void* Psi, int B, hipStream_t s) = 0;
   virtual int rls_update(const void* psi, const void* u, const void* psin, const void* xn, int B, hipStream_t s) = 0;
   virtual int get_model(void* A, void* B, void* C, hipStream_t s) = 0;
@@ -305,6 +307,55 @@ struct Impl : kmpc_handle {
     have_prev = false;
     rls_fresh = true;
     cur = 0;
+    return 0;
+  }
+
+  // kmpc_state_init: the reference's start of the online update (duffing.py:927-930, 944-946) with the given scales
+  int state_init(double P0, double barQ0, hipStream_t s) override {
+    if (!(P0 > 0.0) || !(barQ0 > 0.0)) FAIL(-3, "kmpc_state_init: the scales must be positive");
+    cfg.P0 = P0; cfg.barQ0 = barQ0;
+    return reset(s);
+  }
+  // kmpc_state_init_from: every trajectory continues from given reference-form accumulators (the MATLAB start from the
+  // offline Gram, Koopman_update.m:264-265): K_A0 (L x p), inv_K_G = P0 (p x p), bar_X0 (n x L), bar_Q0 (L x L), host,
+  // row-major.  The handle keeps the gain form: K = K_A0 P0 (duffing.py:938), C = bar_X0 bar_Q0 (duffing.py:953).
+  int state_init_from(const double* KA0, const double* P0m, const double* barX0, const double* barQ0m, hipStream_t s) override {
+    if (!KA0 || !P0m || !barQ0m || (cfg.output_kind == KMPC_OUT_CX && !barX0)) FAIL(-3, "kmpc_state_init_from: bad arguments");
+    int rc = reset(s);
+    if (rc) return rc;
+    std::vector<T> hP((size_t)p * p), hQ((size_t)L * L), hK((size_t)L * p), hC((size_t)n * L, T(0));
+    for (size_t i = 0; i < hP.size(); ++i) hP[i] = (T)P0m[i];
+    for (size_t i = 0; i < hQ.size(); ++i) hQ[i] = (T)barQ0m[i];
+    for (int r = 0; r < L; ++r)
+      for (int c2 = 0; c2 < p; ++c2) {
+        double acc = 0.0;
+        for (int k = 0; k < p; ++k) acc += KA0[(size_t)r * p + k] * P0m[(size_t)k * p + c2];
+        hK[(size_t)r * p + c2] = (T)acc;
+      }
+    if (cfg.output_kind == KMPC_OUT_CX)
+      for (int r = 0; r < n; ++r)
+        for (int c2 = 0; c2 < L; ++c2) {
+          double acc = 0.0;
+          for (int k = 0; k < L; ++k) acc += barX0[(size_t)r * L + k] * barQ0m[(size_t)k * L + c2];
+          hC[(size_t)r * L + c2] = (T)acc;
+        }
+    T* tmp = nullptr;
+    const size_t tot = hP.size() + hQ.size() + hK.size() + hC.size();
+    HIPCHK(hipMalloc(&tmp, sizeof(T) * tot));
+    T* tP = tmp; T* tQ = tP + hP.size(); T* tK = tQ + hQ.size(); T* tC = tK + hK.size();
+    HIPCHK(hipMemcpyAsync(tP, hP.data(), sizeof(T) * hP.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(tQ, hQ.data(), sizeof(T) * hQ.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(tK, hK.data(), sizeof(T) * hK.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemcpyAsync(tC, hC.data(), sizeof(T) * hC.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(launch_broadcast<T>(dP, sP, tP, p * p, B, s));
+    HIPCHK(launch_broadcast<T>(dQ, sQ, tQ, L * L, B, s));
+    HIPCHK(launch_broadcast<T>(dK, sK, tK, L * p, B, s));
+    if (cfg.output_kind == KMPC_OUT_CX) HIPCHK(launch_broadcast<T>(dC, sC, tC, n * L, B, s));
+    if (dKs) HIPCHK(hipMemcpyAsync(dKs, tK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice, s));
+    if (dCs) HIPCHK(hipMemcpyAsync(dCs, tC, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));
+    (void)hipFree(tmp);
+    rls_fresh = false;  // the first online update continues from these accumulators
     return 0;
   }
 
@@ -814,6 +865,11 @@ int kmpc_set_rollout_workgroup(int trajectories) {
   return 0;
 }
 int kmpc_reset(kmpc_handle* h, void* s) { NN(h); return h->reset((hipStream_t)s); }
+int kmpc_state_init(kmpc_handle* h, double P0_scale, double barQ0_scale, void* s) { NN(h); return h->state_init(P0_scale, barQ0_scale, (hipStream_t)s); }
+int kmpc_state_init_from(kmpc_handle* h, const double* K_A0, const double* P0, const double* barX0, const double* barQ0, void* s) {
+  NN(h);
+  return h->state_init_from(K_A0, P0, barX0, barQ0, (hipStream_t)s);
+}
 int kmpc_lift(kmpc_handle* h, const void* X, void* Psi, int B, void* s) { NN(h); return h->lift(X, Psi, B, (hipStream_t)s); }
 int kmpc_rls_update(kmpc_handle* h, const void* psi, const void* u, const void* psin, const void* xn, int B, void* s) { NN(h); return h->rls_update(psi, u, psin, xn, B, (hipStream_t)s); }
 int kmpc_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->get_model(A, B, C, (hipStream_t)s); }

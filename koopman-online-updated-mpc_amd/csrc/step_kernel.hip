@@ -1582,9 +1582,11 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
       // waves only take part in the barriers.
       const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
       const bool hid = wv < MTH, out = wv < MTO;
-      double af[RO_KB2];  // A-fragments of the first k-steps of the coming layer (requested a layer ahead)
-      if (R.nhh > 0) { if (hid) ro_load_afrags(R.Whp[0], KS, wv, 0, lane, af); }
-      else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af);
+      // A-fragments in two alternating batches of 8 k-steps: the first batch of a layer is requested a layer ahead
+      // (it travels across the barrier), every further batch while the previous one is being multiplied
+      double af[2][RO_KB2];
+      if (R.nhh > 0) { if (hid) ro_load_afrags(R.Whp[0], KS, wv, 0, lane, af[0]); }
+      else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af[0]);
       // ---- layer 1 (K = n <= 4: one k-step, W1 zero-padded to 4 columns): one MFMA per hidden tile, bias as the
       //      accumulator input, straight into B-fragment layout.  Operands are requested before the barrier.
       double a1 = 0.0;
@@ -1622,12 +1624,12 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
 #pragma unroll
           for (int bt = 0; bt < 32 / RO_KB2; ++bt) {  // KS <= 32 k-steps in batches
             const int kb = bt * RO_KB2;
-            if (bt > 0 && kb < KS) ro_load_afrags(Wp, KS, wv, kb, lane, af);
+            if (kb + RO_KB2 < KS) ro_load_afrags(Wp, KS, wv, kb + RO_KB2, lane, af[(bt + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < RO_KB2; i += 2) {
-              if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i], act[(kb + i) * 64 + lane], acc0, 0, 0, 0);
+              if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i], act[(kb + i) * 64 + lane], acc0, 0, 0, 0);
               if (kb + i + 1 < KS)
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
             }
           }
         }
@@ -1643,8 +1645,8 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
         }
         // the next layer's first fragments travel across the barrier
         if (!last) {
-          if (h + 1 < R.nhh) { if (hid) ro_load_afrags(R.Whp[h + 1], KS, wv, 0, lane, af); }
-          else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af);
+          if (h + 1 < R.nhh) { if (hid) ro_load_afrags(R.Whp[h + 1], KS, wv, 0, lane, af[0]); }
+          else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af[0]);
         }
         __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
       }

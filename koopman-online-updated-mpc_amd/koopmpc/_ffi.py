@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG_DIR), "libkoopmpc.so")
+# (KMPC_LIB: a measurement build of the same sources, e.g. libkoopmpc_dev.so / libkoopmpc_trace.so)
+LIB_PATH = os.environ.get("KMPC_LIB") or os.path.join(os.path.dirname(_PKG_DIR), "libkoopmpc.so")
 
 KMPC_F32, KMPC_F64 = 0, 1
 KMPC_LIFT_MLP, KMPC_LIFT_RBF_PY, KMPC_LIFT_RBF_MATLAB = 0, 1, 2
@@ -48,6 +49,8 @@ SIGNATURES = {
     "kmpc_rollout_is_fused": (_I, [_VP]),
     "kmpc_set_rollout_workgroup": (_I, [_I]),
     "kmpc_reset": (_I, [_VP, _VP]),
+    "kmpc_state_init": (_I, [_VP, _D, _D, _VP]),
+    "kmpc_state_init_from": (_I, [_VP, _DP, _DP, _DP, _DP, _VP]),
     "kmpc_lift": (_I, [_VP, _VP, _VP, _I, _VP]),
     "kmpc_rls_update": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "kmpc_get_model": (_I, [_VP, _VP, _VP, _VP, _VP]),

@@ -209,6 +209,17 @@ class KoopmanMPC:
                                             self._p(Bm), self._p(Cm), self._stream()), "kmpc_offline_fit")
         return A, Bm, Cm
 
+    def state_init(self, P0=None, barQ0=None, K_A=None, inv_K_G=None, bar_X=None, bar_Q=None):
+        """Start of the online update.  Scales only: K_A = 0, inv_K_G = P0 I, bar_X = 0, bar_Q = barQ0 I
+        (duffing.py:927-930, 944-946).  With the reference's accumulators (K_A (L,p), inv_K_G (p,p), bar_X (n,L),
+        bar_Q (L,L)): every trajectory continues from them (Koopman_update.m:264-265)."""
+        if K_A is None:
+            self._chk(self.lib.kmpc_state_init(self.h, float(self.cfg.P0 if P0 is None else P0),
+                                               float(self.cfg.barQ0 if barQ0 is None else barQ0), self._stream()), "kmpc_state_init")
+            return
+        self._chk(self.lib.kmpc_state_init_from(self.h, _dptr(K_A), _dptr(inv_K_G), _dptr(bar_X) if bar_X is not None else None,
+                                                _dptr(bar_Q), self._stream()), "kmpc_state_init_from")
+
     def reset(self):
         self._chk(self.lib.kmpc_reset(self.h, self._stream()), "kmpc_reset")
 

@@ -185,6 +185,41 @@ def test_condense_matches_oracle(torch_mod, KM, L, N, output, threads):
         assert np.abs(f2[b] - fo).max() <= 1e-10 * max(1.0, np.abs(fo).max())
 
 
+def test_state_init_from_reference_accumulators(torch_mod, KM):
+    """kmpc_state_init_from: the reference's own accumulators after 60 loop iterations (K_A, inv_K_G, bar_X, bar_Q of
+    the golden Duffing loop) become the state of every trajectory; the model is K_A inv_K_G / bar_X bar_Q, and the
+    next update with the loop's next transition gives the model the reference had one iteration later (to the
+    K_A inv_K_G re-association floor of this loop, 5e-8).  kmpc_state_init restarts with other scales."""
+    g = _load("duffing_loop.npz")
+    w = ko.load_mlp_weights(_load("weights_duffing.npz"))
+    k = 60
+    B = 3
+    mpc = KM(n=2, L=8, N=10, batch=B, weights=w)
+    mpc.state_init(K_A=g["loop_K_A"][k], inv_K_G=g["loop_inv_K_G"][k], bar_X=g["loop_bar_X"][k], bar_Q=g["loop_bar_Q"][k])
+    A, Bm, Cm = [t.cpu().numpy() for t in mpc.get_model()]
+    Kext = g["loop_K_A"][k] @ g["loop_inv_K_G"][k]
+    for b in range(B):
+        # (the product cancels: entries of inv_K_G reach 1e4 -- summation order shows at 1e-12)
+        assert np.abs(A[b] - Kext[:, :8]).max() <= 1e-10 * np.abs(Kext).max()
+        assert np.abs(Bm[b][:, 0] - Kext[:, 8]).max() <= 1e-10 * np.abs(Kext).max()
+        assert np.abs(Cm[b] - g["loop_bar_X"][k] @ g["loop_bar_Q"][k]).max() <= 1e-10
+    tile = lambda v: np.tile(np.reshape(v, (-1, 1)), (1, B))
+    A, Bm, Cm = [t.cpu().numpy() for t in mpc.Koopman_update(tile(g["loop_xlift"][k + 1]), np.full(B, float(np.ravel(g["loop_u_loc"][k + 1])[0])),
+                                                              tile(g["loop_ylift"][k + 1]), tile(g["loop_x_loc"][k + 1]))]
+    ref = g["loop_K_ext"][k + 1]
+    assert np.abs(A[1] - ref[:, :8]).max() <= 5e-7 * np.abs(ref).max()
+    assert np.abs(Bm[1][:, 0] - ref[:, 8]).max() <= 5e-7 * np.abs(ref).max()
+    Cref = g["loop_bar_X"][k + 1] @ g["loop_bar_Q"][k + 1]  # C = bar_X bar_Q after the update (duffing.py:953)
+    assert np.abs(Cm[1] - Cref).max() <= 5e-7 * max(1.0, np.abs(Cref).max())
+    # scales-only restart: the first update afterwards starts from K_A = 0, P = 1e5 I like vanderpol.py:875
+    mpc.state_init(P0=1e5, barQ0=1e5)
+    z = np.concatenate([g["loop_xlift"][k + 1].ravel(), np.ravel(g["loop_u_loc"][k + 1])[:1]])
+    A, Bm, Cm = [t.cpu().numpy() for t in mpc.Koopman_update(tile(g["loop_xlift"][k + 1]), np.full(B, z[-1]), tile(g["loop_ylift"][k + 1]),
+                                                              tile(g["loop_x_loc"][k + 1]))]
+    K1 = np.outer(g["loop_ylift"][k + 1].ravel(), z) * (1e5 / (1.0 + 1e5 * (z @ z)))  # = y z' (P0 I - P0^2 z z' / (1 + P0 z'z))
+    assert np.abs(np.concatenate([A[0], Bm[0]], 1) - K1).max() <= 1e-9 * max(1.0, np.abs(K1).max())
+
+
 def test_solve_dare_and_dlqr_match_reference_vectors(torch_mod):
     """kmpc_solve_dare (batched Riccati iteration on the device) against the values the reference's own solve_DARE /
     dlqr computed (tests/golden/dare.npz) and against the oracle's iteration counts.  Converged cases: P within 1e-9
