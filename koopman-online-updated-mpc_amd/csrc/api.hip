@@ -628,7 +628,7 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMalloc(&dKs, sizeof(T) * (size_t)L * p));
     HIPCHK(hipMalloc(&dCs, sizeof(T) * (size_t)n * L));
     HIPCHK(hipMalloc(&dHs, sizeof(T) * (size_t)N * N));
-    HIPCHK(hipMalloc(&dFs, sizeof(T) * (size_t)N * L));
+    HIPCHK(hipMalloc(&dFs, sizeof(T) * (size_t)N * (L + 1)));  // (one more column in the delta-u form)
     HIPCHK(hipMalloc(&df0s, sizeof(T) * (size_t)N));
     // until samples exist the shared model is the offline one (trajectory 0's copy, duffing.py:811-813)
     HIPCHK(hipMemcpy(dKs, dK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice));
@@ -637,7 +637,6 @@ struct Impl : kmpc_handle {
   }
   int shared_local_gram(const void* X, double* delta, hipStream_t s) override {
     if (!X || !delta) FAIL(-3, "kmpc_shared_local_gram: null pointer");
-    if (cfg.delta_u || cfg.out_rows > 0) FAIL(-3, "shared-model mode does not implement the delta-u / Cy-row options yet");
     int rc = shared_alloc();
     if (rc) return rc;
     T* psi_now = dPsi[cur];
@@ -670,7 +669,8 @@ struct Impl : kmpc_handle {
     }
     HIPCHK(launch_shared_condense<T>(dKs, dCs, (const T*)ref, L, n, q, N,
                                      cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX, cfg.Qw, cfg.Rw, dHs, dFs,
-                                     df0s, s, (have_wterm && !wterm_from_dare) ? dWt : nullptr));
+                                     df0s, s, (have_wterm && !wterm_from_dare) ? dWt : nullptr, cfg.delta_u ? 1 : 0,
+                                     cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0));
     StepArgs<T> a = base_args(B);
     a.phases = PH_QP;
     a.H_in = dHs; a.h_shared = 1; a.F_in = dFs; a.f0_in = df0s;

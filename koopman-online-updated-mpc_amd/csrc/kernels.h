@@ -141,7 +141,8 @@ template <typename T> hipError_t launch_shared_solve(const double* gram, int L, 
                                                      T* Qout = nullptr);
 template <typename T> hipError_t launch_shared_condense(const T* K, const T* C, const T* ref, int L, int n, int q, int N,
                                                         int out_kind, double Qw, double Rw, T* Hout, T* Fout, T* f0out,
-                                                        hipStream_t s, const T* Wterm = nullptr);
+                                                        hipStream_t s, const T* Wterm = nullptr, int du_mode = 0,
+                                                        int cy0 = 0);
 template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s);
 template <typename T> hipError_t launch_export_model(const T* K, long strideK, const T* C, long strideC, int n, int L,
                                                      int B, T* A_out, T* B_out, T* C_out, hipStream_t s);

@@ -1348,9 +1348,12 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       // shared-model mode: f_b = F psi_b + f0 (the per-trajectory part of the condensed QP)
       for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
       block_sync<TPB>();
+      // (delta-u form: F has one more column, for u_prev -- the augmented state is [psi; u_prev], Tank_System.m:290)
+      const int Lf = L + (a.du_mode ? 1 : 0);
       for (int e = tid; e < N; e += TPB) {
         T acc = a.f0_in[e];
-        for (int l = 0; l < L; ++l) acc += a.F_in[e * L + l] * sy[l];
+        for (int l = 0; l < L; ++l) acc += a.F_in[e * Lf + l] * sy[l];
+        if (a.du_mode) acc += a.F_in[e * Lf + L] * a.u_prev[b];
         sf[e] = acc;
       }
     } else {

@@ -619,6 +619,69 @@ def test_shared_model_closed_loop_vs_oracle(torch_mod, KM, L, N, B, layers):
     assert worst_m < 1e-7 and worst_u < 1e-6
 
 
+@pytest.mark.parametrize("L,N,B", [(10, 20, 24), (32, 40, 12)])
+def test_shared_model_delta_u_tank_vs_oracle(torch_mod, KM, L, N, B):
+    """BASELINE cfg4 as specified: cascaded tanks, ONE model for the batch from pooled Gram sums (the all-reduced
+    block), the MPC in the delta-u form on the augmented model [A B; 0 1], [B; 1], [Cy C 0] (Tank_System.m:110-113,
+    265-268, 290) with the first-move box (:182-188), output = second tank level.  Against the oracle: SharedEdmd for
+    the model, the delta-u condense / exact QP of OracleDeltaUController per trajectory.  L = 32, N = 40 are cfg4's sizes."""
+    torch = torch_mod
+    from koopmpc.synth import random_mlp_weights
+
+    rng = np.random.RandomState(L + N)
+    w = ko.load_mlp_weights(_load("weights_tank.npz")) if L == 10 else random_mlp_weights(2, 100, 2, L, seed=9)
+    lift_fn = lambda x: ko.mlp_lift(w, x)
+    mpc = KM(n=2, L=L, N=N, batch=B, weights=w, layers=2, lb=-0.5, ub=0.5, umin=-8.0, umax=8.0, Qw=10.0, Rw=1e-3, P0=1e4,
+             barQ0=1e4, delta_u=True, out_row0=1, out_rows=1)
+    Ub = 10 * rng.rand(100, 100) - 5
+    xc = np.maximum(4 * rng.rand(2, 100) - 2, 0.0)
+    Xs, Ys, Us = [], [], []
+    for i in range(100):
+        xn = ko.tank_step(xc, Ub[i])
+        Xs.append(xc); Ys.append(xn); Us.append(Ub[i][None, :]); xc = xn
+    Xd, Yd, Ud = np.concatenate(Xs, 1), np.concatenate(Ys, 1), np.concatenate(Us, 1)
+    V = np.concatenate([lift_fn(Xd), Ud], 0)
+    M = np.concatenate([lift_fn(Yd), Xd], 0) @ V.T @ np.linalg.pinv(V @ V.T)
+    A, Bm, C = M[:L, :L], M[:L, L:], M[L:, :L]
+    mpc.set_model(A, Bm, C)
+    r = np.ones((1, N))
+    sh = ko.SharedEdmd(L, 2, P0=1e4, barQ0=1e4)
+    X = np.abs(rng.rand(2, B))
+    uabs = np.zeros(B)
+    prev = None
+    worst_u, worst_m, compared = 0.0, 0.0, 0
+    for k in range(7):
+        u = mpc.shared_step(X, r).cpu().numpy()
+        dU = mpc.Useq.cpu().numpy()
+        st = mpc.status.cpu().numpy()
+        assert (st <= 1).all(), k
+        Psi = lift_fn(X)
+        if prev is not None:
+            sh.add(*ko.SharedEdmd.gram(prev[0], prev[1], Psi, X))
+            A, Bm, C = sh.model()
+            Ag, Bg, Cg = [t.cpu().numpy() for t in mpc.shared_model()]
+            scale = max(np.abs(A).max(), np.abs(Bm).max())
+            worst_m = max(worst_m, np.abs(Ag - A).max() / scale, np.abs(Bg - Bm).max() / scale)
+        ctl = ko.OracleDeltaUController(lift_fn, L, 2, N, A, Bm, C)
+        for b in range(B):
+            ctl.u = float(uabs[b])
+            At, Bt, Co, xt = ctl.qp(Psi[:, b])
+            _, _, H, f, _ = ko.condense(At, Bt, Co, xt, r, N, 10.0, 1e-3)
+            lbv = np.full(N, -0.5); ubv = np.full(N, 0.5)
+            lbv[0] = max(-0.5, -8.0 - uabs[b]); ubv[0] = min(0.5, 8.0 - uabs[b])
+            if np.linalg.cond(H) < 1e10 and st[b] == 0:
+                dUo, _ = ko.qp_exact(H, f, lbv, ubv)
+                worst_u = max(worst_u, np.abs(dU[:, b] - dUo).max(), abs(u[b] - (uabs[b] + dUo[0])))
+                compared += 1
+        uabs = u.copy()
+        prev = (Psi, u.copy())
+        X = ko.tank_step(X, u, switched=(k > 3))
+    print("shared delta-u tank L=%d N=%d: model %.2e, increments %.2e (%d QPs compared)" % (L, N, worst_m, worst_u, compared))
+    assert compared >= 3 * B
+    assert worst_m < 1e-6 and worst_u < 1e-6
+    assert np.all(np.abs(u) <= 8.0) and np.all(np.abs(dU) <= 0.5 + 1e-12)
+
+
 def test_shared_model_two_shards_equal_one_batch(torch_mod, KM):
     """The batch split over two handles (two 'ranks' on one GPU) with the Gram sums added by hand -- the job
     ncclAllReduce does between the two stages -- gives the same shared model and controls as one handle."""
