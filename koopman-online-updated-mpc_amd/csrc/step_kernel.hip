@@ -89,6 +89,10 @@ template <typename T> struct StepVar {
   const T* psi_now;
   T* U0;
   T* x_next;  // fused roll-out: LDS slot that receives x_{k+1} for the workgroup's next lift (else null)
+  // fused roll-out: lane i < L carries psi_i(x_k) and psi_i(x_{k-1}) in registers -- the step does not read them back
+  // from memory (the read-back sat behind the round trip of the store that had just written them)
+  int psi_in_regs;
+  T psi_now_v, psi_prev_v;
 };
 
 // e = tid, tid + TPB, ... < count.  With a compile-time COUNT the loop is fully unrolled, so that the loads of all
@@ -336,14 +340,14 @@ template <typename T> __device__ __forceinline__ T wave_min_x(T v) {
 
 template <typename T, int N_>
 __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
-                                        T* red, T* qx_out) {
+                                        T* red, T* qx_out, T up, T xw_pre) {
   constexpr int RM = (N_ + 7) / 8;
   const int tid = local_tid<64>(), ti = tid >> 3, tj = tid & 7;
   const int myvar = ti + 8 * tj;
   const bool own = (tj < RM) && (myvar < N_);
   // per-variable box: in the delta-u form the first increment also keeps the absolute input inside
   // [umin, umax]:  lb_1 = max(lb, umin - u_prev), ub_1 = min(ub, umax - u_prev)   (Tank_System.m:182-188)
-  const T uprev = a.du_mode ? a.u_prev[b] : T(0);
+  const T uprev = a.du_mode ? up : T(0);  // (requested at the top of the step)
   T lb = a.lb, ub = a.ub;
   const T tol = (T)Tol<T>::kkt();
   const T eact = (T)Tol<T>::act() * (ub - lb);
@@ -400,7 +404,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   // start: the previous minimiser when the handle keeps one, else clip(0) -- the reference's start (its
   // pastRes_loc is never updated: zeros at every step, duffing.py:634-635, 859).  The minimiser is unique: the
   // start only changes the work.
-  T x = own ? (a.x_warm ? tclip(a.x_warm[(size_t)myvar * a.B + b], lb, ub) : c0) : T(0);
+  T x = own ? (a.x_warm ? tclip(xw_pre, lb, ub) : c0) : T(0);  // (xw_pre: requested before the H / f pass)
   T hx = T(0);  // H x at the start (x need not be uniform: the first variable's box may differ)
   {
     T xc[RM];
@@ -872,6 +876,23 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   T* const qg = qxa + N;
 
     KTRACE(0);
+  // requested before anything waits: the previous input (RLS regressor, delta-u form) and -- static sizes -- the
+  // reference, which the condense phase needs only after the state has been written back (requested there, the
+  // load sat behind the round trip of those stores)
+  const T up = a.u_prev[b];
+  T xw_pre = T(0);
+  constexpr int REFN = (Q_ > 0 && N_ > 0 && Q_ * N_ <= 4 * TPB) ? (Q_ * N_ + TPB - 1) / TPB : 0;
+  T refp[REFN > 0 ? REFN : 1];
+  if constexpr (REFN > 0) {
+    if (sv.phases & PH_CONDENSE) {
+      const T* refg = a.ref + (a.ref_per_traj ? (size_t)b * q * N : 0);
+#pragma unroll
+      for (int i = 0; i < REFN; ++i) {
+        const int e = tid + i * TPB, ec = e < q * N ? e : 0, k = ec / q, r = ec - k * q;
+        refp[i] = refg[r * N + k];
+      }
+    }
+  }
 
   // =====================================================================================
   // phase 1: recursive least squares (gain form; algebraically K_A inv_K_G of the reference)
@@ -879,11 +900,25 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   if (sv.phases & PH_RLS) {
     const T* Pg = a.P + (size_t)b * a.strideP;
     T* Kg = a.K + (size_t)b * a.strideK;
-    // Static sizes: bar_Q and C are requested from HBM now, together with P and K, and wait in registers
-    // until the first half of the update is done with the LDS region they go to -- otherwise their latency
-    // sits exposed in the middle of the phase (tools/trace_phases.py: 6.4 -> ~3 us for the C part).
+    // Every HBM request of the phase is issued before the first wait, in the order the data is needed (vector memory
+    // returns in order): the step's small inputs, P and K, then -- static sizes -- bar_Q and C, which wait in registers
+    // until the first half of the update is done with the LDS region they go to.  All of them are UNCONDITIONAL loads
+    // with clamped indices: a load that is skipped on some lanes and replaced by a zero there makes the compiler wait
+    // for every outstanding load before it may write that zero (the phase used to start with three serialised memory
+    // round trips because of this), and costs a masked region of four scalar instructions per load.
+    const int il = tid < L ? tid : L - 1, in = tid < n ? tid : n - 1;  // (L <= 64 <= TPB: one element per thread)
+    const T zp = sv.psi_in_regs ? sv.psi_prev_v : sv.psi_prev[il * a.pp_sl + b * a.pp_sb];
+    const T yp = sv.psi_in_regs ? sv.psi_now_v : sv.psi_now[il * a.pn_sl + b * a.pn_sb];
+    const T xp = a.x_now[(size_t)in * B + b];
+    constexpr int PP_ = L_ > 0 ? (L_ + 1) * (L_ + 1) : 0, LP_ = L_ > 0 ? L_ * (L_ + 1) : 0, LL_ = L_ * L_;
+    constexpr bool STATE_REGS = L_ > 0 && (PP_ + TPB - 1) / TPB <= 17;
+    T pr[STATE_REGS ? (PP_ + TPB - 1) / TPB : 1], kr[STATE_REGS ? (LP_ + TPB - 1) / TPB : 1];
+    if constexpr (STATE_REGS) {
+      for_strided<TPB, PP_>(tid, p * p, [&](int e, int i) { pr[i] = Pg[e]; });
+      for_strided<TPB, LP_>(tid, L * p, [&](int e, int i) { kr[i] = Kg[e]; });
+    }
     constexpr int QPRE = (L_ > 0) ? (L_ * L_ + TPB - 1) / TPB : 0;
-    constexpr bool PREFETCH = (L_ > 0) && (QPRE <= 16);
+    constexpr bool PREFETCH = (L_ > 0) && (QPRE <= 17);
     T qpre[PREFETCH ? QPRE : 1], cpre[PREFETCH ? 2 : 1];
     if constexpr (PREFETCH) {
       if (out_cx) {
@@ -892,23 +927,22 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 #pragma unroll
         for (int i = 0; i < QPRE; ++i) {
           const int e = tid + i * TPB;
-          qpre[i] = e < L * L ? Qg0[e] : T(0);
+          qpre[i] = Qg0[e < L * L ? e : L * L - 1];
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
           const int e = tid + i * TPB;
-          cpre[i] = (!sv.first_update && e < n * L) ? Cg0[e] : T(0);
+          cpre[i] = Cg0[e < n * L ? e : 0];  // (first update: replaced by zero when it goes to LDS)
         }
       }
     }
-    constexpr int PP_ = L_ > 0 ? (L_ + 1) * (L_ + 1) : 0, LP_ = L_ > 0 ? L_ * (L_ + 1) : 0, LL_ = L_ * L_;
-    if constexpr (L_ > 0 && (PP_ + TPB - 1) / TPB <= 16) {
-      T pr[(PP_ + TPB - 1) / TPB], kr[(LP_ + TPB - 1) / TPB];
-      for_strided<TPB, PP_>(tid, p * p, [&](int e, int i) { pr[i] = Pg[e]; });
+    if (tid < L) { sz[tid] = zp; sy[tid] = yp; }
+    if (tid == 0) sz[L] = up;
+    if (tid < n) sx[tid] = xp;
+    if constexpr (STATE_REGS) {
       const bool fu = sv.first_update != 0;
-      for_strided<TPB, LP_>(tid, L * p, [&](int e, int i) { kr[i] = fu ? T(0) : Kg[e]; });
       for_strided<TPB, PP_>(tid, p * p, [&](int e, int i) { sX[e] = pr[i]; });
-      for_strided<TPB, LP_>(tid, L * p, [&](int e, int i) { sK[e] = kr[i]; });
+      for_strided<TPB, LP_>(tid, L * p, [&](int e, int i) { sK[e] = fu ? T(0) : kr[i]; });
     } else {
       for (int e = tid; e < p * p; e += TPB) sX[e] = Pg[e];
       if (sv.first_update) {
@@ -917,12 +951,6 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
       }
     }
-    for (int i = tid; i < L; i += TPB) {
-      sz[i] = sv.psi_prev[i * a.pp_sl + b * a.pp_sb];
-      sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
-    }
-    if (tid == 0) sz[L] = a.u_prev[b];
-    for (int i = tid; i < n; i += TPB) sx[i] = a.x_now[(size_t)i * B + b];
     block_sync<TPB>();
     KTRACE(1);
 
@@ -979,7 +1007,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int e = tid + i * TPB;
-            if (e < n * L) sC[e] = cpre[i];
+            if (e < n * L) sC[e] = sv.first_update ? T(0) : cpre[i];
           }
         }
       } else {
@@ -1028,7 +1056,8 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       const T* Cg = a.C + (size_t)b * a.strideC;
       for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
     }
-    for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
+    if (sv.psi_in_regs) { if (tid < L) sy[tid] = sv.psi_now_v; }
+    else for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
     block_sync<TPB>();
   }
 
@@ -1042,9 +1071,17 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       sV[i] = sK[i * p + L];  // v_0 = B
       sW[i] = sy[i];          // w_0 = psi(x_k)
     }
-    for (int e = tid; e < q * N; e += TPB) {  // sEr[k][r] starts as -r[r][k]
-      const int k = e / q, r = e - k * q;
-      sEr[e] = -ref[r * N + k];
+    if constexpr (REFN > 0) {  // sEr[k][r] starts as -r[r][k]
+#pragma unroll
+      for (int i = 0; i < REFN; ++i) {
+        const int e = tid + i * TPB;
+        if (e < q * N) sEr[e] = -refp[i];
+      }
+    } else {
+      for (int e = tid; e < q * N; e += TPB) {
+        const int k = e / q, r = e - k * q;
+        sEr[e] = -ref[r * N + k];
+      }
     }
     block_sync<TPB>();
     KTRACE(5);
@@ -1061,7 +1098,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(a.cy0 + t - L) * L + l] : T(0));
       // delta-u form (Tank_System.m:110-113): the augmented state [x; u_prev] propagates as
       // x+ = A x + B s with s = 1 on the v-chain (B~ = [B; 1]) and s = u_prev on the w-chain
-      const T bs = (a.du_mode && isA) ? sK[t * p + L] * (half ? a.u_prev[b] : T(1)) : T(0);
+      const T bs = (a.du_mode && isA) ? sK[t * p + L] * (half ? up : T(1)) : T(0);
       if (!cx && half == 0 && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
       if constexpr (sizeof(T) == 8) {
         // float64: the vector stays in the lanes (DPP row broadcast + one cross-row swap per step); LDS only
@@ -1141,7 +1178,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 #pragma unroll
       for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(a.cy0 + t - L) * L + l] : T(0));
       const T bcol = (a.du_mode && isA) ? sK[t * p + L] : T(0);
-      const T upv = a.du_mode ? a.u_prev[b] : T(0);
+      const T upv = a.du_mode ? up : T(0);
       if (!cx && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
       typedef T T2 __attribute__((ext_vector_type(2)));
       int cur = 0;
@@ -1169,6 +1206,47 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         if (isC) {
           if (j < N) sG[j * q + (t - L)] = accv;             // g_j = Co v_j
           if (j >= 1) sEr[(j - 1) * q + (t - L)] += accw;    // e_j = Co w_j - r_{j-1}
+        }
+        block_sync<TPB>();
+        cur ^= 1;
+      }
+    } else if constexpr (L_ > 0 && TPB == 256 && (L_ + Q_ <= 128) && ((L_ & 1) == 0)) {
+      // Static path for four-wave trajectories (cfg5 sizes, L = 64): waves 0-1 run the v-chain, waves 2-3 the w-chain;
+      // thread t of a half keeps row t of [A; Co] in REGISTERS for the whole recursion (the generic path re-reads the
+      // 32 KB matrix from LDS at each of the N + 1 steps: LDS-bandwidth bound), the current vectors are broadcast
+      // 16-byte LDS reads.
+      const int half = tid >> 7, t = tid & 127;
+      const int nco = cx ? q : 0;
+      const bool isA = t < L, isC = (t >= L) && (t < L + nco);
+      T row[L_];
+#pragma unroll
+      for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(a.cy0 + t - L) * L + l] : T(0));
+      const T bs = (a.du_mode && isA) ? sK[t * p + L] * (half ? up : T(1)) : T(0);
+      if (!cx && half == 0 && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
+      typedef T T2 __attribute__((ext_vector_type(2)));
+      int cur = 0;
+      for (int j = 0; j <= N; ++j) {
+        const T2* v2 = reinterpret_cast<const T2*>(__builtin_assume_aligned((half ? sW : sV) + cur * L, 2 * sizeof(T)));
+        T ac4[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int l = 0; l < L_ / 2; ++l) {
+          const T2 x2 = v2[l];
+          ac4[(2 * l) & 3] += row[2 * l] * x2.x;
+          ac4[(2 * l + 1) & 3] += row[2 * l + 1] * x2.y;
+        }
+        const T acc = ((ac4[0] + ac4[1]) + (ac4[2] + ac4[3])) + (isA ? bs : T(0));
+        if (half == 0) {
+          if (isA && j < N) {
+            sV[(cur ^ 1) * L + t] = acc;                      // v_{j+1}
+            if (!cx && j + 1 < N) sG[(j + 1) * q + t] = acc;  // g_{j+1} = v_{j+1}
+          }
+          if (isC && j < N) sG[j * q + (t - L)] = acc;        // g_j = Co v_j
+        } else {
+          if (isA && j < N) {
+            sW[(cur ^ 1) * L + t] = acc;                      // w_{j+1}
+            if (!cx) sEr[j * q + t] += acc;                   // e_{j+1} = w_{j+1} - r_j
+          }
+          if (isC && j >= 1) sEr[(j - 1) * q + (t - L)] += acc;  // e_j = Co w_j - r_{j-1}
         }
         block_sync<TPB>();
         cur ^= 1;
@@ -1231,6 +1309,14 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     }
     // H[a][b] = Qw * S(b-a, N-1-b) (+Rw on the diagonal),  S(d,t) = sum_{s<=t} g_{s+d}.g_s
     KTRACE(6);
+    if constexpr (N_ > 0 && N_ <= 40 && TPB == 64) {
+      // the previous minimiser of this lane's variable (register solver: variable (lane >> 3) + 8 (lane & 7)) is
+      // requested now -- asked for at the start of the solve, it was a memory round trip nobody could hide
+      if ((sv.phases & PH_QP) && a.x_warm) {
+        const int mv = (tid >> 3) + 8 * (tid & 7);
+        xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
+      }
+    }
     if constexpr (TPB == 64 && N_ > 0 && N_ <= 32 && Q_ > 0) {
       // One pass for both: lane d < N walks diagonal d of H, lane 32 + a accumulates f[a].  Both are sums of
       // g_t . w_{t+idx} with w = g (H) or e (f), so the two halves of the wave share one instruction stream.
@@ -1374,8 +1460,12 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   // =====================================================================================
   if (sv.phases & PH_QP) {
     if constexpr (N_ > 0 && N_ <= 40 && TPB == 64) {
+      if (!(sv.phases & PH_CONDENSE) && a.x_warm) {  // QP-only call: nothing has requested the warm start yet
+        const int mv = (tid >> 3) + 8 * (tid & 7);
+        xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
+      }
       // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
-      if (qp_regs<T, N_>(sH, sf, a, sv, b, red, qx)) {
+      if (qp_regs<T, N_>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
         block_sync<TPB>();
         qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
       }
@@ -1389,7 +1479,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 template <typename T, int TPB, int L_, int N_, int Q_>
 __global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr};
+  const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0)};
   step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
 
@@ -1461,6 +1551,10 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
 
   bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
   int cur = ra.cur;
+  // lane i < L: psi_i(x_{k-1}) of this wave's trajectory, carried from step to step (a launch that continues an earlier
+  // one starts from the handle's copy)
+  double psi_prev_reg = 0.0;
+  if (live && ra.have_prev && (int)(tid0 & 63) < L) psi_prev_reg = ra.psi[ra.cur ^ 1][(size_t)b * L + (tid0 & 63)];
   typedef const RolloutArgs<double> __attribute__((address_space(4))) * kernarg_ptr_t;
   for (int k = 0; k < ra.steps; ++k) {
     // The step arguments stay in the kernel-argument segment and are re-read where they are used: hoisted out
@@ -1665,11 +1759,13 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
       asm volatile("" : "+s"(woff), "+s"(bk));  // (as local_tid: keeps the step's address arithmetic inside the loop)
       double* const wsm = smem + woff;
       double* const psi_now = R.psi[cur];
-      if (lane < L) psi_now[(size_t)b * L + lane] = psi_i;
-      __threadfence_block();  // the step reads psi back through its ordinary (global) input
+      if (lane < L) psi_now[(size_t)b * L + lane] = psi_i;  // (state of the handle; the step takes psi from the registers)
       StepVar<double> sv;
       sv.psi_now = psi_now;
       sv.psi_prev = R.psi[cur ^ 1];
+      sv.psi_in_regs = 1;
+      sv.psi_now_v = psi_i;
+      sv.psi_prev_v = psi_prev_reg;
       sv.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
       sv.first_update = fresh ? 1 : 0;
       sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
@@ -1694,6 +1790,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
     if (have_prev) fresh = false;
     have_prev = true;
     cur ^= 1;
+    psi_prev_reg = psi_i;
   }
   if (!RBF && live && (tid0 & 63) == 0) {  // (the host zeroed status / iters before the launch)
     const int* const acc = reinterpret_cast<const int*>(sXn + wave * 4 + 2);
@@ -1833,7 +1930,13 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
 
 template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
-  if (threads == 256) return launch_impl<T, 256, 0, 0, 0>(a, s);
+  if (threads == 256) {
+#ifndef KMPC_DEV_CFG2_ONLY
+    // BASELINE cfg5 sizes (L = 64, N = 50, y = Cx): four waves per trajectory, dimensions fixed at compile time
+    if (a.L == 64 && a.N == 50 && a.q == 2 && a.out_kind == OUT_CX) return launch_impl<T, 256, 64, 50, 2>(a, s);
+#endif
+    return launch_impl<T, 256, 0, 0, 0>(a, s);
+  }
   // (the static instantiations take the output kind from q: y = C x has q <= n <= 4 < 8 <= L rows, y = psi has q = L)
   if ((a.q == a.L) != (a.out_kind == OUT_LIFT)) return launch_impl<T, 64, 0, 0, 0>(a, s);
   // compile-time specialisations: BASELINE cfg1/cfg2 (L=20, N=20, y = Cx) and the reference's own
