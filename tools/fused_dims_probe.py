@@ -27,7 +27,7 @@ if __name__ == "__main__":
         np.save(sys.argv[6], X)
         print("L=%d N=%d B=%d layers=%d fused=%s: %.2f M steps/s, worst status %d, Newton/step %.2f" % (L, N, B, layers, fused, rate, st, it), flush=True)
     else:
-        for cfg in [(8, 30, 4096, 100, 3), (20, 30, 4096, 100, 3), (32, 40, 2048, 100, 2)]:
+        for cfg in ([(8, 30, 4096, int(os.environ["STEPS"]), 3)] if "STEPS" in os.environ else [(8, 30, 4096, 100, 3), (20, 30, 4096, 100, 3), (32, 40, 2048, 100, 2)]):
             outs = []
             for env in ({}, {"KMPC_NO_FUSED_ROLLOUT": "1"}):
                 f = "/tmp/x_%d_%d_%d.npy" % (cfg[0], cfg[1], len(env))
