@@ -591,6 +591,264 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
 }
 
 // ---------------------------------------------------------------------------------------
+// Register-tableau box QP for four-wave trajectories (compile-time N <= 64, 256 threads; cfg5 sizes N = 50).
+// Same method and the same decisions as qp_regs; the 256 threads form a 16 x 16 grid (ti = tid >> 4, tj = tid & 15),
+// thread (ti, tj) keeps T(ti+16r, tj+16c) and H(ti+16r, tj+16c) in registers, variable i is owned by thread
+// (i & 15, i >> 4).  The threads of a grid row are the 16 lanes of a DPP row, so mat-vec partial sums are all-reduced
+// with DPP; what crosses waves goes through LDS: the pivot row / column of a sweep (double-buffered: one barrier per
+// sweep instead of the two barriers and the N^2 LDS read-modify-writes of the LDS tableau), the vector of a mat-vec,
+// the variable sets (64-bit masks assembled with LDS atomics).
+// ---------------------------------------------------------------------------------------
+template <typename T> __device__ __forceinline__ T dpp_row_mirror(T v);
+template <> __device__ __forceinline__ double dpp_row_mirror<double>(double v) {
+  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x140, 0xf, 0xf, true),
+                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x140, 0xf, 0xf, true));
+}
+template <> __device__ __forceinline__ float dpp_row_mirror<float>(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
+}
+template <typename T> __device__ __forceinline__ T allreduce16(T v) {
+  v = allreduce8(v);
+  v += dpp_row_mirror<T>(v);
+  return v;
+}
+
+template <typename T, int N_, int KR>
+__device__ __forceinline__ void sweep_put256(const T (&Tm)[(N_ + 15) / 16][(N_ + 15) / 16], int kt, int ti, int tj, T* col, T* row) {
+  constexpr int RM = (N_ + 15) / 16;
+  if (tj == kt) {
+#pragma unroll
+    for (int r = 0; r < RM; ++r) col[ti + 16 * r] = Tm[r][KR];
+  }
+  if (ti == kt) {
+#pragma unroll
+    for (int c = 0; c < RM; ++c) row[tj + 16 * c] = Tm[KR][c];
+  }
+}
+template <typename T, int N_, int KR>
+__device__ __forceinline__ void sweep_regs256(T (&Tm)[(N_ + 15) / 16][(N_ + 15) / 16], int kt, bool rev, T d, int ti, int tj,
+                                              const T* col, const T* row) {
+  constexpr int RM = (N_ + 15) / 16;
+  const T dinv = fast_rcp(d);
+  const T s = rev ? T(-1) : T(1);
+  T ct[RM], rt[RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r) ct[r] = col[ti + 16 * r];            // T(ti+16r, k)
+#pragma unroll
+  for (int c = 0; c < RM; ++c) rt[c] = row[tj + 16 * c] * dinv;     // T(k, tj+16c) / d
+  if (ti == kt) {  // this thread holds row k in block row KR (see sweep_regs for the edited-input form)
+    ct[KR] = -s;
+#pragma unroll
+    for (int c = 0; c < RM; ++c) Tm[KR][c] = T(0);
+  }
+  if (tj == kt) {
+    rt[KR] = -s * dinv;
+#pragma unroll
+    for (int r = 0; r < RM; ++r) Tm[r][KR] = T(0);
+  }
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int c = 0; c < RM; ++c) Tm[r][c] -= ct[r] * rt[c];
+}
+
+template <typename T, int N_>
+__device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
+                                           T* red, T* work, T* qx_out, T up) {
+  constexpr int RM = (N_ + 15) / 16;
+  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
+  const int myvar = ti + 16 * tj;
+  const bool own = (tj < RM) && (myvar < N_);
+  T* const qv = work;             // 64: the vector of a mat-vec, by variable
+  T* const colb = work + 64;      // 2 x 64: pivot column of a sweep (double-buffered)
+  T* const rowb = work + 192;     // 2 x 64: pivot row
+  unsigned long long* const smk = reinterpret_cast<unsigned long long*>(work + 320);  // 3 variable sets
+  const T uprev = a.du_mode ? up : T(0);
+  T lb = a.lb, ub = a.ub;
+  const T tol = (T)Tol<T>::kkt();
+  const T eact = (T)Tol<T>::act() * (ub - lb);
+  const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
+  if (a.du_mode && tid == 0) {  // first increment: absolute input range folded in (Tank_System.m:182-188)
+    lb = (a.umin - uprev) > lb ? (a.umin - uprev) : lb;
+    ub = (a.umax - uprev) < ub ? (a.umax - uprev) : ub;
+  }
+  const T c0 = tclip(T(0), lb, ub);
+
+  T Tm[RM][RM], Hm[RM][RM];
+#pragma unroll
+  for (int r = 0; r < RM; ++r)
+#pragma unroll
+    for (int c = 0; c < RM; ++c) {
+      const int i = ti + 16 * r, j = tj + 16 * c;
+      Hm[r][c] = (i < N_ && j < N_) ? sH[i * N_ + j] : T(0);
+      Tm[r][c] = T(2) * Hm[r][c];
+    }
+  const T fi = own ? sf[myvar] : T(0);
+  if (tid < 64) qv[tid] = T(0);  // (entries beyond N stay zero)
+  // y_i = sum_j M_ij v_j for the owner of variable i (v given by the owners)
+  auto matvec = [&](const T (&M)[RM][RM], T vin) -> T {
+    __syncthreads();  // the previous vector has been read
+    if (own) qv[myvar] = vin;
+    __syncthreads();
+    T xc[RM];
+#pragma unroll
+    for (int c = 0; c < RM; ++c) xc[c] = qv[tj + 16 * c];
+    T out = T(0);
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      T s0 = T(0);
+#pragma unroll
+      for (int c = 0; c < RM; ++c) s0 += M[r][c] * xc[c];
+      s0 = allreduce16(s0);
+      if (tj == r) out = s0;
+    }
+    return own ? out : T(0);
+  };
+  T ra = T(0);
+  {
+#pragma unroll
+    for (int r = 0; r < RM; ++r) {
+      T s1 = T(0);
+#pragma unroll
+      for (int c = 0; c < RM; ++c) s1 += tabs(Hm[r][c]);
+      s1 = allreduce16(s1);
+      if (tj == r) ra = s1;
+    }
+  }
+  const T gs = tabs(fi) + T(2) * ra * xmaxb;
+  T x = own ? (a.x_warm ? tclip(a.x_warm[(size_t)myvar * a.B + b], lb, ub) : c0) : T(0);
+  T hx = matvec(Hm, x);
+  T J0 = block_sum<T, 256>(own ? x * (hx + fi) : T(0), red);
+  unsigned long long Smask = 0ull;
+  int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0;
+
+  while (true) {
+    T g = T(0);
+    bool bad = false, inI = false, loose = false;
+    if (own) {
+      g = T(2) * hx + fi;
+      const bool atl = x <= lb + eact, atu = x >= ub - eact;
+      inI = (atl && (g > T(0))) || (atu && (g < T(0)));
+      const T viol = inI ? T(0) : tabs(g);
+      const T res = tabs(x - tclip(x - g, lb, ub));
+      const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
+      bad = !((viol <= tol * gs) || (res <= tol * xs));
+      loose = viol > (T)Tol<T>::tight() * gs;
+    }
+    __syncthreads();
+    if (tid < 3) smk[tid] = 0ull;
+    __syncthreads();
+    if (own) {
+      if (bad) atomicOr(&smk[0], 1ull << myvar);
+      if (loose) atomicOr(&smk[1], 1ull << myvar);
+      if (inI) atomicOr(&smk[2], 1ull << myvar);
+    }
+    __syncthreads();
+    const unsigned long long Bmask = smk[0], Imask = smk[2];
+    const bool refine = smk[1] != 0ull;
+    constexpr unsigned long long allmask = (N_ >= 64) ? ~0ull : ((1ull << N_) - 1ull);
+    if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
+    if (Bmask == 0ull && (it > 0 || !a.x_warm)) {  // (see qp_regs: a warm start is never returned unsolved)
+      if (!refine || polish >= 2) { status = 0; break; }
+      ++polish;
+    }
+    if (it >= a.max_iter || refresh > 4) { status = 1; break; }
+    if (it >= N_ + 10) { status = 3; break; }  // crawling: the active-set loop of qp_lds finishes from here
+    unsigned long long Fmask = ~Imask & allmask;
+
+    bool broke = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      unsigned long long diff = Smask ^ Fmask;
+      while (diff) {
+        const int k = __ffsll((long long)diff) - 1;
+        diff &= diff - 1ull;
+        const int kt = k & 15, kr = k >> 4;
+        const bool rev = (Smask >> k) & 1ull;
+        T* const col = colb + (nsw & 1) * 64;
+        T* const row = rowb + (nsw & 1) * 64;
+        ++nsw;
+        switch (kr) {
+          case 0: sweep_put256<T, N_, 0>(Tm, kt, ti, tj, col, row); break;
+          case 1: if constexpr (RM > 1) sweep_put256<T, N_, 1>(Tm, kt, ti, tj, col, row); break;
+          case 2: if constexpr (RM > 2) sweep_put256<T, N_, 2>(Tm, kt, ti, tj, col, row); break;
+          default: if constexpr (RM > 3) sweep_put256<T, N_, 3>(Tm, kt, ti, tj, col, row); break;
+        }
+        __syncthreads();
+        const T d = col[k];  // T(k, k)
+        if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
+          broke = true;
+          if (pass == 1) Fmask &= ~(1ull << k);
+          continue;
+        }
+        switch (kr) {
+          case 0: sweep_regs256<T, N_, 0>(Tm, kt, rev, d, ti, tj, col, row); break;
+          case 1: if constexpr (RM > 1) sweep_regs256<T, N_, 1>(Tm, kt, rev, d, ti, tj, col, row); break;
+          case 2: if constexpr (RM > 2) sweep_regs256<T, N_, 2>(Tm, kt, rev, d, ti, tj, col, row); break;
+          default: if constexpr (RM > 3) sweep_regs256<T, N_, 3>(Tm, kt, rev, d, ti, tj, col, row); break;
+        }
+        Smask ^= (1ull << k);
+      }
+      if (!broke || pass == 1) break;
+      ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hm[r][c];
+      Smask = 0ull;
+    }
+    Fmask = Smask;
+
+    // Newton direction on F, straight to the bound on I
+    const bool isF = own && ((Fmask >> myvar) & 1ull);
+    T pdir = matvec(Tm, isF ? g : T(0));
+    if (!isF) pdir = own ? ((g > T(0) ? lb : (g < T(0) ? ub : x)) - x) : T(0);
+
+    // projected Armijo search on the true cost
+    T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
+    while (true) {
+      xa = own ? tclip(x + alpha * pdir, lb, ub) : T(0);
+      hxa = matvec(Hm, xa);
+      T pJa = own ? xa * (hxa + fi) : T(0);
+      T pdec = own ? (isF ? alpha * (-g * pdir) : g * (x - xa)) : T(0);
+      block_sum2<T, 256>(pJa, pdec, red);
+      Ja = pJa;
+      const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
+      if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
+      alpha *= T(0.25);
+    }
+    x = xa;
+    hx = hxa;
+    J0 = Ja;
+    ++it;
+  }
+  if (status == 2) x = own ? c0 : T(0);  // (see qp_regs: non-finite data never leaves as a NaN input)
+  if (status == 3) {
+    __syncthreads();
+    if (own) qx_out[myvar] = x;
+    return true;
+  }
+  const int B = a.B;
+  if (own) {
+    if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
+    if (a.x_warm) a.x_warm[(size_t)myvar * B + b] = x;
+  }
+  if (tid == 0) {  // thread 0 owns variable 0
+    const T uout = a.du_mode ? uprev + x : x;
+    if (sv.U0) sv.U0[b] = uout;
+    if (a.u_store) a.u_store[b] = uout;
+    if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
+      T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
+      plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
+      a.X_rw[b] = x1;
+      a.X_rw[(size_t)B + b] = x2;
+    }
+    if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
+    if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+  }
+  return false;
+}
+
+// ---------------------------------------------------------------------------------------
 // LDS-tableau box QP (run-time N <= 64, 64 or 256 threads): the generic solver, and the safeguard the
 // register solver falls back to.  Projected Newton on the swept tableau in LDS; when it crawls
 // (N+10 iterations or 2N Armijo backtracks) or when `as_from_start` is set the loop continues as a PRIMAL
@@ -1469,6 +1727,13 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         block_sync<TPB>();
         qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
       }
+    } else if constexpr (N_ > 0 && N_ <= 64 && TPB == 256) {
+      // four-wave register tableau; the workspace is the vector area behind qx / qxa / qg (dead set A of the phase)
+      static_assert(L_ == 0 || 2 * (L_ + 1) + 6 * L_ + 1 + 2 * N_ * Q_ >= 3 * N_ + 324, "qp_regs256 workspace");
+      if (qp_regs256<T, N_>(sH, sf, a, sv, b, red, qg + N, qx, up)) {
+        block_sync<TPB>();
+        qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
+      }
     } else {
       qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, false);
     }
@@ -1477,7 +1742,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 
 // one workgroup of TPB threads per trajectory
 template <typename T, int TPB, int L_, int N_, int Q_>
-__global__ __launch_bounds__(TPB) void step_kernel(const StepArgs<T> a) {
+__global__ __launch_bounds__(TPB, (TPB == 256 ? 2 : 1)) void step_kernel(const StepArgs<T> a) {  // (four-wave trajectories: two workgroups per CU fit the LDS, so at most 256 registers)
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0)};
   step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
@@ -1592,42 +1857,51 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
           psi_i = d * d * log(d + R.eps);
         }
       }
-    } else if constexpr (NW == 4) {
-      // Four trajectories per workgroup (four workgroups per CU, which drift apart: a SIMD then holds waves in
-      // different phases of the step, and a barrier only makes four trajectories wait for each other).  Encoder on
-      // v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction = 16 output rows x 4 trajectories x
-      // 4 k.  Operand lanes (probed, tools/ubench/mfma_f64_4x4.hip): A lane 16k + 4blk + i, B lane 16k + 4blk + j,
-      // D lane 16i + 4blk + j -- so the A-fragments are the SAME packed tiles the 16x16x4 path reads (lane = 16k + row
-      // in tile), B is the activation (k, j) replicated over the blocks (broadcast LDS read), and a tile's output comes
-      // back as row 4blk + i, column j.  On gfx950 this shape runs at the same flop rate as the 16x16x4 one, so the
-      // lift costs the same f64 pipe time per trajectory as with 16 columns.  Wave w owns hidden tiles w and w + 4
-      // (two tiles x two k-parities = four independent accumulator chains), the output tiles go to the waves from
-      // the top (wave 3 has one hidden tile when Hp = 112).
+    } else if constexpr (NW == 4) {  // (written for 4 or 8 columns; with 8 the 16x16x4 path below measures better: 89 vs 87 M steps/s)
+      // Four or eight trajectories per workgroup (four / two workgroups per CU, which drift apart: a SIMD then holds
+      // waves in different phases of the step, and a barrier only makes a few trajectories wait for each other).
+      // Encoder on v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction = 16 output rows x 4
+      // trajectories x 4 k.  Operand lanes (probed, tools/ubench/mfma_f64_4x4.hip): A lane 16k + 4blk + i, B lane
+      // 16k + 4blk + j, D lane 16i + 4blk + j -- so the A-fragments are the SAME packed tiles the 16x16x4 path reads
+      // (lane = 16k + row in tile), B is the activation (k, j) replicated over the blocks (broadcast LDS read), and a
+      // tile's output comes back as row 4blk + i, column j.  On gfx950 this shape runs at the flop rate of the
+      // 16x16x4 one, so the lift costs the same f64 pipe time per trajectory as with 16 columns (the 16x16x4 shape with
+      // 8 columns wastes half of it).  NW = 4: wave w owns hidden tiles w and w + 4; NW = 8: tile w, multiplied with
+      // both groups of four columns (the fragment is loaded once).  Either way four independent accumulator chains
+      // per wave; the output tiles go to the waves from the top (the last wave has less hidden work when Hp = 112).
+      constexpr int CG = NW / 4;      // groups of four trajectory columns
+      constexpr int NT = 8 / NW;      // hidden tiles per wave (Hp <= 128: eight tiles)
       const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
-      const int boff = (lane >> 4) * 4 + (lane & 3);          // B operand: element (k, j) of a k-step
+      const int boff = (lane >> 4) * NC + (lane & 3);         // B operand: element (k, j) of a k-step (+ 4 cg)
       const int drow = ((lane >> 2) & 3) * 4 + (lane >> 4);   // D: row within the tile
       const int dcol = lane & 3;
-      const int th0 = wv, th1 = wv + 4;                       // hidden tiles of this wave
-      const bool vh0 = th0 < MTH, vh1 = th1 < MTH;
-      const int to0 = 3 - wv;                                 // output tile of this wave
+      const int th0 = wv, th1 = wv + NW;                      // hidden tiles of this wave
+      const bool vh0 = th0 < MTH, vh1 = NT > 1 && th1 < MTH;
+      const int to0 = NW - 1 - wv;                            // output tile of this wave
       const bool vo0 = to0 < MTO;
       double af[2][RO_KB2];  // double-buffered batches of A-fragments (one tile at a time: registers are scarce here)
       // first layer: one k-step (K = n <= 4, W1 zero-padded to 4 columns), bias as the accumulator input
-      double a1[2] = {0.0, 0.0}, c1[2] = {0.0, 0.0};
-      if (vh0) { a1[0] = R.W1[4 * (16 * th0 + (lane & 15)) + (lane >> 4)]; c1[0] = R.b1[16 * th0 + drow]; }
-      if (vh1) { a1[1] = R.W1[4 * (16 * th1 + (lane & 15)) + (lane >> 4)]; c1[1] = R.b1[16 * th1 + drow]; }
+      double a1[NT], c1[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int th = wv + t * NW;
+        const bool v = th < MTH;
+        a1[t] = v ? R.W1[4 * (16 * th + (lane & 15)) + (lane >> 4)] : 0.0;
+        c1[t] = v ? R.b1[16 * th + drow] : 0.0;
+      }
       if (R.nhh > 0) { if (vh0) ro_load_afrags(R.Whp[0], KS, th0, 0, lane, af[0]); }
       else if (vo0) ro_load_afrags(R.Wop, KS, to0, 0, lane, af[0]);
-      __syncthreads();  // every wave is done with its LDS region (previous step); x_k of the four trajectories is in sXn
-      {
-        const double xb = sXn[(lane & 3) * 4 + (lane >> 4)];
-        if (vh0) {
-          const double v = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[0], xb, c1[0], 0, 0, 0);
-          sAct0[(16 * th0 + drow) * 4 + dcol] = v > 0.0 ? v : 0.0;
-        }
-        if (vh1) {
-          const double v = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[1], xb, c1[1], 0, 0, 0);
-          sAct0[(16 * th1 + drow) * 4 + dcol] = v > 0.0 ? v : 0.0;
+      __syncthreads();  // every wave is done with its LDS region (previous step); x_k of the trajectories is in sXn
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int th = wv + t * NW;
+        if (th < MTH) {
+#pragma unroll
+          for (int cg = 0; cg < CG; ++cg) {
+            const double xb = sXn[(cg * 4 + (lane & 3)) * 4 + (lane >> 4)];
+            const double v = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[t], xb, c1[t], 0, 0, 0);
+            sAct0[(16 * th + drow) * NC + cg * 4 + dcol] = v > 0.0 ? v : 0.0;
+          }
         }
       }
       __syncthreads();
@@ -1639,30 +1913,43 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
         double* actn = (h & 1) ? sAct0 : sAct1;
         const double* Wp = last ? R.Wop : R.Whp[h & 1];
         const double* bias = last ? R.bo : R.bh[h & 1];
-        double acc[2][2] = {{v0 ? bias[16 * t0 + drow] : 0.0, 0.0}, {v1 ? bias[16 * t1 + drow] : 0.0, 0.0}};
+        double acc[NT][CG][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const double bv = (t ? v1 : v0) ? bias[16 * (t ? t1 : t0) + drow] : 0.0;
+#pragma unroll
+          for (int cg = 0; cg < CG; ++cg) { acc[t][cg][0] = bv; acc[t][cg][1] = 0.0; }
+        }
         constexpr int NB = 32 / RO_KB2;  // batches per tile (KS <= 32 k-steps)
 #pragma unroll
-        for (int g = 0; g < 2 * NB; ++g) {  // batch g: tile g / NB, k-steps (g % NB) * 8 ..; batch g + 1 is requested first
+        for (int g = 0; g < NT * NB; ++g) {  // batch g: tile g / NB, k-steps (g % NB) * 8 ..; batch g + 1 is requested first
           const int tl = g / NB, kb = (g % NB) * RO_KB2;
-          if (g + 1 < 2 * NB) {
+          if (g + 1 < NT * NB) {
             const int tl2 = (g + 1) / NB, kb2 = ((g + 1) % NB) * RO_KB2;
             if ((tl2 ? v1 : v0) && kb2 < KS) ro_load_afrags(Wp, KS, tl2 ? t1 : t0, kb2, lane, af[(g + 1) & 1]);
           }
           if ((tl ? v1 : v0) && kb < KS) {
 #pragma unroll
             for (int i = 0; i < RO_KB2; ++i)
-              if (kb + i < KS)
-                acc[tl][i & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g & 1][i], act[(kb + i) * 16 + boff], acc[tl][i & 1], 0, 0, 0);
+              if (kb + i < KS) {
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg)
+                  acc[tl][cg][i & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g & 1][i], act[(kb + i) * 4 * NC + boff + 4 * cg],
+                                                                         acc[tl][cg][i & 1], 0, 0, 0);
+              }
           }
         }
-        if (v0) {
-          const double v = acc[0][0] + acc[0][1];
-          if (last) sPsi[(16 * t0 + drow) * 4 + dcol] = v;
-          else actn[(16 * t0 + drow) * 4 + dcol] = v > 0.0 ? v : 0.0;
-        }
-        if (v1) {
-          const double v = acc[1][0] + acc[1][1];
-          actn[(16 * t1 + drow) * 4 + dcol] = v > 0.0 ? v : 0.0;
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t ? v1 : v0) {
+            const int tt = t ? t1 : t0;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+              const double v = acc[t][cg][0] + acc[t][cg][1];
+              if (last) sPsi[(16 * tt + drow) * NC + cg * 4 + dcol] = v;
+              else actn[(16 * tt + drow) * NC + cg * 4 + dcol] = v > 0.0 ? v : 0.0;
+            }
+          }
         }
         // the next layer's first fragments travel across the barrier
         if (!last) {
@@ -1671,7 +1958,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
         }
         __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
       }
-      if (lane < L) psi_i = sPsi[lane * 4 + wv];
+      if (lane < L) psi_i = sPsi[lane * NC + wv];
     } else {
       // Cooperative encoder.  Wave w < Hp/16 owns hidden M tile w for the whole K range (two alternating
       // accumulator chains), so bias + ReLU are applied on the accumulator registers and the result is written
