@@ -1,0 +1,457 @@
+// rollout_kernel.hip -- the fused roll-out: `steps` iterations of the reference loop body (duffing.py:823-1012) in ONE
+// launch, step_body (step_body.h) inside, encoder on MFMA.  Compiled as its own translation unit (in parallel with
+// step_kernel.hip); the trace build includes it into step_kernel.hip instead.
+#include "step_body.h"
+
+namespace kmpc {
+
+// ---------------------------------------------------------------------------------------
+// Fused roll-out: `steps` iterations of the reference loop body (duffing.py:823-1012) in ONE launch.
+//
+// A workgroup of 16 waves owns 16 trajectories and walks them through all the steps; workgroups never
+// synchronise with each other, so the launch no longer waits for the slowest QP of the whole batch at every
+// step (a per-step launch is one round of waves: it lasts as long as its slowest trajectory), only the 16
+// trajectories of a workgroup meet -- at the lift, which they compute together:
+//   MLP encoder on v_mfma_f64_16x16x4_f64 with the 16 trajectories as the N dimension; wave w owns hidden M
+//   tile w over the whole K range, bias + ReLU are applied on the accumulator registers and written straight
+//   into the next layer's B-fragment layout (one barrier per layer).  The weights are pre-packed A-fragments.
+//   The lift scratch overlays the per-wave LDS regions, which are dead between two steps.
+// RBF lift: every wave lifts its own state, the waves of a workgroup never meet.
+// ---------------------------------------------------------------------------------------
+typedef double d4_t __attribute__((ext_vector_type(4)));
+// NW = waves (= trajectories) per workgroup: 16 (one workgroup per CU) or 8 (two per CU, MFMA tiles half empty:
+// used when the batch would otherwise leave CUs without a workgroup).
+constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
+constexpr int ro_scratch() { return 2 * RO_ACT; }     // overlays the per-wave regions between two steps
+constexpr int RO_KB2 = 8;                             // A-fragments are fetched and multiplied in batches of 8 k-steps
+// not overlaid: psi (Lp x columns), x_{k+1} of the trajectories (columns x 4); 16 MFMA columns for 8 / 16 waves, 4 for 4
+static int ro_cols(int waves) { return waves == 4 ? 4 : 16; }
+static int ro_keep(int Lp, int waves) { return Lp * ro_cols(waves) + 4 * ro_cols(waves); }
+
+// A-fragments of tile `tile`, k-steps ks0 .. ks0+15 (zero beyond KS)
+__device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int tile, int ks0, int lane, double (&af)[RO_KB2]) {
+#pragma unroll
+  for (int i = 0; i < RO_KB2; ++i) {
+    const int ks = ks0 + i;
+    af[i] = ks < KS ? Wp[((size_t)tile * KS + ks) * 64 + lane] : 0.0;
+  }
+}
+
+// KS_ < 0: RBF lift (no cooperation between the waves; the MLP code and its registers are not in that kernel, and the
+// log / sqrt constants of the RBF not in the MLP kernels).
+// KS_ > 0: k-steps of the encoder's hidden width fixed at compile time (25 = the reference's 100 hidden units): the
+// fragment loads and the MFMAs become straight-line code (with a run-time count every one of them sat behind its own
+// uniform branch and waited for its own LDS read); 0: run-time width.
+// Register budget: the LDS decides how many trajectories (= waves) a CU holds; up to four waves per SIMD get 128
+// VGPRs each (cfg2: 16 trajectories per CU), dimension sets with large per-trajectory regions leave room for more.
+template <int L_, int N_, int Q_, int NW> constexpr int ro_max_threads() {
+  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
+  constexpr size_t wgs = cap / (pw * NW);
+  constexpr size_t waves = wgs * NW > 16 ? 16 : (wgs * NW < (size_t)NW ? (size_t)NW : wgs * NW);
+  return waves > 8 ? 1024 : (waves > 4 ? 512 : 256);  // 4 / 2 / 1 waves per SIMD
+}
+template <int L_, int N_, int Q_, int NW, int KS_>
+__global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_kernel(const RolloutArgs<double> ra) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* const smem = reinterpret_cast<double*>(smem_raw);
+  constexpr int NC = NW == 4 ? 4 : 16;  // trajectory columns of the cooperative encoder
+  constexpr bool RBF = KS_ < 0;         // the lift kind is a compile-time property (KS_ = -1: thin-plate RBF, per wave)
+  const int tid0 = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave-uniform: trajectory index and LDS base stay scalar
+  const int B = ra.s.B, n = ra.s.n, L = L_;
+  const int b0 = blockIdx.x * (int)(blockDim.x >> 6), b = b0 + wave;  // NW waves (MLP lift); RBF: as many as fit in LDS
+  const bool live = b < B;
+  // lift scratch (overlays the per-wave regions between two steps)
+  double* const sAct0 = smem;
+  double* const sAct1 = sAct0 + RO_ACT;
+  double* const sPsi = smem + ra.keep_off;  // behind the per-wave regions: survives into the step
+  double* const sXn = sPsi + ra.Lp * NC;
+  if (!RBF && tid0 < 4 * NC) sXn[tid0] = 0.0;  // (columns of trajectories this workgroup does not have)
+  __syncthreads();
+  if (!RBF && (tid0 & 63) < 4)
+    sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? ra.s.X_rw[(size_t)(tid0 & 63) * B + b] : 0.0;
+
+  bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
+  int cur = ra.cur;
+  // lane i < L: psi_i(x_{k-1}) of this wave's trajectory, carried from step to step (a launch that continues an earlier
+  // one starts from the handle's copy)
+  double psi_prev_reg = 0.0;
+  if (live && ra.have_prev && (int)(tid0 & 63) < L) psi_prev_reg = ra.psi[ra.cur ^ 1][(size_t)b * L + (tid0 & 63)];
+  typedef const RolloutArgs<double> __attribute__((address_space(4))) * kernarg_ptr_t;
+  for (int k = 0; k < ra.steps; ++k) {
+    // The step arguments stay in the kernel-argument segment and are re-read where they are used: hoisted out
+    // of this loop they would pin ~150 scalar registers for the whole kernel (the asm hides the loop invariance).
+    kernarg_ptr_t kp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(kp));
+    const RolloutArgs<double> __attribute__((address_space(4)))& R = *kp;
+    const StepArgs<double>& a = *(const StepArgs<double>*)(&kp->s);  // psi strides (1, L), accumulate = 1: host
+    // (as local_tid: lane- and wave-derived addresses and the lift's tiling constants are recomputed in every
+    //  iteration instead of being carried across the step in registers)
+    int wv = wave;
+    asm volatile("" : "+s"(wv));
+    const int lane = local_tid<64>();
+    (void)wv;
+#ifdef KMPC_TRACE
+    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 16] = wall_clock64();  // this wave is ready for step k
+#endif
+    double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
+    if constexpr (RBF) {
+      if (live && lane < L) {
+        double x[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) x[i] = (i < n) ? a.X_rw[(size_t)i * B + b] : 0.0;
+        const double* c = R.cx + (size_t)lane * n;
+        if (R.rbf_matlab) {
+          double r2 = 0.0;
+          for (int i = 0; i < n; ++i) { const double d = x[i] - c[i]; r2 += d * d; }
+          psi_i = r2 > 0.0 ? r2 * log(sqrt(r2)) : 0.0;
+        } else {
+          double xx = 0.0, cc = 0.0, xc = 0.0;
+          for (int i = 0; i < n; ++i) { xx += x[i] * x[i]; cc += c[i] * c[i]; xc += x[i] * c[i]; }
+          double d2 = xx - 2.0 * xc + cc;
+          d2 = d2 > 0.0 ? d2 : 0.0;
+          const double d = sqrt(d2);
+          psi_i = d * d * log(d + R.eps);
+        }
+      }
+    } else if constexpr (NW == 4) {  // (written for 4 or 8 columns; with 8 the 16x16x4 path below measures better: 89 vs 87 M steps/s)
+      // Four or eight trajectories per workgroup (four / two workgroups per CU, which drift apart: a SIMD then holds
+      // waves in different phases of the step, and a barrier only makes a few trajectories wait for each other).
+      // Encoder on v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction = 16 output rows x 4
+      // trajectories x 4 k.  Operand lanes (probed, tools/ubench/mfma_f64_4x4.hip): A lane 16k + 4blk + i, B lane
+      // 16k + 4blk + j, D lane 16i + 4blk + j -- so the A-fragments are the SAME packed tiles the 16x16x4 path reads
+      // (lane = 16k + row in tile), B is the activation (k, j) replicated over the blocks (broadcast LDS read), and a
+      // tile's output comes back as row 4blk + i, column j.  On gfx950 this shape runs at the flop rate of the
+      // 16x16x4 one, so the lift costs the same f64 pipe time per trajectory as with 16 columns (the 16x16x4 shape with
+      // 8 columns wastes half of it).  NW = 4: wave w owns hidden tiles w and w + 4; NW = 8: tile w, multiplied with
+      // both groups of four columns (the fragment is loaded once).  Either way four independent accumulator chains
+      // per wave; the output tiles go to the waves from the top (the last wave has less hidden work when Hp = 112).
+      constexpr int CG = NW / 4;      // groups of four trajectory columns
+      constexpr int NT = 8 / NW;      // hidden tiles per wave (Hp <= 128: eight tiles)
+      const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
+      const int boff = (lane >> 4) * NC + (lane & 3);         // B operand: element (k, j) of a k-step (+ 4 cg)
+      const int drow = ((lane >> 2) & 3) * 4 + (lane >> 4);   // D: row within the tile
+      const int dcol = lane & 3;
+      const int th0 = wv, th1 = wv + NW;                      // hidden tiles of this wave
+      const bool vh0 = th0 < MTH, vh1 = NT > 1 && th1 < MTH;
+      const int to0 = NW - 1 - wv;                            // output tile of this wave
+      const bool vo0 = to0 < MTO;
+      double af[2][RO_KB2];  // double-buffered batches of A-fragments (one tile at a time: registers are scarce here)
+      // first layer: one k-step (K = n <= 4, W1 zero-padded to 4 columns), bias as the accumulator input
+      double a1[NT], c1[NT];
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int th = wv + t * NW;
+        const bool v = th < MTH;
+        a1[t] = v ? R.W1[4 * (16 * th + (lane & 15)) + (lane >> 4)] : 0.0;
+        c1[t] = v ? R.b1[16 * th + drow] : 0.0;
+      }
+      if (R.nhh > 0) { if (vh0) ro_load_afrags(R.Whp[0], KS, th0, 0, lane, af[0]); }
+      else if (vo0) ro_load_afrags(R.Wop, KS, to0, 0, lane, af[0]);
+      __syncthreads();  // every wave is done with its LDS region (previous step); x_k of the trajectories is in sXn
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int th = wv + t * NW;
+        if (th < MTH) {
+#pragma unroll
+          for (int cg = 0; cg < CG; ++cg) {
+            const double xb = sXn[(cg * 4 + (lane & 3)) * 4 + (lane >> 4)];
+            const double v = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[t], xb, c1[t], 0, 0, 0);
+            sAct0[(16 * th + drow) * NC + cg * 4 + dcol] = v > 0.0 ? v : 0.0;
+          }
+        }
+      }
+      __syncthreads();
+      for (int h = 0; h <= R.nhh; ++h) {
+        const bool last = h == R.nhh;
+        const int t0 = last ? to0 : th0, t1 = th1;
+        const bool v0 = last ? vo0 : vh0, v1 = last ? false : vh1;
+        const double* act = (h & 1) ? sAct1 : sAct0;
+        double* actn = (h & 1) ? sAct0 : sAct1;
+        const double* Wp = last ? R.Wop : R.Whp[h & 1];
+        const double* bias = last ? R.bo : R.bh[h & 1];
+        double acc[NT][CG][2];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          const double bv = (t ? v1 : v0) ? bias[16 * (t ? t1 : t0) + drow] : 0.0;
+#pragma unroll
+          for (int cg = 0; cg < CG; ++cg) { acc[t][cg][0] = bv; acc[t][cg][1] = 0.0; }
+        }
+        constexpr int NB = 32 / RO_KB2;  // batches per tile (KS <= 32 k-steps)
+#pragma unroll
+        for (int g = 0; g < NT * NB; ++g) {  // batch g: tile g / NB, k-steps (g % NB) * 8 ..; batch g + 1 is requested first
+          const int tl = g / NB, kb = (g % NB) * RO_KB2;
+          if (g + 1 < NT * NB) {
+            const int tl2 = (g + 1) / NB, kb2 = ((g + 1) % NB) * RO_KB2;
+            if ((tl2 ? v1 : v0) && kb2 < KS) ro_load_afrags(Wp, KS, tl2 ? t1 : t0, kb2, lane, af[(g + 1) & 1]);
+          }
+          if ((tl ? v1 : v0) && kb < KS) {
+#pragma unroll
+            for (int i = 0; i < RO_KB2; ++i)
+              if (kb + i < KS) {
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg)
+                  acc[tl][cg][i & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g & 1][i], act[(kb + i) * 4 * NC + boff + 4 * cg],
+                                                                         acc[tl][cg][i & 1], 0, 0, 0);
+              }
+          }
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+          if (t ? v1 : v0) {
+            const int tt = t ? t1 : t0;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+              const double v = acc[t][cg][0] + acc[t][cg][1];
+              if (last) sPsi[(16 * tt + drow) * NC + cg * 4 + dcol] = v;
+              else actn[(16 * tt + drow) * NC + cg * 4 + dcol] = v > 0.0 ? v : 0.0;
+            }
+          }
+        }
+        // the next layer's first fragments travel across the barrier
+        if (!last) {
+          if (h + 1 < R.nhh) { if (vh0) ro_load_afrags(R.Whp[h + 1], KS, th0, 0, lane, af[0]); }
+          else if (vo0) ro_load_afrags(R.Wop, KS, to0, 0, lane, af[0]);
+        }
+        __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
+      }
+      if (lane < L) psi_i = sPsi[lane * NC + wv];
+    } else {
+      // Cooperative encoder.  Wave w < Hp/16 owns hidden M tile w for the whole K range (two alternating
+      // accumulator chains), so bias + ReLU are applied on the accumulator registers and the result is written
+      // straight into the next layer's B-fragment layout: one barrier per layer, no partial sums.  The other
+      // waves only take part in the barriers.
+      const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
+      const bool hid = wv < MTH, out = wv < MTO;
+      // A-fragments in two alternating batches of 8 k-steps: the first batch of a layer is requested a layer ahead
+      // (it travels across the barrier), every further batch while the previous one is being multiplied
+      double af[2][RO_KB2];
+      if (R.nhh > 0) { if (hid) ro_load_afrags(R.Whp[0], KS, wv, 0, lane, af[0]); }
+      else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af[0]);
+      // ---- layer 1 (K = n <= 4: one k-step, W1 zero-padded to 4 columns): one MFMA per hidden tile, bias as the
+      //      accumulator input, straight into B-fragment layout.  Operands are requested before the barrier.
+      double a1 = 0.0;
+      d4_t c1 = {0.0, 0.0, 0.0, 0.0};
+      if (hid) {
+        a1 = R.W1[4 * (16 * wv + (lane & 15)) + (lane >> 4)];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c1[r] = R.b1[16 * wv + (lane >> 4) + 4 * r];
+      }
+      __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all trajectories is in sXn
+      if (hid) {
+        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sXn[4 * (lane & 15) + (lane >> 4)], c1, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * wv + (lane >> 4) + 4 * r;
+          sAct0[(row >> 2) * 64 + ((row & 3) << 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
+        }
+      }
+      __syncthreads();
+      // ---- hidden -> hidden layers, then the output layer, all as: tile = wave, full K
+      for (int h = 0; h <= R.nhh; ++h) {
+        const bool last = h == R.nhh;
+        const bool mine = last ? out : hid;
+        const double* act = (h & 1) ? sAct1 : sAct0;
+        double* actn = (h & 1) ? sAct0 : sAct1;
+        const double* Wp = last ? R.Wop : R.Whp[h & 1];
+        const double* bias = last ? R.bo : R.bh[h & 1];
+        // accumulator register r of lane l holds row (l >> 4) + 4 r, column l & 15 of the tile
+        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        if (mine) {  // the bias is the accumulator input of the first chain
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc0[r] = bias[16 * wv + (lane >> 4) + 4 * r];
+        }
+        if (mine) {
+#pragma unroll
+          for (int bt = 0; bt < 32 / RO_KB2; ++bt) {  // KS <= 32 k-steps in batches
+            const int kb = bt * RO_KB2;
+            if (kb + RO_KB2 < KS) ro_load_afrags(Wp, KS, wv, kb + RO_KB2, lane, af[(bt + 1) & 1]);
+#pragma unroll
+            for (int i = 0; i < RO_KB2; i += 2) {
+              if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i], act[(kb + i) * 64 + lane], acc0, 0, 0, 0);
+              if (kb + i + 1 < KS)
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
+            }
+          }
+        }
+        if (mine) {
+          const int col = lane & 15;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wv + (lane >> 4) + 4 * r;
+            const double v = acc0[r] + acc1[r];
+            if (last) sPsi[row * 16 + col] = v;
+            else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+          }
+        }
+        // the next layer's first fragments travel across the barrier
+        if (!last) {
+          if (h + 1 < R.nhh) { if (hid) ro_load_afrags(R.Whp[h + 1], KS, wv, 0, lane, af[0]); }
+          else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af[0]);
+        }
+        __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
+      }
+      if (lane < L) psi_i = sPsi[lane * 16 + wv];
+    }
+
+#ifdef KMPC_TRACE
+    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 17] = wall_clock64();  // lift done
+    if (lane == 0 && b < 8192 && k == 0) kmpc_trace_buf[b * 32 + 19] = wall_clock64();
+#endif
+    if (live) {
+      int woff = wv * R.wstride, bk = b;
+      asm volatile("" : "+s"(woff), "+s"(bk));  // (as local_tid: keeps the step's address arithmetic inside the loop)
+      double* const wsm = smem + woff;
+      double* const psi_now = R.psi[cur];
+      if (lane < L) psi_now[(size_t)b * L + lane] = psi_i;  // (state of the handle; the step takes psi from the registers)
+      StepVar<double> sv;
+      sv.psi_now = psi_now;
+      sv.psi_prev = R.psi[cur ^ 1];
+      sv.psi_in_regs = 1;
+      sv.psi_now_v = psi_i;
+      sv.psi_prev_v = psi_prev_reg;
+      sv.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
+      sv.first_update = fresh ? 1 : 0;
+      sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
+      sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
+      sv.x_next = RBF ? nullptr : sXn + wv * 4;
+      step_body<double, 64, L_, N_, Q_>(a, sv, bk, wsm);
+      if (R.X_log) {
+        __threadfence_block();
+        if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
+      }
+    }
+#ifdef KMPC_TRACE
+    if (lane == 0 && b < 8192) {
+      const unsigned long long t18 = wall_clock64();
+      kmpc_trace_buf[b * 32 + 18] = t18;  // step k done
+      // whole-launch sums: barrier wait + lift, step body (k == 0 resets)
+      const unsigned long long dl = kmpc_trace_buf[b * 32 + 17] - kmpc_trace_buf[b * 32 + 16], db = t18 - kmpc_trace_buf[b * 32 + 17];
+      kmpc_trace_buf[b * 32 + 20] = (k == 0 ? 0ull : kmpc_trace_buf[b * 32 + 20]) + dl;
+      kmpc_trace_buf[b * 32 + 21] = (k == 0 ? 0ull : kmpc_trace_buf[b * 32 + 21]) + db;
+    }
+#endif
+    if (have_prev) fresh = false;
+    have_prev = true;
+    cur ^= 1;
+    psi_prev_reg = psi_i;
+  }
+  if (!RBF && live && (tid0 & 63) == 0) {  // (the host zeroed status / iters before the launch)
+    const int* const acc = reinterpret_cast<const int*>(sXn + wave * 4 + 2);
+    if (ra.s.status) ra.s.status[b] = acc[0];
+    if (ra.s.iters) ra.s.iters[b] = acc[1];
+  }
+}
+
+// waves (= trajectories) per workgroup of the fused roll-out.  MLP lift: 16 (one workgroup per CU) or 8 (two per
+// CU); the RBF lift needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.
+// 0: does not fit.
+static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves, int Lp, int* wstride) {
+  const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr) / sizeof(double) + 1) & ~(size_t)1;
+  if (wstride) *wstride = (int)per_wave;
+  size_t elems = per_wave * waves;
+  if (rbf) return elems;
+  const size_t scratch = waves == 4 ? RO_ACT + 128 * 4 : ro_scratch();  // (sAct1 sits RO_ACT behind sAct0)
+  if (elems < scratch) elems = scratch;
+  return elems + ro_keep(Lp, waves);
+}
+static int g_rollout_workgroup = 0;  // kmpc_set_rollout_workgroup
+void set_rollout_workgroup(int trajectories) { g_rollout_workgroup = trajectories; }
+static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
+  const size_t cap = 160 * 1024 / sizeof(double);
+  if (!rbf) {
+    static const char* env = getenv("KMPC_ROLLOUT_WAVES");  // measurement aid: force 4, 8 or 16
+    // workgroups of w trajectories that fit on one CU (LDS is handed out in 512-byte granules; 16 waves per CU)
+    auto wgs = [&](int w) -> int {
+      const size_t e = (rollout_lds_elems(n, L, q, N, false, w, Lp, nullptr) + 63) & ~(size_t)63;
+      const int k = (int)(cap / e);
+      return k * w > 16 ? 16 / w : k;
+    };
+    if (g_rollout_workgroup) return wgs(g_rollout_workgroup) > 0 ? g_rollout_workgroup : 0;
+    if (env && (atoi(env) == 4 || atoi(env) == 8 || atoi(env) == 16)) return wgs(atoi(env)) > 0 ? atoi(env) : 0;
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    // Most trajectories per CU wins; ties go to the larger workgroup (cfg2 at B = 4096: 91.3 / 89.0 / 84.5 M steps/s
+    // with 16 / 8 / 4 trajectories per workgroup).  Batches that leave CUs without a 16-trajectory workgroup are
+    // spread as smaller ones (B = 2048: 43.5 vs 35.7 M steps/s with 8, B = 1024: 22.6 vs 18.4).
+    int best = 0, best_traj = 0;
+    for (int w = 16; w >= 4; w >>= 1) {
+      const int t = wgs(w) * w;
+      if (t > best_traj) { best = w; best_traj = t; }
+    }
+    if (best == 16 && wgs(8) * 8 >= 16 && (B + 15) / 16 < cus) return 8;
+    return best;
+  }
+  for (int w = 16; w >= 4; w >>= 1)
+    if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
+  return 0;
+}
+template <int L_, int N_, int Q_, int NW, int KS_>
+static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, size_t lds, hipStream_t s) {
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW, KS_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  const int grid = (k.s.B + waves - 1) / waves;
+  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_>), dim3(grid), dim3(64 * waves), lds, s, k);
+  return hipGetLastError();
+}
+template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
+  RolloutArgs<double> k = a;
+  const bool rbf = a.lift_rbf != 0;
+  const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
+  if (waves == 0) return hipErrorInvalidValue;
+  step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2);
+  const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
+  k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp, waves));
+  const size_t lds = elems * sizeof(double);
+  if (lds > 160 * 1024) return hipErrorInvalidValue;
+  // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
+  const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
+  if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1>(k, waves, lds, s);
+  // (workgroup sizes whose per-wave regions alone exceed the LDS are not instantiated)
+  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
+  if constexpr (4 * pw <= cap)
+    if (waves == 4) return ks25 ? launch_rollout_nw<L_, N_, Q_, 4, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 4, 0>(k, waves, lds, s);
+  if constexpr (8 * pw <= cap)
+    if (waves == 8) return ks25 ? launch_rollout_nw<L_, N_, Q_, 8, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 8, 0>(k, waves, lds, s);
+  if constexpr (16 * pw <= cap)
+    if (waves == 16) return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0>(k, waves, lds, s);
+  return hipErrorInvalidValue;
+}
+
+template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
+  if (sizeof(T) != 8 || threads == 256 || n > 4) return false;
+  const bool inst = (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
+                    (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2) || (L == 10 && N == 20 && q == 1) ||
+                    (L == 20 && N == 30 && q == 2) || (L == 32 && N == 40 && q == 2) || (L == 32 && N == 40 && q == 1);
+  return inst && rollout_waves(n, L, q, N, rbf, 64) > 0;  // (Lp <= 64)
+}
+template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
+  if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
+  if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
+    return hipErrorInvalidValue;
+  if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
+#ifndef KMPC_DEV_CFG2_ONLY  // (development builds compile the cfg2 instantiations only)
+  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 2) return launch_rollout_impl<8, 10, 2>(a, s);
+  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 8) return launch_rollout_impl<8, 10, 8>(a, s);
+  if (a.s.L == 8 && a.s.N == 30 && a.s.q == 8) return launch_rollout_impl<8, 30, 8>(a, s);
+  if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);
+  if (a.s.L == 10 && a.s.N == 20 && a.s.q == 1) return launch_rollout_impl<10, 20, 1>(a, s);  // Tank_System.m dimensions
+  if (a.s.L == 20 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<20, 30, 2>(a, s);  // BASELINE cfg3 sizes, y = Cx
+  if (a.s.L == 32 && a.s.N == 40 && a.s.q == 2) return launch_rollout_impl<32, 40, 2>(a, s);  // BASELINE cfg4 sizes
+  if (a.s.L == 32 && a.s.N == 40 && a.s.q == 1) return launch_rollout_impl<32, 40, 1>(a, s);
+#endif
+  return hipErrorInvalidValue;
+}
+template <> hipError_t launch_rollout_fused<float>(const RolloutArgs<float>&, hipStream_t) { return hipErrorInvalidValue; }
+template bool rollout_fused_available<float>(int, int, int, int, int, bool);
+template bool rollout_fused_available<double>(int, int, int, int, int, bool);
+
+}  // namespace kmpc

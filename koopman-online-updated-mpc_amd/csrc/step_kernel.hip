@@ -1,8 +1,8 @@
 // step_kernel.hip -- the per-trajectory hot path on gfx950: RLS-EDMD update -> condensed QP
-// build -> box-QP solve (step_body), as a per-step kernel (one 64-lane wave per trajectory by default, four for
-// large dimensions) and inside the fused roll-out kernel (all steps of the closed loop in one launch, 16
-// trajectories per workgroup, encoder on MFMA; second half of this file).  Covariance / model / KKT tiles live in
-// LDS, the persistent state streams HBM -> LDS -> HBM exactly once per step.
+// build -> box-QP solve (step_body, step_body.h), as a per-step kernel (one 64-lane wave per trajectory by default,
+// four for large dimensions); the same step_body runs inside the fused roll-out kernel (all steps of the closed loop
+// in one launch, 16 trajectories per workgroup, encoder on MFMA: rollout_kernel.hip).  Covariance / model / KKT
+// tiles live in LDS, the persistent state streams HBM -> LDS -> HBM exactly once per step.
 //
 // Reference arithmetic restated here (file:line under the reference root):
 //   RLS of [A B]  duffing.py:900, 927-938, 965-967 (lambda form Koopman_update.m:258-278)
@@ -13,1731 +13,14 @@
 //
 // LDS map (elements of T):  X[r1] : P -> bar_Q -> H      Y[r2] : K, C -> elimination matrix
 //                           V     : vectors (RLS/condense set aliased with the QP set)
-#include "kernels.h"
-#include "plant_device.h"
-
-#ifdef KMPC_TRACE
-// Measurement build only (make trace -> libkoopmpc_trace.so, tools/trace_phases.py): lane 0 of every
-// workgroup stamps the 100 MHz wall clock at the phase boundaries.  Never compiled into libkoopmpc.so.
-__device__ unsigned long long kmpc_trace_buf[8192 * 32];
-#define KTRACE(slot)                                                                                      \
-  do {                                                                                                    \
-    if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + (slot)] = wall_clock64();                          \
-  } while (0)
-extern "C" int kmpc_trace_read(void* host, size_t bytes) {
-  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kmpc_trace_buf), bytes, 0, hipMemcpyDeviceToHost);
-}
-#else
-#define KTRACE(slot)
-#endif
+#include "step_body.h"
 
 namespace kmpc {
 
-// ---------------------------------------------------------------------------------------
-// host-side LDS sizing (shared with the launcher)
-// ---------------------------------------------------------------------------------------
-static constexpr int imax(int a, int b) { return a > b ? a : b; }
-
-static constexpr int vec_elems(int n, int L, int q, int N) {
-  const int p = L + 1;
-  const int setA = 2 * p + 6 * L + n + 2 * N * q;  // sz sPz | sy sE sV(2) sW(2) | sx | sG sEr
-  const int setB = 3 * N;                          // qx qxa qg
-  return imax(setA, setB) + N /*sf*/ + 16 /*reduction scratch*/;
-}
-
-static constexpr int step_region1(int L, int N) { return (imax(imax((L + 1) * (L + 1), L * L), N * N) + 1) & ~1; }
-static constexpr int step_region2(int n, int L, int N) { return (imax(L * (L + 1) + n * L, N * N) + 1) & ~1; }
-static constexpr size_t step_lds_elems(int n, int L, int q, int N) {
-  return (size_t)step_region1(L, N) + step_region2(n, L, N) + vec_elems(n, L, q, N);
-}
 size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2) {
   if (r1) *r1 = step_region1(L, N);
   if (r2) *r2 = step_region2(n, L, N);
   return step_lds_elems(n, L, q, N) * elem;
-}
-
-// ---------------------------------------------------------------------------------------
-// device helpers
-// ---------------------------------------------------------------------------------------
-// One trajectory is solved by TPB threads.  TPB == 64: a single wave -- its lanes exchange data through LDS in
-// program order, so a "barrier" is only a compiler/memory fence at wavefront scope and the code may run as one
-// wave of a larger workgroup (the fused roll-out kernel puts 16 trajectories in a workgroup).  TPB == 256:
-// a real workgroup barrier.
-template <int TPB> __device__ __forceinline__ void block_sync() {
-  if constexpr (TPB == 64) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  } else {
-    __syncthreads();
-  }
-}
-template <int TPB> __device__ __forceinline__ int local_tid() {
-  // (single wave: the lane index from mbcnt, so that no register has to keep threadIdx alive)
-  int t = TPB == 64 ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : (int)threadIdx.x;
-  // opaque on purpose: inside the step loop of the fused roll-out every address and mask derived from the lane
-  // index is loop-invariant, and hoisting them all out of the loop costs far more registers than recomputing
-  asm volatile("" : "+v"(t));
-  return t;
-}
-
-// the arguments that change from step to step inside a fused roll-out (everything else stays in the kernel
-// argument segment); the per-step kernel fills it from its StepArgs
-template <typename T> struct StepVar {
-  int phases, first_update, plant_switched;
-  const T* psi_prev;
-  const T* psi_now;
-  T* U0;
-  T* x_next;  // fused roll-out: LDS slot that receives x_{k+1} for the workgroup's next lift (else null)
-  // fused roll-out: lane i < L carries psi_i(x_k) and psi_i(x_{k-1}) in registers -- the step does not read them back
-  // from memory (the read-back sat behind the round trip of the store that had just written them)
-  int psi_in_regs;
-  T psi_now_v, psi_prev_v;
-};
-
-// e = tid, tid + TPB, ... < count.  With a compile-time COUNT the loop is fully unrolled, so that the loads of all
-// its iterations are in flight before the first one is waited for (as a run-time loop each iteration is a
-// complete memory round trip: 14 of them made up the 6 us the RLS phase spent fetching P and K).
-template <int TPB, int COUNT, typename F> __device__ __forceinline__ void for_strided(int tid, int count, F&& f) {
-  if constexpr (COUNT > 0) {
-    constexpr int IT = (COUNT + TPB - 1) / TPB;
-#pragma unroll
-    for (int i = 0; i < IT; ++i) {
-      const int e = tid + i * TPB;
-      if ((i + 1) * TPB <= COUNT || e < COUNT) f(e, i);  // only the last round needs the lane test (tid < TPB)
-    }
-  } else {
-    int i = 0;
-    for (int e = tid; e < count; e += TPB, ++i) f(e, i);
-  }
-}
-
-template <typename T> struct Tol;
-template <> struct Tol<double> {
-  static __device__ __forceinline__ double kkt() { return 1e-9; }
-  static __device__ __forceinline__ double tight() { return 1e-12; }
-  static __device__ __forceinline__ double act() { return 1e-8; }
-  static __device__ __forceinline__ double slack() { return 1e-14; }
-};
-template <> struct Tol<float> {
-  static __device__ __forceinline__ float kkt() { return 2e-5f; }
-  static __device__ __forceinline__ float tight() { return 2e-6f; }
-  static __device__ __forceinline__ float act() { return 1e-5f; }
-  static __device__ __forceinline__ float slack() { return 1e-6f; }
-};
-
-template <typename T> __device__ __forceinline__ T tabs(T v) { return v < T(0) ? -v : v; }
-template <typename T> __device__ __forceinline__ T tclip(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
-
-// ---- register-resident mat-vec chain (condense, static path): the current vector lives in the lanes and is
-// read with the f64 DPP row broadcast of gfx90a+ -- v_fmac_f64_dpp ... row_newbcast:n multiplies by lane n of
-// the reader's own 16-lane row -- so a chain step touches neither LDS nor a barrier.
-template <int LANE, bool NOP>
-__device__ __forceinline__ void fmac_rowbcast(double& acc, double vec, double coef) {
-  // a VALU write of `vec` must be 2 wait states old before DPP reads it: the first use of a step carries the nop
-  if constexpr (NOP)
-    asm volatile("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(vec), "v"(coef), "n"(LANE));
-  else
-    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(vec), "v"(coef), "n"(LANE));
-}
-// acc[l & 3] += row[l] * vec[l], vec[l] = lane l of v0 (l < 16) or lane l-16 of v1, within the reader's row
-template <int L_, int l = 0>
-__device__ __forceinline__ void chain_dot(double (&ac)[4], double v0, double v1, const double (&row)[L_]) {
-  if constexpr (l < L_) {
-    if constexpr (l < 16) fmac_rowbcast<l, l == 0>(ac[l & 3], v0, row[l]);
-    else fmac_rowbcast<l - 16, l == 16>(ac[l & 3], v1, row[l]);
-    chain_dot<L_, l + 1>(ac, v0, v1, row);
-  }
-}
-// Lane t of a 32-lane half holds element t.  v_permlane16_swap (gfx950) exchanges the odd 16-lane rows of its
-// first operand with the even rows of the second: with both = a, every row of a half receives
-// v0 = elements 0..15 and v1 = elements 16..31 of that half, the layout chain_dot reads.
-__device__ __forceinline__ void half_gather(double a, double& v0, double& v1) {
-  const int lo = __double2loint(a), hi = __double2hiint(a);
-  const auto rl = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-  const auto rh = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-  v0 = __hiloint2double(rh[0], rl[0]);
-  v1 = __hiloint2double(rh[1], rl[1]);
-}
-
-// ---- wave-wide sum on DPP (no LDS crossbar): Hillis-Steele prefix inside each 16-lane row with
-// row_shr 1/2/4/8 (bound_ctrl zero-fills), then the four row totals are read from lanes 15/31/47/63.
-__device__ __forceinline__ int dpp_shr(int v, int ctrl) {
-  switch (ctrl) {
-    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
-    case 2: return __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
-    case 4: return __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
-    default: return __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
-  }
-}
-__device__ __forceinline__ double dpp_shr(double v, int ctrl) {
-  return __hiloint2double(dpp_shr(__double2hiint(v), ctrl), dpp_shr(__double2loint(v), ctrl));
-}
-__device__ __forceinline__ float dpp_shr(float v, int ctrl) { return __int_as_float(dpp_shr(__float_as_int(v), ctrl)); }
-__device__ __forceinline__ double lane_bcast(double v, int lane) {
-  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane),
-                          __builtin_amdgcn_readlane(__double2loint(v), lane));
-}
-__device__ __forceinline__ float lane_bcast(float v, int lane) {
-  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
-}
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-  v += dpp_shr(v, 1);
-  v += dpp_shr(v, 2);
-  v += dpp_shr(v, 4);
-  v += dpp_shr(v, 8);
-  return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
-}
-
-// sum over the whole block; every thread gets the result.  `red` holds >= 8 elements.
-template <typename T, int TPB> __device__ __forceinline__ T block_sum(T v, T* red) {
-  v = wave_sum(v);
-  if (TPB == 64) return v;
-  const int w = threadIdx.x >> 6;
-  block_sync<TPB>();  // protect red[] from the previous use
-  if ((threadIdx.x & 63) == 0) red[w] = v;
-  block_sync<TPB>();
-  T s = T(0);
-#pragma unroll
-  for (int i = 0; i < TPB / 64; ++i) s += red[i];
-  return s;
-}
-
-// two sums at once (their shuffle chains interleave); results returned in place
-template <typename T, int TPB> __device__ __forceinline__ void block_sum2(T& v0, T& v1, T* red) {
-  v0 += dpp_shr(v0, 1); v1 += dpp_shr(v1, 1);
-  v0 += dpp_shr(v0, 2); v1 += dpp_shr(v1, 2);
-  v0 += dpp_shr(v0, 4); v1 += dpp_shr(v1, 4);
-  v0 += dpp_shr(v0, 8); v1 += dpp_shr(v1, 8);
-  v0 = (lane_bcast(v0, 15) + lane_bcast(v0, 31)) + (lane_bcast(v0, 47) + lane_bcast(v0, 63));
-  v1 = (lane_bcast(v1, 15) + lane_bcast(v1, 31)) + (lane_bcast(v1, 47) + lane_bcast(v1, 63));
-  if (TPB == 64) return;
-  const int w = threadIdx.x >> 6;
-  block_sync<TPB>();
-  if ((threadIdx.x & 63) == 0) { red[w] = v0; red[4 + w] = v1; }
-  block_sync<TPB>();
-  T s0 = T(0), s1 = T(0);
-#pragma unroll
-  for (int i = 0; i < TPB / 64; ++i) { s0 += red[i]; s1 += red[4 + i]; }
-  v0 = s0; v1 = s1;
-}
-
-// ---------------------------------------------------------------------------------------
-// the kernel
-// ---------------------------------------------------------------------------------------
-
-// ---------------------------------------------------------------------------------------
-// Register-tableau box QP for compile-time N <= 40, one wave per trajectory.
-//
-// The 64 lanes form an 8 x 8 grid (ti = lane>>3, tj = lane&7).  Lane (ti, tj) keeps the blocks
-// Tm[r][c] = T(ti+8r, tj+8c) and Hm[r][c] = H(ti+8r, tj+8c) of the swept tableau and of H in
-// REGISTERS for the whole solve; variable i is owned by lane (i&7, i>>3).  A sweep on variable k
-// needs column k for the lane's rows and row k for its columns: two register fetches across
-// lanes (ds_bpermute, no LDS storage, no barrier), then RM*RM fused multiply-adds
-// T_ij -= T_ik T_kj / d, with T_kj <- s T_kj / d, T_ik <- s T_ik / d, T_kk <- -1/d on the lanes that hold
-// row / column k (s = +1 sweep in, -1 sweep out).
-// Mat-vecs (Newton direction with T, line-search products with H) are partial sums over the
-// lane's columns followed by an 8-lane DPP all-reduce.
-// ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int dpp_q(int v, int sel) {
-  switch (sel) {
-    case 0: return __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-    case 1: return __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xf, 0xf, true);   // quad_perm [2,3,0,1]
-    default: return __builtin_amdgcn_update_dpp(0, v, 0x141, 0xf, 0xf, true); // row_half_mirror
-  }
-}
-__device__ __forceinline__ double dpp_q(double v, int sel) {
-  return __hiloint2double(dpp_q(__double2hiint(v), sel), dpp_q(__double2loint(v), sel));
-}
-__device__ __forceinline__ float dpp_q(float v, int sel) { return __int_as_float(dpp_q(__float_as_int(v), sel)); }
-template <typename T> __device__ __forceinline__ T allreduce8(T v) {
-  v += dpp_q(v, 0);
-  v += dpp_q(v, 1);
-  v += dpp_q(v, 2);
-  return v;
-}
-
-// fast reciprocal: hardware estimate + two Newton steps (full double / float accuracy for the
-// normalised pivots met here; an IEEE-exact division costs ~10 dependent f64 ops at ~40 cycles each)
-__device__ __forceinline__ double fast_rcp(double d) {
-  double r = __builtin_amdgcn_rcp(d);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
-  return r;
-}
-__device__ __forceinline__ float fast_rcp(float d) {
-  float r = __builtin_amdgcn_rcpf(d);
-  r = __builtin_fmaf(__builtin_fmaf(-d, r, 1.0f), r, r);
-  return r;
-}
-// register fetch from another lane with a precomputed byte address (ds_bpermute_b32)
-__device__ __forceinline__ double bperm(int addr, double v) {
-  return __hiloint2double(__builtin_amdgcn_ds_bpermute(addr, __double2hiint(v)),
-                          __builtin_amdgcn_ds_bpermute(addr, __double2loint(v)));
-}
-__device__ __forceinline__ float bperm(int addr, float v) {
-  return __int_as_float(__builtin_amdgcn_ds_bpermute(addr, __float_as_int(v)));
-}
-
-template <typename T, int N_, int KR>
-__device__ __forceinline__ void sweep_regs(T (&Tm)[(N_ + 7) / 8][(N_ + 7) / 8], int kt, bool rev, T d, int ti, int tj) {
-  constexpr int RM = (N_ + 7) / 8;
-  const T dinv = fast_rcp(d);
-  const T s = rev ? T(-1) : T(1);
-  const bool rowk = (ti == kt), colk = (tj == kt);  // this lane holds row k / column k in block KR
-  const int arow = (ti * 8 + kt) << 2, acol = (kt * 8 + tj) << 2;
-  T ct[RM], rt[RM];
-#pragma unroll
-  for (int r = 0; r < RM; ++r) ct[r] = bperm(arow, Tm[r][KR]);  // T(ti+8r, k)
-#pragma unroll
-  for (int c = 0; c < RM; ++c) rt[c] = bperm(acol, Tm[KR][c]) * dinv;  // T(k, tj+8c) / d
-  // Uniform update v = T_ij - ct_i * rt_j.  Row and column k come out of the SAME expression by
-  // editing its inputs on the lanes that hold them (exact, no cancellation):
-  //   row k    : T := 0, ct := -s             ->  v =  s T_kj / d
-  //   column k : T := 0, rt := -s / d         ->  v =  s T_ik / d
-  //   (k, k)   : both                         ->  v = -1 / d
-  if (rowk) {
-    ct[KR] = -s;
-#pragma unroll
-    for (int c = 0; c < RM; ++c) Tm[KR][c] = T(0);
-  }
-  if (colk) {
-    rt[KR] = -s * dinv;
-#pragma unroll
-    for (int r = 0; r < RM; ++r) Tm[r][KR] = T(0);
-  }
-#pragma unroll
-  for (int r = 0; r < RM; ++r)
-#pragma unroll
-    for (int c = 0; c < RM; ++c) Tm[r][c] -= ct[r] * rt[c];
-}
-
-// (kr is a constant after unrolling: the switch folds to one call)
-template <typename T, int N_>
-__device__ __forceinline__ void sweep_regs_at(T (&Tm)[(N_ + 7) / 8][(N_ + 7) / 8], int kr, int kt, bool rev, T d, int ti, int tj) {
-  constexpr int RM = (N_ + 7) / 8;
-  switch (kr) {
-    case 0: sweep_regs<T, N_, 0>(Tm, kt, rev, d, ti, tj); break;
-    case 1: if constexpr (RM > 1) sweep_regs<T, N_, 1>(Tm, kt, rev, d, ti, tj); break;
-    case 2: if constexpr (RM > 2) sweep_regs<T, N_, 2>(Tm, kt, rev, d, ti, tj); break;
-    case 3: if constexpr (RM > 3) sweep_regs<T, N_, 3>(Tm, kt, rev, d, ti, tj); break;
-    default: if constexpr (RM > 4) sweep_regs<T, N_, 4>(Tm, kt, rev, d, ti, tj); break;
-  }
-}
-
-template <typename T> __device__ __forceinline__ T wave_max_x(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const T w = __shfl_xor(v, o, 64); v = w > v ? w : v; }
-  return v;
-}
-template <typename T> __device__ __forceinline__ T wave_min_x(T v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const T w = __shfl_xor(v, o, 64); v = w < v ? w : v; }
-  return v;
-}
-
-template <typename T, int N_>
-__device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
-                                        T* red, T* qx_out, T up, T xw_pre) {
-  constexpr int RM = (N_ + 7) / 8;
-  const int tid = local_tid<64>(), ti = tid >> 3, tj = tid & 7;
-  const int myvar = ti + 8 * tj;
-  const bool own = (tj < RM) && (myvar < N_);
-  // per-variable box: in the delta-u form the first increment also keeps the absolute input inside
-  // [umin, umax]:  lb_1 = max(lb, umin - u_prev), ub_1 = min(ub, umax - u_prev)   (Tank_System.m:182-188)
-  const T uprev = a.du_mode ? up : T(0);  // (requested at the top of the step)
-  T lb = a.lb, ub = a.ub;
-  const T tol = (T)Tol<T>::kkt();
-  const T eact = (T)Tol<T>::act() * (ub - lb);
-  const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
-  if (a.du_mode && tid == 0) {
-    lb = (a.umin - uprev) > lb ? (a.umin - uprev) : lb;
-    ub = (a.umax - uprev) < ub ? (a.umax - uprev) : ub;
-  }
-  const T c0 = tclip(T(0), lb, ub);
-
-  // The tableau lives in registers.  N <= 24 (cfg1/2, reference dims): H itself stays in LDS (this lane's blocks at
-  // hb[r] + 8c) and is re-read for the few mat-vecs with H -- a second register copy costs 2 RM^2 VGPRs of the 128
-  // that four waves per SIMD allow, and the fused roll-out spilled because of it.  Longer horizons evaluate more
-  // line-search products per solve and keep the register copy (L = 8, N = 30: 209 vs 254 us per step).
-  constexpr bool HREG = N_ > 24;
-  T Tm[RM][RM], Hm[HREG ? RM : 1][HREG ? RM : 1];
-  int hb[RM];    // LDS element offset of H(ti+8r, tj), or -1 beyond N
-  bool cok[RM];  // column tj+8c exists
-#pragma unroll
-  for (int r = 0; r < RM; ++r) hb[r] = (ti + 8 * r < N_) ? (ti + 8 * r) * N_ + tj : -1;
-#pragma unroll
-  for (int c = 0; c < RM; ++c) cok[c] = tj + 8 * c < N_;
-  if constexpr (HREG) {
-#pragma unroll
-    for (int r = 0; r < RM; ++r)
-#pragma unroll
-      for (int c = 0; c < RM; ++c) Hm[r][c] = (hb[r] >= 0 && cok[c]) ? sH[hb[r] + 8 * c] : T(0);
-  }
-  auto Hel = [&](int r, int c) -> T {
-    if constexpr (HREG) return Hm[r][c];
-    else return (hb[r] >= 0 && cok[c]) ? sH[hb[r] + 8 * c] : T(0);
-  };
-#pragma unroll
-  for (int r = 0; r < RM; ++r)
-#pragma unroll
-    for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
-  const T fi = own ? sf[myvar] : T(0);
-  // row sums of |H| for the owner's variable: partial over my columns, 8-lane all-reduce,
-  // the owner of variable ti + 8*tj picks block row r = tj
-  T ra = T(0);
-  {
-    T pa[RM];
-#pragma unroll
-    for (int r = 0; r < RM; ++r) {
-      T s1 = T(0);
-#pragma unroll
-      for (int c = 0; c < RM; ++c) s1 += tabs(Hel(r, c));
-      pa[r] = allreduce8(s1);
-    }
-#pragma unroll
-    for (int r = 0; r < RM; ++r) if (tj == r) ra = pa[r];
-  }
-  const T gs = tabs(fi) + T(2) * ra * xmaxb;
-  // start: the previous minimiser when the handle keeps one, else clip(0) -- the reference's start (its
-  // pastRes_loc is never updated: zeros at every step, duffing.py:634-635, 859).  The minimiser is unique: the
-  // start only changes the work.
-  T x = own ? (a.x_warm ? tclip(xw_pre, lb, ub) : c0) : T(0);  // (xw_pre: requested before the H / f pass)
-  T hx = T(0);  // H x at the start (x need not be uniform: the first variable's box may differ)
-  {
-    T xc[RM];
-#pragma unroll
-    for (int c = 0; c < RM; ++c) xc[c] = __shfl(x, tj * 8 + c, 64);
-#pragma unroll
-    for (int r = 0; r < RM; ++r) {
-      T s0 = T(0);
-#pragma unroll
-      for (int c = 0; c < RM; ++c) s0 += Hel(r, c) * xc[c];
-      s0 = allreduce8(s0);
-      if (tj == r) hx = s0;
-    }
-    if (!own) hx = T(0);
-  }
-  T p0 = own ? x * (hx + fi) : T(0);
-  T J0 = wave_sum(p0);
-  const unsigned long long ownmask = __ballot(own);
-  unsigned long long Smask = 0ull;  // lane-space mask of the variables swept into T
-  int it = 0, status = 1, refresh = 0, polish = 0;
-  KTRACE(8);
-
-  while (true) {
-    T g = T(0);
-    bool bad = false, inI = false, loose = false;
-    if (own) {
-      g = T(2) * hx + fi;
-      const bool atl = x <= lb + eact, atu = x >= ub - eact;
-      inI = (atl && (g > T(0))) || (atu && (g < T(0)));
-      // KKT violation in gradient units: |g| inside the box, the wrong-signed part of g on a bound
-      const T viol = inI ? T(0) : tabs(g);
-      const T res = tabs(x - tclip(x - g, lb, ub));  // what a projected gradient step would still move
-      const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
-      bad = !((viol <= tol * gs) || (res <= tol * xs));
-      loose = viol > (T)Tol<T>::tight() * gs;
-    }
-    const unsigned long long Bmask = __ballot(bad);
-    const bool refine = __ballot(loose) != 0ull;
-    const unsigned long long Imask = __ballot(inI);
-    if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
-    // The KKT test certifies, it does not define the answer.  A point that passes it only loosely (after a
-    // damped or clipped step, or after a Newton step with a tableau that many set changes have worn) gets up
-    // to two more Newton solves on its face -- iterative refinement -- so that the result does not depend on
-    // the path (cold or warm start) beyond rounding.  A warm start itself is never returned unsolved.
-    if (Bmask == 0ull && (it > 0 || !a.x_warm)) {
-      if (!refine || polish >= 2) { status = 0; break; }
-      ++polish;
-    }
-    if (it >= a.max_iter || refresh > 4) { status = 1; break; }
-    // Safeguard: projected Newton can crawl (tiny Armijo steps) on ill-conditioned, almost fully saturated
-    // problems; after N+10 iterations the caller finishes the solve from the current point with the
-    // active-set method of qp_lds (rare: ~4e-5 of the QPs of the cfg3-sized closed loop).
-    if (it >= N_ + 10) { status = 3; break; }
-    unsigned long long Fmask = ~Imask & ownmask;
-    if (it == 0) KTRACE(9);
-
-    bool broke = false;
-    for (int pass = 0; pass < 2; ++pass) {
-      const unsigned long long diff = Smask ^ Fmask;
-      // One straight-line block per variable, in owner-lane order ((k&7)*8 + (k>>3), the order of the bit scan):
-      // with k a compile-time constant the block index, the pivot lane and the owner tests fold, and the tableau
-      // stays in the same registers from block to block (a run-time switch over the block index cost ~20 register
-      // moves per sweep).  Blocks of variables that do not change sides are skipped by a uniform branch.
-#pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
-#pragma unroll
-        for (int kr = 0; kr < RM; ++kr) {
-          if (kt + 8 * kr < N_) {
-            const int kl = kt * 8 + kr;
-            if ((diff >> kl) & 1ull) {
-              const bool rev = (Smask >> kl) & 1ull;
-              const T d = lane_bcast(Tm[kr][kr], kt * 9);
-              if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
-                broke = true;
-                if (pass == 1) Fmask &= ~(1ull << kl);
-              } else {
-                sweep_regs_at<T, N_>(Tm, kr, kt, rev, d, ti, tj);
-                Smask ^= (1ull << kl);
-              }
-            }
-          }
-        }
-      }
-      if (!broke || pass == 1) break;
-      ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
-#pragma unroll
-      for (int r = 0; r < RM; ++r)
-#pragma unroll
-        for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
-      Smask = 0ull;
-    }
-    Fmask = Smask;
-    if (it == 0) KTRACE(10);
-
-    // Newton direction on F: p_i = sum_{j in F} T_ij g_j ; straight to the bound on I
-    const bool isF = own && ((Fmask >> tid) & 1ull);
-    const T gm = isF ? g : T(0);
-    T pdir = T(0);
-    {
-      T gc[RM];
-#pragma unroll
-      for (int c = 0; c < RM; ++c) gc[c] = __shfl(gm, tj * 8 + c, 64);  // owner of variable tj + 8c
-#pragma unroll
-      for (int r = 0; r < RM; ++r) {
-        T s0 = T(0);
-#pragma unroll
-        for (int c = 0; c < RM; ++c) s0 += Tm[r][c] * gc[c];
-        s0 = allreduce8(s0);
-        if (tj == r) pdir = s0;
-      }
-    }
-    if (!isF) pdir = own ? ((g > T(0) ? lb : (g < T(0) ? ub : x)) - x) : T(0);
-
-    if (it == 0) KTRACE(11);
-    // projected Armijo search on the true cost
-    T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
-    while (true) {
-      xa = own ? tclip(x + alpha * pdir, lb, ub) : T(0);
-      T xc[RM];
-#pragma unroll
-      for (int c = 0; c < RM; ++c) xc[c] = __shfl(xa, tj * 8 + c, 64);
-#pragma unroll
-      for (int r = 0; r < RM; ++r) {
-        T s0 = T(0);
-#pragma unroll
-        for (int c = 0; c < RM; ++c) s0 += Hel(r, c) * xc[c];
-        s0 = allreduce8(s0);
-        if (tj == r) hxa = s0;
-      }
-      T pJa = own ? xa * (hxa + fi) : T(0);
-      T pdec = own ? (isF ? alpha * (-g * pdir) : g * (x - xa)) : T(0);
-      block_sum2<T, 64>(pJa, pdec, red);
-      Ja = pJa;
-      const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
-      if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
-      alpha *= T(0.25);
-    }
-    x = xa;
-    hx = hxa;
-    J0 = Ja;
-    if (it == 0) KTRACE(12);
-    ++it;
-  }
-  KTRACE(13);
-#ifdef KMPC_TRACE
-  if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + 15] = (unsigned long long)it;
-#endif
-
-  // non-finite problem data (status 2): the point handed back is the feasible start clip(0), never a NaN -- the
-  // plant state and the next warm start stay finite and the caller sees the status
-  if (status == 2) x = own ? c0 : T(0);
-  if (status == 3) {  // hand the current point to the active-set solver
-    if (own) qx_out[myvar] = x;
-    return true;
-  }
-  const int B = a.B;
-  if (own) {
-    if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
-    if (a.x_warm) a.x_warm[(size_t)myvar * B + b] = x;
-  }
-  if (tid == 0) {  // lane 0 owns variable 0
-    const T uout = a.du_mode ? uprev + x : x;  // U0 = U0 + dU*(1)   (Tank_System.m:192)
-    if (sv.U0) sv.U0[b] = uout;
-    if (a.u_store) a.u_store[b] = uout;
-    if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
-      // fused roll-out: x_k waits in the workgroup's LDS slot (no HBM round trip at the end of the step)
-      T x1 = sv.x_next ? sv.x_next[0] : a.X_rw[b], x2 = sv.x_next ? sv.x_next[1] : a.X_rw[(size_t)B + b];
-      plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
-      a.X_rw[b] = x1;
-      a.X_rw[(size_t)B + b] = x2;
-      if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
-    }
-    if (sv.x_next) {  // ... and the status / iteration counters are accumulated next to it, written once at the end
-      int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
-      acc[0] = acc[0] > status ? acc[0] : status;
-      acc[1] += it;
-    } else {
-      if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
-      if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
-    }
-  }
-  KTRACE(14);
-  return false;
-}
-
-// ---------------------------------------------------------------------------------------
-// Register-tableau box QP for four-wave trajectories (compile-time N <= 64, 256 threads; cfg5 sizes N = 50).
-// Same method and the same decisions as qp_regs; the 256 threads form a 16 x 16 grid (ti = tid >> 4, tj = tid & 15),
-// thread (ti, tj) keeps T(ti+16r, tj+16c) and H(ti+16r, tj+16c) in registers, variable i is owned by thread
-// (i & 15, i >> 4).  The threads of a grid row are the 16 lanes of a DPP row, so mat-vec partial sums are all-reduced
-// with DPP; what crosses waves goes through LDS: the pivot row / column of a sweep (double-buffered: one barrier per
-// sweep instead of the two barriers and the N^2 LDS read-modify-writes of the LDS tableau), the vector of a mat-vec,
-// the variable sets (64-bit masks assembled with LDS atomics).
-// ---------------------------------------------------------------------------------------
-template <typename T> __device__ __forceinline__ T dpp_row_mirror(T v);
-template <> __device__ __forceinline__ double dpp_row_mirror<double>(double v) {
-  return __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x140, 0xf, 0xf, true),
-                          __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x140, 0xf, 0xf, true));
-}
-template <> __device__ __forceinline__ float dpp_row_mirror<float>(float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x140, 0xf, 0xf, true));
-}
-template <typename T> __device__ __forceinline__ T allreduce16(T v) {
-  v = allreduce8(v);
-  v += dpp_row_mirror<T>(v);
-  return v;
-}
-
-template <typename T, int N_, int KR>
-__device__ __forceinline__ void sweep_put256(const T (&Tm)[(N_ + 15) / 16][(N_ + 15) / 16], int kt, int ti, int tj, T* col, T* row) {
-  constexpr int RM = (N_ + 15) / 16;
-  if (tj == kt) {
-#pragma unroll
-    for (int r = 0; r < RM; ++r) col[ti + 16 * r] = Tm[r][KR];
-  }
-  if (ti == kt) {
-#pragma unroll
-    for (int c = 0; c < RM; ++c) row[tj + 16 * c] = Tm[KR][c];
-  }
-}
-template <typename T, int N_, int KR>
-__device__ __forceinline__ void sweep_regs256(T (&Tm)[(N_ + 15) / 16][(N_ + 15) / 16], int kt, bool rev, T d, int ti, int tj,
-                                              const T* col, const T* row) {
-  constexpr int RM = (N_ + 15) / 16;
-  const T dinv = fast_rcp(d);
-  const T s = rev ? T(-1) : T(1);
-  T ct[RM], rt[RM];
-#pragma unroll
-  for (int r = 0; r < RM; ++r) ct[r] = col[ti + 16 * r];            // T(ti+16r, k)
-#pragma unroll
-  for (int c = 0; c < RM; ++c) rt[c] = row[tj + 16 * c] * dinv;     // T(k, tj+16c) / d
-  if (ti == kt) {  // this thread holds row k in block row KR (see sweep_regs for the edited-input form)
-    ct[KR] = -s;
-#pragma unroll
-    for (int c = 0; c < RM; ++c) Tm[KR][c] = T(0);
-  }
-  if (tj == kt) {
-    rt[KR] = -s * dinv;
-#pragma unroll
-    for (int r = 0; r < RM; ++r) Tm[r][KR] = T(0);
-  }
-#pragma unroll
-  for (int r = 0; r < RM; ++r)
-#pragma unroll
-    for (int c = 0; c < RM; ++c) Tm[r][c] -= ct[r] * rt[c];
-}
-
-template <typename T, int N_>
-__device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
-                                           T* red, T* work, T* qx_out, T up) {
-  constexpr int RM = (N_ + 15) / 16;
-  const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
-  const int myvar = ti + 16 * tj;
-  const bool own = (tj < RM) && (myvar < N_);
-  T* const qv = work;             // 64: the vector of a mat-vec, by variable
-  T* const colb = work + 64;      // 2 x 64: pivot column of a sweep (double-buffered)
-  T* const rowb = work + 192;     // 2 x 64: pivot row
-  unsigned long long* const smk = reinterpret_cast<unsigned long long*>(work + 320);  // 3 variable sets
-  const T uprev = a.du_mode ? up : T(0);
-  T lb = a.lb, ub = a.ub;
-  const T tol = (T)Tol<T>::kkt();
-  const T eact = (T)Tol<T>::act() * (ub - lb);
-  const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
-  if (a.du_mode && tid == 0) {  // first increment: absolute input range folded in (Tank_System.m:182-188)
-    lb = (a.umin - uprev) > lb ? (a.umin - uprev) : lb;
-    ub = (a.umax - uprev) < ub ? (a.umax - uprev) : ub;
-  }
-  const T c0 = tclip(T(0), lb, ub);
-
-  T Tm[RM][RM], Hm[RM][RM];
-#pragma unroll
-  for (int r = 0; r < RM; ++r)
-#pragma unroll
-    for (int c = 0; c < RM; ++c) {
-      const int i = ti + 16 * r, j = tj + 16 * c;
-      Hm[r][c] = (i < N_ && j < N_) ? sH[i * N_ + j] : T(0);
-      Tm[r][c] = T(2) * Hm[r][c];
-    }
-  const T fi = own ? sf[myvar] : T(0);
-  if (tid < 64) qv[tid] = T(0);  // (entries beyond N stay zero)
-  // y_i = sum_j M_ij v_j for the owner of variable i (v given by the owners)
-  auto matvec = [&](const T (&M)[RM][RM], T vin) -> T {
-    __syncthreads();  // the previous vector has been read
-    if (own) qv[myvar] = vin;
-    __syncthreads();
-    T xc[RM];
-#pragma unroll
-    for (int c = 0; c < RM; ++c) xc[c] = qv[tj + 16 * c];
-    T out = T(0);
-#pragma unroll
-    for (int r = 0; r < RM; ++r) {
-      T s0 = T(0);
-#pragma unroll
-      for (int c = 0; c < RM; ++c) s0 += M[r][c] * xc[c];
-      s0 = allreduce16(s0);
-      if (tj == r) out = s0;
-    }
-    return own ? out : T(0);
-  };
-  T ra = T(0);
-  {
-#pragma unroll
-    for (int r = 0; r < RM; ++r) {
-      T s1 = T(0);
-#pragma unroll
-      for (int c = 0; c < RM; ++c) s1 += tabs(Hm[r][c]);
-      s1 = allreduce16(s1);
-      if (tj == r) ra = s1;
-    }
-  }
-  const T gs = tabs(fi) + T(2) * ra * xmaxb;
-  T x = own ? (a.x_warm ? tclip(a.x_warm[(size_t)myvar * a.B + b], lb, ub) : c0) : T(0);
-  T hx = matvec(Hm, x);
-  T J0 = block_sum<T, 256>(own ? x * (hx + fi) : T(0), red);
-  unsigned long long Smask = 0ull;
-  int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0;
-
-  while (true) {
-    T g = T(0);
-    bool bad = false, inI = false, loose = false;
-    if (own) {
-      g = T(2) * hx + fi;
-      const bool atl = x <= lb + eact, atu = x >= ub - eact;
-      inI = (atl && (g > T(0))) || (atu && (g < T(0)));
-      const T viol = inI ? T(0) : tabs(g);
-      const T res = tabs(x - tclip(x - g, lb, ub));
-      const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
-      bad = !((viol <= tol * gs) || (res <= tol * xs));
-      loose = viol > (T)Tol<T>::tight() * gs;
-    }
-    __syncthreads();
-    if (tid < 3) smk[tid] = 0ull;
-    __syncthreads();
-    if (own) {
-      if (bad) atomicOr(&smk[0], 1ull << myvar);
-      if (loose) atomicOr(&smk[1], 1ull << myvar);
-      if (inI) atomicOr(&smk[2], 1ull << myvar);
-    }
-    __syncthreads();
-    const unsigned long long Bmask = smk[0], Imask = smk[2];
-    const bool refine = smk[1] != 0ull;
-    constexpr unsigned long long allmask = (N_ >= 64) ? ~0ull : ((1ull << N_) - 1ull);
-    if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
-    if (Bmask == 0ull && (it > 0 || !a.x_warm)) {  // (see qp_regs: a warm start is never returned unsolved)
-      if (!refine || polish >= 2) { status = 0; break; }
-      ++polish;
-    }
-    if (it >= a.max_iter || refresh > 4) { status = 1; break; }
-    if (it >= N_ + 10) { status = 3; break; }  // crawling: the active-set loop of qp_lds finishes from here
-    unsigned long long Fmask = ~Imask & allmask;
-
-    bool broke = false;
-    for (int pass = 0; pass < 2; ++pass) {
-      unsigned long long diff = Smask ^ Fmask;
-      while (diff) {
-        const int k = __ffsll((long long)diff) - 1;
-        diff &= diff - 1ull;
-        const int kt = k & 15, kr = k >> 4;
-        const bool rev = (Smask >> k) & 1ull;
-        T* const col = colb + (nsw & 1) * 64;
-        T* const row = rowb + (nsw & 1) * 64;
-        ++nsw;
-        switch (kr) {
-          case 0: sweep_put256<T, N_, 0>(Tm, kt, ti, tj, col, row); break;
-          case 1: if constexpr (RM > 1) sweep_put256<T, N_, 1>(Tm, kt, ti, tj, col, row); break;
-          case 2: if constexpr (RM > 2) sweep_put256<T, N_, 2>(Tm, kt, ti, tj, col, row); break;
-          default: if constexpr (RM > 3) sweep_put256<T, N_, 3>(Tm, kt, ti, tj, col, row); break;
-        }
-        __syncthreads();
-        const T d = col[k];  // T(k, k)
-        if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
-          broke = true;
-          if (pass == 1) Fmask &= ~(1ull << k);
-          continue;
-        }
-        switch (kr) {
-          case 0: sweep_regs256<T, N_, 0>(Tm, kt, rev, d, ti, tj, col, row); break;
-          case 1: if constexpr (RM > 1) sweep_regs256<T, N_, 1>(Tm, kt, rev, d, ti, tj, col, row); break;
-          case 2: if constexpr (RM > 2) sweep_regs256<T, N_, 2>(Tm, kt, rev, d, ti, tj, col, row); break;
-          default: if constexpr (RM > 3) sweep_regs256<T, N_, 3>(Tm, kt, rev, d, ti, tj, col, row); break;
-        }
-        Smask ^= (1ull << k);
-      }
-      if (!broke || pass == 1) break;
-      ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
-#pragma unroll
-      for (int r = 0; r < RM; ++r)
-#pragma unroll
-        for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hm[r][c];
-      Smask = 0ull;
-    }
-    Fmask = Smask;
-
-    // Newton direction on F, straight to the bound on I
-    const bool isF = own && ((Fmask >> myvar) & 1ull);
-    T pdir = matvec(Tm, isF ? g : T(0));
-    if (!isF) pdir = own ? ((g > T(0) ? lb : (g < T(0) ? ub : x)) - x) : T(0);
-
-    // projected Armijo search on the true cost
-    T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
-    while (true) {
-      xa = own ? tclip(x + alpha * pdir, lb, ub) : T(0);
-      hxa = matvec(Hm, xa);
-      T pJa = own ? xa * (hxa + fi) : T(0);
-      T pdec = own ? (isF ? alpha * (-g * pdir) : g * (x - xa)) : T(0);
-      block_sum2<T, 256>(pJa, pdec, red);
-      Ja = pJa;
-      const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
-      if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
-      alpha *= T(0.25);
-    }
-    x = xa;
-    hx = hxa;
-    J0 = Ja;
-    ++it;
-  }
-  if (status == 2) x = own ? c0 : T(0);  // (see qp_regs: non-finite data never leaves as a NaN input)
-  if (status == 3) {
-    __syncthreads();
-    if (own) qx_out[myvar] = x;
-    return true;
-  }
-  const int B = a.B;
-  if (own) {
-    if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
-    if (a.x_warm) a.x_warm[(size_t)myvar * B + b] = x;
-  }
-  if (tid == 0) {  // thread 0 owns variable 0
-    const T uout = a.du_mode ? uprev + x : x;
-    if (sv.U0) sv.U0[b] = uout;
-    if (a.u_store) a.u_store[b] = uout;
-    if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
-      T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
-      plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
-      a.X_rw[b] = x1;
-      a.X_rw[(size_t)B + b] = x2;
-    }
-    if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
-    if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
-  }
-  return false;
-}
-
-// ---------------------------------------------------------------------------------------
-// LDS-tableau box QP (run-time N <= 64, 64 or 256 threads): the generic solver, and the safeguard the
-// register solver falls back to.  Projected Newton on the swept tableau in LDS; when it crawls
-// (N+10 iterations or 2N Armijo backtracks) or when `as_from_start` is set the loop continues as a PRIMAL
-// ACTIVE-SET method on the same tableau: Newton direction on the free set, ratio test to the first blocking
-// bound, one wrong-signed multiplier released per minimiser -- monotone and finite for a strictly convex QP.
-// ---------------------------------------------------------------------------------------
-template <typename T, int TPB>
-__device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T* qxa, T* qg, T* red,
-                                       const StepArgs<T>& a, const StepVar<T>& sv, int b, int N, bool as_from_start) {
-  const int tid = local_tid<TPB>(), B = a.B;
-  const T uprev = a.du_mode ? a.u_prev[b] : T(0);
-  T lb = a.lb, ub = a.ub;
-  const T tol = (T)Tol<T>::kkt();
-  const T eact = (T)Tol<T>::act() * (ub - lb);
-  const T xmaxb = tabs(lb) > tabs(ub) ? tabs(lb) : tabs(ub);
-  if (a.du_mode && tid == 0) {  // first increment: absolute input range folded in (Tank_System.m:182-188)
-    lb = (a.umin - uprev) > lb ? (a.umin - uprev) : lb;
-    ub = (a.umax - uprev) < ub ? (a.umax - uprev) : ub;
-  }
-  const T c0 = tclip(T(0), lb, ub);
-  constexpr int TS = (TPB == 64) ? 8 : 16;  // 2-D thread tile of the sweeps
-  constexpr int RMAX = 64 / TS;             // rows / columns per thread (N <= 64)
-  const int ti = tid / TS, tj = tid % TS;
-  const bool mine = tid < N;  // thread i < N owns variable i (N <= 64 <= TPB)
-  const unsigned long long allmask = (N >= 64) ? ~0ull : ((1ull << N) - 1ull);
-  unsigned long long* const smask = reinterpret_cast<unsigned long long*>(red + 8);
-  T* const sval = red + 12;  // broadcast slot for wave-0 scalars (256-thread blocks)
-
-  T gs = T(1);
-  if (mine) {
-    T ra = T(0);
-    for (int j = 0; j < N; ++j) ra += tabs(sH[j * N + tid]);
-    gs = tabs(sf[tid]) + T(2) * ra * xmaxb;  // magnitude of the terms of the gradient
-    // start: clip(0) as the reference (duffing.py:634-635), or the point the register solver handed over
-    qx[tid] = as_from_start ? tclip(qx[tid], lb, ub) : (a.x_warm ? tclip(a.x_warm[(size_t)tid * B + b], lb, ub) : c0);
-  }
-  for (int i = ti; i < N; i += TS)
-    for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
-  block_sync<TPB>();
-  T x = mine ? qx[tid] : T(0), hx = T(0);
-  if (mine) {  // H x at the start (x need not be uniform: the first variable's box may differ)
-    for (int j = 0; j < N; ++j) hx += sH[j * N + tid] * qx[j];
-  }
-  T J0 = block_sum<T, TPB>(mine ? x * (hx + sf[tid]) : T(0), red);
-
-  unsigned long long Smask = 0ull;  // variables currently swept into T
-  unsigned long long Wmask = 0ull;  // active-set mode: variables held at a bound
-  int it = 0, status = 1, refresh = 0, polish = 0;
-  bool mode_as = false, at_min = false;
-
-  // every thread gets wave 0's value of a block-uniform quantity
-  auto bcast_mask = [&](unsigned long long m) -> unsigned long long {
-    if (TPB == 64) return m;
-    block_sync<TPB>();
-    if (tid == 0) smask[0] = m;
-    block_sync<TPB>();
-    return smask[0];
-  };
-  auto bcast_val = [&](T v) -> T {
-    if (TPB == 64) return v;
-    block_sync<TPB>();
-    if (tid == 0) sval[0] = v;
-    block_sync<TPB>();
-    return sval[0];
-  };
-
-  while (true) {
-    // ---- gradient, KKT residual, natural bound set
-    T g = T(0);
-    bool bad = false, inI = false, loose = false;
-    if (mine) {
-      g = T(2) * hx + sf[tid];
-      const bool atl = x <= lb + eact, atu = x >= ub - eact;
-      inI = (atl && (g > T(0))) || (atu && (g < T(0)));
-      const T viol = inI ? T(0) : tabs(g);  // KKT violation in gradient units
-      const T res = tabs(x - tclip(x - g, lb, ub));
-      const T xs = tabs(x) > T(1) ? tabs(x) : T(1);
-      bad = !((viol <= tol * gs) || (res <= tol * xs));
-      loose = viol > (T)Tol<T>::tight() * gs;
-    }
-    const unsigned long long Bmask = bcast_mask(__ballot(bad));  // wave 0 holds every variable (N <= 64)
-    const bool refine = bcast_mask(__ballot(loose)) != 0ull;
-    const unsigned long long Imask = bcast_mask(__ballot(inI));
-    if (!(J0 == J0) || tabs(J0) > (T)1e300) { status = 2; break; }
-    if (Bmask == 0ull && (it > 0 || as_from_start || !a.x_warm)) {  // see qp_regs
-      if (!refine || mode_as || polish >= 2) { status = 0; break; }
-      ++polish;
-    }
-    if (it >= a.max_iter || refresh > 4) { status = 1; break; }
-    if (!mode_as && (as_from_start || it >= N + 10)) {
-      mode_as = true;
-      at_min = false;
-      Wmask = Imask;
-    }
-    if (mode_as && at_min) {  // x minimises the cost on the free set: release the worst wrong-signed multiplier
-      const bool inW = (Wmask >> tid) & 1ull;
-      const T vr = (mine && inW && !inI) ? tabs(g) / gs : T(0);
-      const T vmax = bcast_val(wave_max_x(vr));
-      const unsigned long long cand = bcast_mask(__ballot(mine && vr == vmax));
-      if (vmax > tol) Wmask &= ~(1ull << (__ffsll((long long)cand) - 1));
-      at_min = false;
-    }
-    unsigned long long Fmask = (mode_as ? ~Wmask : ~Imask) & allmask;
-
-    // ---- bring T to the free set: one symmetric sweep per changed variable
-    bool broke = false;
-    for (int pass = 0; pass < 2; ++pass) {
-      unsigned long long diff = Smask ^ Fmask;
-      while (diff) {
-        const int k = __ffsll((long long)diff) - 1;
-        diff &= diff - 1ull;
-        const bool rev = (Smask >> k) & 1ull;
-        const T piv = sM[k * N + k];
-        if (!((rev ? -piv : piv) > T(0))) {  // numerical breakdown of the tableau
-          broke = true;
-          if (pass == 1) Fmask &= ~(1ull << k);  // clean rebuild: keep this variable fixed this iteration
-          continue;
-        }
-        const T dinv = T(1) / piv;
-        T rj[RMAX];  // this thread's columns of pivot row k
-#pragma unroll
-        for (int c = 0; c < RMAX; ++c) {
-          const int j = tj + c * TS;
-          rj[c] = (j < N && j != k) ? sM[k * N + j] : T(0);
-        }
-#pragma unroll
-        for (int r = 0; r < RMAX; ++r) {
-          const int i = ti + r * TS;
-          if (i < N && i != k) {
-            const T ci = sM[k * N + i] * dinv;
-#pragma unroll
-            for (int c = 0; c < RMAX; ++c) {
-              const int j = tj + c * TS;
-              if (j < N && j != k) sM[i * N + j] -= ci * rj[c];
-            }
-          }
-        }
-        block_sync<TPB>();
-        if (mine) {
-          if (tid == k) {
-            sM[k * N + k] = -dinv;
-          } else {
-            const T v = sM[k * N + tid] * (rev ? -dinv : dinv);
-            sM[k * N + tid] = v;
-            sM[tid * N + k] = v;
-          }
-        }
-        block_sync<TPB>();
-        Smask ^= (1ull << k);
-      }
-      if (!broke || pass == 1) break;
-      ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
-      for (int i = ti; i < N; i += TS)
-        for (int j = tj; j < N; j += TS) sM[i * N + j] = T(2) * sH[i * N + j];
-      block_sync<TPB>();
-      Smask = 0ull;
-    }
-    Fmask = Smask;  // what is actually swept (a variable whose pivot broke down stays fixed)
-
-    // ---- direction: Newton on F (T_FF = -(2H_FF)^-1) as a mat-vec with the masked gradient
-    const bool isF = mine && ((Fmask >> tid) & 1ull);
-    if (mine) qg[tid] = isF ? g : T(0);
-    block_sync<TPB>();
-    T pdir = T(0);
-    if (isF) {
-      for (int j = 0; j < N; ++j) pdir += sM[j * N + tid] * qg[j];
-    } else if (mine && !mode_as) {
-      pdir = (g > T(0) ? lb : (g < T(0) ? ub : x)) - x;  // projected Newton: straight to the bound on I
-    }
-
-    T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
-    bool one_shot = false;
-    int jb = -1;
-    if (mode_as) {
-      // ratio test: the largest step along the Newton direction that keeps the free variables inside the box
-      T al = (T)1e300;
-      if (isF && pdir < T(0) && x + pdir < lb) al = (lb - x) / pdir;
-      if (isF && pdir > T(0) && x + pdir > ub) al = (ub - x) / pdir;
-      const T amin = bcast_val(wave_min_x(al));
-      alpha = amin < T(1) ? (amin > T(0) ? amin : T(0)) : T(1);
-      if (amin < T(1)) {
-        const unsigned long long cand = bcast_mask(__ballot(mine && al == amin));
-        jb = __ffsll((long long)cand) - 1;
-        Wmask |= (1ull << jb);
-      } else {
-        at_min = true;
-      }
-      one_shot = true;
-    }
-    // ---- projected Armijo search on the true cost (active-set mode: one evaluation at the ratio-test step)
-    while (true) {
-      if (mine) {
-        xa = tclip(x + alpha * pdir, lb, ub);
-        if (tid == jb) xa = pdir < T(0) ? lb : ub;  // the blocking variable sits exactly on its bound
-        qxa[tid] = xa;
-      }
-      block_sync<TPB>();
-      T pJa = T(0), pdec = T(0);
-      if (mine) {
-        hxa = T(0);
-        for (int j = 0; j < N; ++j) hxa += sH[j * N + tid] * qxa[j];
-        pJa = xa * (hxa + sf[tid]);
-        pdec = isF ? alpha * (-g * pdir) : g * (x - xa);
-      }
-      block_sum2<T, TPB>(pJa, pdec, red);
-      Ja = pJa;
-      const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
-      if (one_shot || (J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
-      alpha *= T(0.25);
-      block_sync<TPB>();
-    }
-    x = xa;
-    hx = hxa;
-    J0 = Ja;
-    ++it;
-  }
-  if (status == 2) x = c0;  // (see qp_regs: non-finite data never leaves as a NaN input)
-  if (mine) qx[tid] = x;
-  block_sync<TPB>();
-
-  if (mine) {
-    if (a.Useq) a.Useq[(size_t)tid * B + b] = qx[tid];
-    if (a.x_warm) a.x_warm[(size_t)tid * B + b] = qx[tid];
-  }
-  if (tid == 0) {
-    const T uout = a.du_mode ? uprev + qx[0] : qx[0];
-    if (sv.U0) sv.U0[b] = uout;
-    if (a.u_store) a.u_store[b] = uout;
-    if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
-      // fused roll-out: x_k waits in the workgroup's LDS slot (no HBM round trip at the end of the step)
-      T x1 = sv.x_next ? sv.x_next[0] : a.X_rw[b], x2 = sv.x_next ? sv.x_next[1] : a.X_rw[(size_t)B + b];
-      plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
-      a.X_rw[b] = x1;
-      a.X_rw[(size_t)B + b] = x2;
-      if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
-    }
-    if (sv.x_next) {  // ... and the status / iteration counters are accumulated next to it, written once at the end
-      int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
-      acc[0] = acc[0] > status ? acc[0] : status;
-      acc[1] += it;
-    } else {
-      if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
-      if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
-    }
-  }
-}
-
-// L_, N_, Q_ != 0: dimensions fixed at compile time (every inner loop unrolls, index math folds);
-// 0: taken from the arguments at run time (generic fallback, same source).
-// Four waves per SIMD (<= 128 VGPRs) for the small static configurations: BASELINE cfg2 puts exactly 4096
-// trajectories = 4 waves per SIMD on the chip, so one register too many costs a whole second round.
-template <typename T, int TPB, int L_, int N_, int Q_>
-__device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>& sv, const int b, T* const sm) {
-  const int tid = local_tid<TPB>();
-  // y = C x has q = rows of C <= n < L outputs, y = psi has q = L: with static dimensions the output kind is known
-  // at compile time and the other variant's code disappears (Q_ == L_ only in the lifted-output instantiations)
-  const bool out_cx = (Q_ > 0 && L_ > 0) ? (Q_ != L_) : (a.out_kind == OUT_CX);
-  const int n = a.n, L = L_ ? L_ : a.L, p = L + 1, q = Q_ ? Q_ : a.q, N = N_ ? N_ : a.N, B = a.B;
-
-  T* const sX = sm;            // P / bar_Q / H
-  T* const sY = sX + a.r1;     // K, C / elimination matrix
-  T* const sK = sY;
-  T* const sC = sY + L * p;
-  T* const sH = sX;
-  T* const sM = sY;
-  T* const vec = sY + a.r2;
-  T* const red = vec;          // 16  reduction scratch (+ the 64-bit set mask at red[8])
-  T* const sf = red + 16;      // N   (lives condense -> QP)
-  T* const va = sf + N;        // aliased vector sets
-  // set A (RLS + condense)
-  T* const sz = va;            // p
-  T* const sPz = sz + p;       // p
-  T* const sy = sPz + p;       // L   psi_now
-  T* const sE = sy + L;        // L
-  T* const sV = sE + L;        // 2L
-  T* const sW = sV + 2 * L;    // 2L
-  T* const sx = sW + 2 * L;    // n
-  T* const sG = sx + n;        // N*q
-  T* const sEr = sG + N * q;   // N*q
-  // set B (QP)
-  T* const qx = va;
-  T* const qxa = qx + N;
-  T* const qg = qxa + N;
-
-    KTRACE(0);
-  // requested before anything waits: the previous input (RLS regressor, delta-u form) and -- static sizes -- the
-  // reference, which the condense phase needs only after the state has been written back (requested there, the
-  // load sat behind the round trip of those stores)
-  const T up = a.u_prev[b];
-  T xw_pre = T(0);
-  constexpr int REFN = (Q_ > 0 && N_ > 0 && Q_ * N_ <= 4 * TPB) ? (Q_ * N_ + TPB - 1) / TPB : 0;
-  T refp[REFN > 0 ? REFN : 1];
-  if constexpr (REFN > 0) {
-    if (sv.phases & PH_CONDENSE) {
-      const T* refg = a.ref + (a.ref_per_traj ? (size_t)b * q * N : 0);
-#pragma unroll
-      for (int i = 0; i < REFN; ++i) {
-        const int e = tid + i * TPB, ec = e < q * N ? e : 0, k = ec / q, r = ec - k * q;
-        refp[i] = refg[r * N + k];
-      }
-    }
-  }
-
-  // =====================================================================================
-  // phase 1: recursive least squares (gain form; algebraically K_A inv_K_G of the reference)
-  // =====================================================================================
-  if (sv.phases & PH_RLS) {
-    const T* Pg = a.P + (size_t)b * a.strideP;
-    T* Kg = a.K + (size_t)b * a.strideK;
-    // Every HBM request of the phase is issued before the first wait, in the order the data is needed (vector memory
-    // returns in order): the step's small inputs, P and K, then -- static sizes -- bar_Q and C, which wait in registers
-    // until the first half of the update is done with the LDS region they go to.  All of them are UNCONDITIONAL loads
-    // with clamped indices: a load that is skipped on some lanes and replaced by a zero there makes the compiler wait
-    // for every outstanding load before it may write that zero (the phase used to start with three serialised memory
-    // round trips because of this), and costs a masked region of four scalar instructions per load.
-    const int il = tid < L ? tid : L - 1, in = tid < n ? tid : n - 1;  // (L <= 64 <= TPB: one element per thread)
-    const T zp = sv.psi_in_regs ? sv.psi_prev_v : sv.psi_prev[il * a.pp_sl + b * a.pp_sb];
-    const T yp = sv.psi_in_regs ? sv.psi_now_v : sv.psi_now[il * a.pn_sl + b * a.pn_sb];
-    const T xp = a.x_now[(size_t)in * B + b];
-    constexpr int PP_ = L_ > 0 ? (L_ + 1) * (L_ + 1) : 0, LP_ = L_ > 0 ? L_ * (L_ + 1) : 0, LL_ = L_ * L_;
-    constexpr bool STATE_REGS = L_ > 0 && (PP_ + TPB - 1) / TPB <= 17;
-    T pr[STATE_REGS ? (PP_ + TPB - 1) / TPB : 1], kr[STATE_REGS ? (LP_ + TPB - 1) / TPB : 1];
-    if constexpr (STATE_REGS) {
-      for_strided<TPB, PP_>(tid, p * p, [&](int e, int i) { pr[i] = Pg[e]; });
-      for_strided<TPB, LP_>(tid, L * p, [&](int e, int i) { kr[i] = Kg[e]; });
-    }
-    constexpr int QPRE = (L_ > 0) ? (L_ * L_ + TPB - 1) / TPB : 0;
-    constexpr bool PREFETCH = (L_ > 0) && (QPRE <= 17);
-    T qpre[PREFETCH ? QPRE : 1], cpre[PREFETCH ? 2 : 1];
-    if constexpr (PREFETCH) {
-      if (out_cx) {
-        const T* Qg0 = a.Qb + (size_t)b * a.strideQ;
-        const T* Cg0 = a.C + (size_t)b * a.strideC;
-#pragma unroll
-        for (int i = 0; i < QPRE; ++i) {
-          const int e = tid + i * TPB;
-          qpre[i] = Qg0[e < L * L ? e : L * L - 1];
-        }
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const int e = tid + i * TPB;
-          cpre[i] = Cg0[e < n * L ? e : 0];  // (first update: replaced by zero when it goes to LDS)
-        }
-      }
-    }
-    if (tid < L) { sz[tid] = zp; sy[tid] = yp; }
-    if (tid == 0) sz[L] = up;
-    if (tid < n) sx[tid] = xp;
-    if constexpr (STATE_REGS) {
-      const bool fu = sv.first_update != 0;
-      for_strided<TPB, PP_>(tid, p * p, [&](int e, int i) { sX[e] = pr[i]; });
-      for_strided<TPB, LP_>(tid, L * p, [&](int e, int i) { sK[e] = fu ? T(0) : kr[i]; });
-    } else {
-      for (int e = tid; e < p * p; e += TPB) sX[e] = Pg[e];
-      if (sv.first_update) {
-        for (int e = tid; e < L * p; e += TPB) sK[e] = T(0);
-      } else {
-        for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
-      }
-    }
-    block_sync<TPB>();
-    KTRACE(1);
-
-    // Pz (P symmetric: column walk is conflict-free in LDS)
-    for (int i = tid; i < p; i += TPB) {
-      T acc = T(0);
-#pragma unroll
-      for (int j = 0; j < p; ++j) acc += sX[j * p + i] * sz[j];
-      sPz[i] = acc;
-    }
-    block_sync<TPB>();
-    T part = T(0);
-    for (int i = tid; i < p; i += TPB) part += sz[i] * sPz[i];
-    const T d = a.lam + block_sum<T, TPB>(part, red);
-    const T dinv = T(1) / d;
-    const T linv = T(1) / a.lam;
-    KTRACE(2);
-
-    // P <- (P - Pz Pz' / d) / lam                                   duffing.py:931-932
-    T* Pw = a.P + (size_t)b * a.strideP;
-    for_strided<TPB, PP_>(tid, p * p, [&](int e, int) {
-      const int i = e / p, j = e - i * p;
-      Pw[e] = (sX[e] - (sPz[i] * sPz[j]) * dinv) * linv;
-    });
-    // innovation  y - K z
-    for (int r = tid; r < L; r += TPB) {
-      T acc = sy[r];
-#pragma unroll
-      for (int j = 0; j < p; ++j) acc -= sK[r * p + j] * sz[j];
-      sE[r] = acc;
-    }
-    block_sync<TPB>();
-    // K <- K + (y - K z) g',  g = Pz / d                            duffing.py:927-938
-    for_strided<TPB, LP_>(tid, L * p, [&](int e, int) {
-      const int r = e / p, j = e - r * p;
-      const T v = sK[e] + sE[r] * (sPz[j] * dinv);
-      sK[e] = v;
-      Kg[e] = v;
-    });
-
-    KTRACE(3);
-    if (out_cx) {
-      // ---- C = bar_X bar_Q, target x_{k+1}, regressor psi(x_k)      duffing.py:943-953
-      const T* Qg = a.Qb + (size_t)b * a.strideQ;
-      T* Cg = a.C + (size_t)b * a.strideC;
-      block_sync<TPB>();  // everyone is done with P in sX and with sE / sPz
-      if (PREFETCH && n * L <= 2 * TPB) {
-        if constexpr (PREFETCH) {
-#pragma unroll
-          for (int i = 0; i < QPRE; ++i) {
-            const int e = tid + i * TPB;
-            if (e < L * L) sX[e] = qpre[i];
-          }
-#pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int e = tid + i * TPB;
-            if (e < n * L) sC[e] = sv.first_update ? T(0) : cpre[i];
-          }
-        }
-      } else {
-        for (int e = tid; e < L * L; e += TPB) sX[e] = Qg[e];
-        if (sv.first_update) {
-          for (int e = tid; e < n * L; e += TPB) sC[e] = T(0);
-        } else {
-          for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
-        }
-      }
-      block_sync<TPB>();
-      for (int i = tid; i < L; i += TPB) {
-        T acc = T(0);
-#pragma unroll
-        for (int j = 0; j < L; ++j) acc += sX[j * L + i] * sz[j];
-        sPz[i] = acc;
-      }
-      for (int r = tid; r < n; r += TPB) {
-        T acc = sx[r];
-        for (int j = 0; j < L; ++j) acc -= sC[r * L + j] * sz[j];
-        sE[r] = acc;
-      }
-      block_sync<TPB>();
-      T part2 = T(0);
-      for (int i = tid; i < L; i += TPB) part2 += sz[i] * sPz[i];
-      const T dc = a.lam + block_sum<T, TPB>(part2, red);
-      const T dcinv = T(1) / dc;
-      T* Qw = a.Qb + (size_t)b * a.strideQ;
-      for_strided<TPB, LL_>(tid, L * L, [&](int e, int) {
-        const int i = e / L, j = e - i * L;
-        Qw[e] = (sX[e] - (sPz[i] * sPz[j]) * dcinv) * linv;
-      });
-      for (int e = tid; e < n * L; e += TPB) {
-        const int r = e / L, j = e - r * L;
-        const T v = (a.c_skip_first && sv.first_update) ? T(0) : sC[e] + sE[r] * (sPz[j] * dcinv);
-        sC[e] = v;
-        Cg[e] = v;
-      }
-    }
-    block_sync<TPB>();
-    KTRACE(4);
-  } else if (sv.phases & PH_CONDENSE) {
-    const T* Kg = a.K + (size_t)b * a.strideK;
-    for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
-    if (out_cx) {
-      const T* Cg = a.C + (size_t)b * a.strideC;
-      for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
-    }
-    if (sv.psi_in_regs) { if (tid < L) sy[tid] = sv.psi_now_v; }
-    else for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
-    block_sync<TPB>();
-  }
-
-  // =====================================================================================
-  // phase 2: condensed QP  H = Qw Phi'Phi + Rw I,  f = 2 Qw Phi'(Gamma psi - r)
-  // =====================================================================================
-  if (sv.phases & PH_CONDENSE) {
-    const T* ref = a.ref + (a.ref_per_traj ? (size_t)b * q * N : 0);
-    const bool cx = out_cx;
-    for (int i = tid; i < L; i += TPB) {
-      sV[i] = sK[i * p + L];  // v_0 = B
-      sW[i] = sy[i];          // w_0 = psi(x_k)
-    }
-    if constexpr (REFN > 0) {  // sEr[k][r] starts as -r[r][k]
-#pragma unroll
-      for (int i = 0; i < REFN; ++i) {
-        const int e = tid + i * TPB;
-        if (e < q * N) sEr[e] = -refp[i];
-      }
-    } else {
-      for (int e = tid; e < q * N; e += TPB) {
-        const int k = e / q, r = e - k * q;
-        sEr[e] = -ref[r * N + k];
-      }
-    }
-    block_sync<TPB>();
-    KTRACE(5);
-    // v_{j+1} = A v_j, w_{j+1} = A w_j;  g_j = Co v_j;  e_j = Co w_j - r_{j-1}
-    if constexpr (L_ > 0 && TPB == 64 && (L_ + Q_ <= 32)) {
-      // Static path: lanes 0-31 run the v-chain, lanes 32-63 the w-chain.  Lane t of a half keeps row t
-      // of the stacked matrix [A; Co] in REGISTERS for the whole recursion; per step it only reads
-      // the current vector (broadcast LDS reads) -- the matrix is never re-read from LDS.
-      const int half = tid >> 5, t = tid & 31;
-      const int nco = cx ? q : 0;
-      const bool isA = t < L, isC = (t >= L) && (t < L + nco);
-      T row[L_];
-#pragma unroll
-      for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(a.cy0 + t - L) * L + l] : T(0));
-      // delta-u form (Tank_System.m:110-113): the augmented state [x; u_prev] propagates as
-      // x+ = A x + B s with s = 1 on the v-chain (B~ = [B; 1]) and s = u_prev on the w-chain
-      const T bs = (a.du_mode && isA) ? sK[t * p + L] * (half ? up : T(1)) : T(0);
-      if (!cx && half == 0 && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
-      if constexpr (sizeof(T) == 8) {
-        // float64: the vector stays in the lanes (DPP row broadcast + one cross-row swap per step); LDS only
-        // receives the outputs g_j, e_j.  11 -> 4 us for the 21 steps of cfg2 (tools/trace_phases.py): the
-        // broadcast LDS reads of the version below kept the LDS pipe of the CU busy for the whole recursion.
-        double v0, v1;
-        half_gather(isA ? (double)(half ? sW[t] : sV[t]) : 0.0, v0, v1);
-        double* const ocol = half ? sEr - q + (t - L) : sG + (t - L);  // output column of an isC lane
-#pragma unroll
-        for (int j = 0; j <= N_; ++j) {  // (unrolled: the step-dependent store conditions and LDS offsets fold)
-          double ac4[4] = {0.0, 0.0, 0.0, 0.0};
-          chain_dot<L_>(ac4, v0, v1, row);
-          const double acc = ((ac4[0] + ac4[1]) + (ac4[2] + ac4[3])) + (isA ? bs : 0.0);
-          if (cx) {
-            // g_j = Co v_j (half 0, j < N) and e_j = Co w_j - r_{j-1} (half 1, j >= 1; sEr holds -r) in ONE masked
-            // region: both are "element j of this lane's output column"
-            if (isC && (half ? j >= 1 : j < N_)) {
-              const double old = ocol[j * q];
-              ocol[j * q] = half ? acc + old : acc;
-            }
-          } else if (half == 0) {
-            if (isA && j + 1 < N) sG[(j + 1) * q + t] = acc;  // g_{j+1} = v_{j+1}
-          } else {
-            if (isA && j < N) sEr[j * q + t] += acc;          // e_{j+1} = w_{j+1} - r_j
-          }
-          half_gather(acc, v0, v1);  // v_{j+1} / w_{j+1} (lanes >= L are never read back)
-        }
-        block_sync<TPB>();
-      } else {
-      int cur = 0;
-      for (int j = 0; j <= N; ++j) {
-        const T* vec = (half ? sW : sV) + cur * L;
-        // four independent FMA chains: a dependent f64 FMA costs ~40 cycles on gfx950 (tools/ubench), but with
-        // four waves per SIMD the kernel is issue-bound, so products and adds stay fused (20 FMA + 3 adds)
-        T ac4[4] = {T(0), T(0), T(0), T(0)};
-        if constexpr ((L_ & 1) == 0) {
-          // 16-byte broadcast reads (ds_read_b128: half the LDS cycles of the ds_read2_b64 the compiler
-          // picks when it cannot prove the alignment); all LDS offsets are even in the static layout
-          typedef T T2 __attribute__((ext_vector_type(2)));
-          const T2* v2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(vec, 2 * sizeof(T)));
-#pragma unroll
-          for (int l = 0; l < L_ / 2; ++l) {
-            const T2 x2 = v2[l];
-            ac4[(2 * l) & 3] += row[2 * l] * x2.x;
-            ac4[(2 * l + 1) & 3] += row[2 * l + 1] * x2.y;
-          }
-        } else {
-#pragma unroll
-          for (int l = 0; l < L_; ++l) ac4[l & 3] += row[l] * vec[l];
-        }
-        T pr[1] = {(ac4[0] + ac4[1]) + (ac4[2] + ac4[3])};
-        const T acc = pr[0] + (isA ? bs : T(0));
-        if (half == 0) {
-          if (isA && j < N) {
-            sV[(cur ^ 1) * L + t] = acc;                      // v_{j+1}
-            if (!cx && j + 1 < N) sG[(j + 1) * q + t] = acc;  // g_{j+1} = v_{j+1}
-          }
-          if (isC && j < N) sG[j * q + (t - L)] = acc;        // g_j = Co v_j
-        } else {
-          if (isA && j < N) {
-            sW[(cur ^ 1) * L + t] = acc;                      // w_{j+1}
-            if (!cx) sEr[j * q + t] += acc;                   // e_{j+1} = w_{j+1} - r_j
-          }
-          if (isC && j >= 1) sEr[(j - 1) * q + (t - L)] += acc;  // e_j = Co w_j - r_{j-1}
-        }
-        block_sync<TPB>();
-        cur ^= 1;
-      }
-      }
-    } else if constexpr (L_ > 0 && TPB == 64 && (L_ + Q_ <= 64) && ((L_ & 1) == 0)) {
-      // Static path for 32 < L + q <= 64 (cfg4 sizes): lane t keeps row t of [A; Co] in registers and
-      // advances BOTH recursions (v and w) each step.
-      const int t = tid;
-      const int nco = cx ? q : 0;
-      const bool isA = t < L, isC = (t >= L) && (t < L + nco);
-      T row[L_];
-#pragma unroll
-      for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(a.cy0 + t - L) * L + l] : T(0));
-      const T bcol = (a.du_mode && isA) ? sK[t * p + L] : T(0);
-      const T upv = a.du_mode ? up : T(0);
-      if (!cx && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
-      typedef T T2 __attribute__((ext_vector_type(2)));
-      int cur = 0;
-      for (int j = 0; j <= N; ++j) {
-        const T2* v2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(sV + cur * L, 2 * sizeof(T)));
-        const T2* w2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(sW + cur * L, 2 * sizeof(T)));
-        T av[2] = {T(0), T(0)}, aw[2] = {T(0), T(0)};
-#pragma unroll
-        for (int l = 0; l < L_ / 2; ++l) {
-          const T2 xv = v2[l], xw = w2[l];
-          av[0] += row[2 * l] * xv.x;
-          av[1] += row[2 * l + 1] * xv.y;
-          aw[0] += row[2 * l] * xw.x;
-          aw[1] += row[2 * l + 1] * xw.y;
-        }
-        const T accv = av[0] + av[1] + bcol, accw = aw[0] + aw[1] + bcol * upv;
-        if (isA && j < N) {
-          sV[(cur ^ 1) * L + t] = accv;                      // v_{j+1}
-          sW[(cur ^ 1) * L + t] = accw;                      // w_{j+1}
-          if (!cx) {
-            if (j + 1 < N) sG[(j + 1) * q + t] = accv;       // g_{j+1} = v_{j+1}
-            sEr[j * q + t] += accw;                          // e_{j+1} = w_{j+1} - r_j
-          }
-        }
-        if (isC) {
-          if (j < N) sG[j * q + (t - L)] = accv;             // g_j = Co v_j
-          if (j >= 1) sEr[(j - 1) * q + (t - L)] += accw;    // e_j = Co w_j - r_{j-1}
-        }
-        block_sync<TPB>();
-        cur ^= 1;
-      }
-    } else if constexpr (L_ > 0 && TPB == 256 && (L_ + Q_ <= 128) && ((L_ & 1) == 0)) {
-      // Static path for four-wave trajectories (cfg5 sizes, L = 64): waves 0-1 run the v-chain, waves 2-3 the w-chain;
-      // thread t of a half keeps row t of [A; Co] in REGISTERS for the whole recursion (the generic path re-reads the
-      // 32 KB matrix from LDS at each of the N + 1 steps: LDS-bandwidth bound), the current vectors are broadcast
-      // 16-byte LDS reads.
-      const int half = tid >> 7, t = tid & 127;
-      const int nco = cx ? q : 0;
-      const bool isA = t < L, isC = (t >= L) && (t < L + nco);
-      T row[L_];
-#pragma unroll
-      for (int l = 0; l < L_; ++l) row[l] = isA ? sK[t * p + l] : (isC ? sC[(a.cy0 + t - L) * L + l] : T(0));
-      const T bs = (a.du_mode && isA) ? sK[t * p + L] * (half ? up : T(1)) : T(0);
-      if (!cx && half == 0 && isA) sG[t] = sV[t];  // y = lifted state: g_0 = B
-      typedef T T2 __attribute__((ext_vector_type(2)));
-      int cur = 0;
-      for (int j = 0; j <= N; ++j) {
-        const T2* v2 = reinterpret_cast<const T2*>(__builtin_assume_aligned((half ? sW : sV) + cur * L, 2 * sizeof(T)));
-        T ac4[4] = {T(0), T(0), T(0), T(0)};
-#pragma unroll
-        for (int l = 0; l < L_ / 2; ++l) {
-          const T2 x2 = v2[l];
-          ac4[(2 * l) & 3] += row[2 * l] * x2.x;
-          ac4[(2 * l + 1) & 3] += row[2 * l + 1] * x2.y;
-        }
-        const T acc = ((ac4[0] + ac4[1]) + (ac4[2] + ac4[3])) + (isA ? bs : T(0));
-        if (half == 0) {
-          if (isA && j < N) {
-            sV[(cur ^ 1) * L + t] = acc;                      // v_{j+1}
-            if (!cx && j + 1 < N) sG[(j + 1) * q + t] = acc;  // g_{j+1} = v_{j+1}
-          }
-          if (isC && j < N) sG[j * q + (t - L)] = acc;        // g_j = Co v_j
-        } else {
-          if (isA && j < N) {
-            sW[(cur ^ 1) * L + t] = acc;                      // w_{j+1}
-            if (!cx) sEr[j * q + t] += acc;                   // e_{j+1} = w_{j+1} - r_j
-          }
-          if (isC && j >= 1) sEr[(j - 1) * q + (t - L)] += acc;  // e_j = Co w_j - r_{j-1}
-        }
-        block_sync<TPB>();
-        cur ^= 1;
-      }
-    } else {
-    int cur = 0;
-      const int ntask = 2 * L + 2 * q;
-      for (int j = 0; j <= N; ++j) {
-        const T* v = sV + cur * L;
-        const T* w = sW + cur * L;
-        T* vn = sV + (cur ^ 1) * L;
-        T* wn = sW + (cur ^ 1) * L;
-        for (int t = tid; t < ntask; t += TPB) {
-          if (t < L) {
-            if (j < N) {
-              T acc = T(0);
-#pragma unroll
-              for (int l = 0; l < L; ++l) acc += sK[t * p + l] * v[l];
-              vn[t] = a.du_mode ? acc + sK[t * p + L] : acc;  // delta-u: x+ = A x + B s, s = 1
-            }
-          } else if (t < 2 * L) {
-            if (j < N) {
-              const int r = t - L;
-              T acc = T(0);
-#pragma unroll
-              for (int l = 0; l < L; ++l) acc += sK[r * p + l] * w[l];
-              wn[r] = a.du_mode ? acc + sK[r * p + L] * a.u_prev[b] : acc;  // s = u_prev
-            }
-          } else if (t < 2 * L + q) {
-            if (j < N) {
-              const int r = t - 2 * L;
-              T g;
-              if (cx) {
-                g = T(0);
-#pragma unroll
-                for (int l = 0; l < L; ++l) g += sC[(a.cy0 + r) * L + l] * v[l];
-              } else {
-                g = v[r];
-              }
-              sG[j * q + r] = g;
-            }
-          } else {
-            if (j >= 1) {
-              const int r = t - 2 * L - q;
-              T y;
-              if (cx) {
-                y = T(0);
-#pragma unroll
-                for (int l = 0; l < L; ++l) y += sC[(a.cy0 + r) * L + l] * w[l];
-              } else {
-                y = w[r];
-              }
-              sEr[(j - 1) * q + r] += y;
-            }
-          }
-        }
-        block_sync<TPB>();
-        cur ^= 1;
-      }
-    }
-    // H[a][b] = Qw * S(b-a, N-1-b) (+Rw on the diagonal),  S(d,t) = sum_{s<=t} g_{s+d}.g_s
-    KTRACE(6);
-    if constexpr (N_ > 0 && N_ <= 40 && TPB == 64) {
-      // the previous minimiser of this lane's variable (register solver: variable (lane >> 3) + 8 (lane & 7)) is
-      // requested now -- asked for at the start of the solve, it was a memory round trip nobody could hide
-      if ((sv.phases & PH_QP) && a.x_warm) {
-        const int mv = (tid >> 3) + 8 * (tid & 7);
-        xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
-      }
-    }
-    if constexpr (TPB == 64 && N_ > 0 && N_ <= 32 && Q_ > 0) {
-      // One pass for both: lane d < N walks diagonal d of H, lane 32 + a accumulates f[a].  Both are sums of
-      // g_t . w_{t+idx} with w = g (H) or e (f), so the two halves of the wave share one instruction stream.
-      const int hf = tid >> 5, idx = tid & 31;
-      const T* const wb = (hf ? sEr : sG) + idx * Q_;
-      const bool on = idx < N_;
-      const bool vec = ((Q_ & 1) == 0) && ((((int)(sG - sm)) & 1) == 0) && ((((int)(sEr - sm)) & 1) == 0);
-      T acc = T(0);
-      // H lanes store H(aa, bb) and H(bb, aa) with bb = N-1-t, aa = bb - idx: element offsets bb (N+1) - idx N and
-      // bb (N+1) - idx; the f lanes take part in the same stores with a scratch slot as target (no second mask)
-      T* const h1 = hf ? red + 14 : sH - idx * N_;
-      T* const h2 = hf ? red + 15 : sH - idx;
-      const int hstep = hf ? 0 : N_ + 1;
-      const T rdiag = (idx == 0 && !hf) ? a.Rw : T(0);
-      auto pass = [&](auto dotq) {
-#pragma unroll
-        for (int t = 0; t < N_; ++t) {
-          if (on && t + idx < N_) {
-            acc += dotq(sG + t * Q_, wb + t * Q_);
-            const T hv = a.Qw * acc + rdiag;
-            h1[(N_ - 1 - t) * hstep] = hv;
-            h2[(N_ - 1 - t) * hstep] = hv;
-          }
-        }
-      };
-      if (vec) {  // 16-byte LDS reads (the layout is even for the shipped dimension sets)
-        typedef T T2 __attribute__((ext_vector_type(2)));
-        pass([](const T* x, const T* y) {
-          const T2* x2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(x, 2 * sizeof(T)));
-          const T2* y2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(y, 2 * sizeof(T)));
-          T s0 = T(0);
-#pragma unroll
-          for (int r = 0; r < Q_ / 2; ++r) { const T2 u = x2[r], w = y2[r]; s0 += u.x * w.x; s0 += u.y * w.y; }
-          return s0;
-        });
-      } else {
-        pass([](const T* x, const T* y) {
-          T s0 = T(0);
-#pragma unroll
-          for (int r = 0; r < Q_; ++r) s0 += x[r] * y[r];
-          return s0;
-        });
-      }
-      if (hf && on) sf[idx] = T(2) * a.Qw * acc;
-    } else {
-    for (int d = tid; d < N; d += TPB) {
-        T acc = T(0);
-#pragma unroll
-        for (int t = 0; t < N; ++t) {
-          if (t + d < N) {
-            T s = T(0);
-#pragma unroll
-            for (int r = 0; r < q; ++r) s += sG[(t + d) * q + r] * sG[t * q + r];
-            acc += s;
-            const int bb = N - 1 - t, aa = bb - d;
-            const T hv = a.Qw * acc + (d == 0 ? a.Rw : T(0));
-            sH[aa * N + bb] = hv;
-            sH[bb * N + aa] = hv;
-          }
-        }
-      }
-      // f on lanes 32.. so that it overlaps the H diagonals of lanes 0..N-1 when the wave has room
-      {
-        const int f0 = (TPB == 64 && N <= 32) ? 32 : 0;
-        for (int aa = tid - f0; aa < N; aa += TPB) {
-          if (aa < 0) continue;
-          T acc = T(0);
-#pragma unroll
-          for (int t = 0; t < N; ++t)
-            if (t + aa < N) {
-#pragma unroll
-              for (int r = 0; r < q; ++r) acc += sG[t * q + r] * sEr[(t + aa) * q + r];
-            }
-          sf[aa] = T(2) * a.Qw * acc;
-        }
-      }
-    }
-    if (a.Wterm) {
-      // terminal block of Q_bar is PN instead of Qw I (Koopman_update.m:381); Wterm = PN - Qw I:
-      //   H[a][b] += g_{N-1-a}' sym(W) g_{N-1-b},   f[a] += 2 g_{N-1-a}' W e_N
-      block_sync<TPB>();
-      const T* const Wt = a.Wterm + (a.wterm_per_traj ? (size_t)b * q * q : (size_t)0);
-      for (int e = tid; e < N * N; e += TPB) {
-        const int aa = e / N, bb = e - aa * N;
-        const T* ga = sG + (N - 1 - aa) * q;
-        const T* gb = sG + (N - 1 - bb) * q;
-        T acc = T(0);
-        for (int r = 0; r < q; ++r)
-          for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * (T(0.5) * (Wt[r * q + s2] + Wt[s2 * q + r])) * gb[s2];
-        sH[e] += acc;
-      }
-      for (int aa = tid; aa < N; aa += TPB) {
-        const T* ga = sG + (N - 1 - aa) * q;
-        const T* eN = sEr + (N - 1) * q;
-        T acc = T(0);
-        for (int r = 0; r < q; ++r)
-          for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * Wt[r * q + s2] * eN[s2];
-        sf[aa] += T(2) * acc;
-      }
-    }
-    block_sync<TPB>();
-    KTRACE(7);
-    if (a.H_out) {
-      T* Hg = a.H_out + (size_t)b * N * N;
-      for (int e = tid; e < N * N; e += TPB) Hg[e] = sH[e];
-    }
-    if (a.f_out) {
-      T* fg = a.f_out + (size_t)b * N;
-      for (int e = tid; e < N; e += TPB) fg[e] = sf[e];
-    }
-  } else if (sv.phases & PH_QP) {
-    const T* Hg = a.H_in + (a.h_shared ? (size_t)0 : (size_t)b * N * N);
-    for (int e = tid; e < N * N; e += TPB) sH[e] = Hg[e];
-    if (a.F_in) {
-      // shared-model mode: f_b = F psi_b + f0 (the per-trajectory part of the condensed QP)
-      for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
-      block_sync<TPB>();
-      // (delta-u form: F has one more column, for u_prev -- the augmented state is [psi; u_prev], Tank_System.m:290)
-      const int Lf = L + (a.du_mode ? 1 : 0);
-      for (int e = tid; e < N; e += TPB) {
-        T acc = a.f0_in[e];
-        for (int l = 0; l < L; ++l) acc += a.F_in[e * Lf + l] * sy[l];
-        if (a.du_mode) acc += a.F_in[e * Lf + L] * a.u_prev[b];
-        sf[e] = acc;
-      }
-    } else {
-      const T* fg = a.f_in + (size_t)b * N;
-      for (int e = tid; e < N; e += TPB) sf[e] = fg[e];
-    }
-    block_sync<TPB>();
-  }
-
-  // =====================================================================================
-  // phase 3: box QP  min u'Hu + f'u, lb <= u <= ub  -- projected Newton (Bertsekas 1982) on a
-  // SWEPT tableau: T = sweep_F(2H) is kept in LDS, T_FF = -(2 H_FF)^-1, so the Newton step on the
-  // free set F is one masked mat-vec and a change of the active set costs one O(N^2) symmetric
-  // sweep per variable that enters or leaves F (no refactorisation).  Projected Armijo arc on the
-  // true cost; termination on the componentwise KKT test evaluated with H itself, so rounding
-  // in T only costs an extra (cheap) iteration.  Cold start at clip(0) as the reference
-  // (duffing.py:634-635); the minimiser is unique, so the start only affects the work.
-  // =====================================================================================
-  if (sv.phases & PH_QP) {
-    if constexpr (N_ > 0 && N_ <= 40 && TPB == 64) {
-      if (!(sv.phases & PH_CONDENSE) && a.x_warm) {  // QP-only call: nothing has requested the warm start yet
-        const int mv = (tid >> 3) + 8 * (tid & 7);
-        xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
-      }
-      // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
-      if (qp_regs<T, N_>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
-        block_sync<TPB>();
-        qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
-      }
-    } else if constexpr (N_ > 0 && N_ <= 64 && TPB == 256) {
-      // four-wave register tableau; the workspace is the vector area behind qx / qxa / qg (dead set A of the phase)
-      static_assert(L_ == 0 || 2 * (L_ + 1) + 6 * L_ + 1 + 2 * N_ * Q_ >= 3 * N_ + 324, "qp_regs256 workspace");
-      if (qp_regs256<T, N_>(sH, sf, a, sv, b, red, qg + N, qx, up)) {
-        block_sync<TPB>();
-        qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
-      }
-    } else {
-      qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, false);
-    }
-  }
 }
 
 // one workgroup of TPB threads per trajectory
@@ -1747,455 +30,6 @@ __global__ __launch_bounds__(TPB, (TPB == 256 ? 2 : 1)) void step_kernel(const S
   const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0)};
   step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
-
-// ---------------------------------------------------------------------------------------
-// Fused roll-out: `steps` iterations of the reference loop body (duffing.py:823-1012) in ONE launch.
-//
-// A workgroup of 16 waves owns 16 trajectories and walks them through all the steps; workgroups never
-// synchronise with each other, so the launch no longer waits for the slowest QP of the whole batch at every
-// step (a per-step launch is one round of waves: it lasts as long as its slowest trajectory), only the 16
-// trajectories of a workgroup meet -- at the lift, which they compute together:
-//   MLP encoder on v_mfma_f64_16x16x4_f64 with the 16 trajectories as the N dimension; wave w owns hidden M
-//   tile w over the whole K range, bias + ReLU are applied on the accumulator registers and written straight
-//   into the next layer's B-fragment layout (one barrier per layer).  The weights are pre-packed A-fragments.
-//   The lift scratch overlays the per-wave LDS regions, which are dead between two steps.
-// RBF lift: every wave lifts its own state, the waves of a workgroup never meet.
-// ---------------------------------------------------------------------------------------
-typedef double d4_t __attribute__((ext_vector_type(4)));
-// NW = waves (= trajectories) per workgroup: 16 (one workgroup per CU) or 8 (two per CU, MFMA tiles half empty:
-// used when the batch would otherwise leave CUs without a workgroup).
-constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
-constexpr int ro_scratch() { return 2 * RO_ACT; }     // overlays the per-wave regions between two steps
-constexpr int RO_KB2 = 8;                             // A-fragments are fetched and multiplied in batches of 8 k-steps
-// not overlaid: psi (Lp x columns), x_{k+1} of the trajectories (columns x 4); 16 MFMA columns for 8 / 16 waves, 4 for 4
-static int ro_cols(int waves) { return waves == 4 ? 4 : 16; }
-static int ro_keep(int Lp, int waves) { return Lp * ro_cols(waves) + 4 * ro_cols(waves); }
-
-// A-fragments of tile `tile`, k-steps ks0 .. ks0+15 (zero beyond KS)
-__device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int tile, int ks0, int lane, double (&af)[RO_KB2]) {
-#pragma unroll
-  for (int i = 0; i < RO_KB2; ++i) {
-    const int ks = ks0 + i;
-    af[i] = ks < KS ? Wp[((size_t)tile * KS + ks) * 64 + lane] : 0.0;
-  }
-}
-
-// KS_ < 0: RBF lift (no cooperation between the waves; the MLP code and its registers are not in that kernel, and the
-// log / sqrt constants of the RBF not in the MLP kernels).
-// KS_ > 0: k-steps of the encoder's hidden width fixed at compile time (25 = the reference's 100 hidden units): the
-// fragment loads and the MFMAs become straight-line code (with a run-time count every one of them sat behind its own
-// uniform branch and waited for its own LDS read); 0: run-time width.
-// Register budget: the LDS decides how many trajectories (= waves) a CU holds; up to four waves per SIMD get 128
-// VGPRs each (cfg2: 16 trajectories per CU), dimension sets with large per-trajectory regions leave room for more.
-template <int L_, int N_, int Q_, int NW> constexpr int ro_max_threads() {
-  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
-  constexpr size_t wgs = cap / (pw * NW);
-  constexpr size_t waves = wgs * NW > 16 ? 16 : (wgs * NW < (size_t)NW ? (size_t)NW : wgs * NW);
-  return waves > 8 ? 1024 : (waves > 4 ? 512 : 256);  // 4 / 2 / 1 waves per SIMD
-}
-template <int L_, int N_, int Q_, int NW, int KS_>
-__global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_kernel(const RolloutArgs<double> ra) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* const smem = reinterpret_cast<double*>(smem_raw);
-  constexpr int NC = NW == 4 ? 4 : 16;  // trajectory columns of the cooperative encoder
-  constexpr bool RBF = KS_ < 0;         // the lift kind is a compile-time property (KS_ = -1: thin-plate RBF, per wave)
-  const int tid0 = threadIdx.x;
-  const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave-uniform: trajectory index and LDS base stay scalar
-  const int B = ra.s.B, n = ra.s.n, L = L_;
-  const int b0 = blockIdx.x * (int)(blockDim.x >> 6), b = b0 + wave;  // NW waves (MLP lift); RBF: as many as fit in LDS
-  const bool live = b < B;
-  // lift scratch (overlays the per-wave regions between two steps)
-  double* const sAct0 = smem;
-  double* const sAct1 = sAct0 + RO_ACT;
-  double* const sPsi = smem + ra.keep_off;  // behind the per-wave regions: survives into the step
-  double* const sXn = sPsi + ra.Lp * NC;
-  if (!RBF && tid0 < 4 * NC) sXn[tid0] = 0.0;  // (columns of trajectories this workgroup does not have)
-  __syncthreads();
-  if (!RBF && (tid0 & 63) < 4)
-    sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? ra.s.X_rw[(size_t)(tid0 & 63) * B + b] : 0.0;
-
-  bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
-  int cur = ra.cur;
-  // lane i < L: psi_i(x_{k-1}) of this wave's trajectory, carried from step to step (a launch that continues an earlier
-  // one starts from the handle's copy)
-  double psi_prev_reg = 0.0;
-  if (live && ra.have_prev && (int)(tid0 & 63) < L) psi_prev_reg = ra.psi[ra.cur ^ 1][(size_t)b * L + (tid0 & 63)];
-  typedef const RolloutArgs<double> __attribute__((address_space(4))) * kernarg_ptr_t;
-  for (int k = 0; k < ra.steps; ++k) {
-    // The step arguments stay in the kernel-argument segment and are re-read where they are used: hoisted out
-    // of this loop they would pin ~150 scalar registers for the whole kernel (the asm hides the loop invariance).
-    kernarg_ptr_t kp = (kernarg_ptr_t)__builtin_amdgcn_kernarg_segment_ptr();
-    asm volatile("" : "+s"(kp));
-    const RolloutArgs<double> __attribute__((address_space(4)))& R = *kp;
-    const StepArgs<double>& a = *(const StepArgs<double>*)(&kp->s);  // psi strides (1, L), accumulate = 1: host
-    // (as local_tid: lane- and wave-derived addresses and the lift's tiling constants are recomputed in every
-    //  iteration instead of being carried across the step in registers)
-    int wv = wave;
-    asm volatile("" : "+s"(wv));
-    const int lane = local_tid<64>();
-    (void)wv;
-#ifdef KMPC_TRACE
-    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 16] = wall_clock64();  // this wave is ready for step k
-#endif
-    double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
-    if constexpr (RBF) {
-      if (live && lane < L) {
-        double x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = (i < n) ? a.X_rw[(size_t)i * B + b] : 0.0;
-        const double* c = R.cx + (size_t)lane * n;
-        if (R.rbf_matlab) {
-          double r2 = 0.0;
-          for (int i = 0; i < n; ++i) { const double d = x[i] - c[i]; r2 += d * d; }
-          psi_i = r2 > 0.0 ? r2 * log(sqrt(r2)) : 0.0;
-        } else {
-          double xx = 0.0, cc = 0.0, xc = 0.0;
-          for (int i = 0; i < n; ++i) { xx += x[i] * x[i]; cc += c[i] * c[i]; xc += x[i] * c[i]; }
-          double d2 = xx - 2.0 * xc + cc;
-          d2 = d2 > 0.0 ? d2 : 0.0;
-          const double d = sqrt(d2);
-          psi_i = d * d * log(d + R.eps);
-        }
-      }
-    } else if constexpr (NW == 4) {  // (written for 4 or 8 columns; with 8 the 16x16x4 path below measures better: 89 vs 87 M steps/s)
-      // Four or eight trajectories per workgroup (four / two workgroups per CU, which drift apart: a SIMD then holds
-      // waves in different phases of the step, and a barrier only makes a few trajectories wait for each other).
-      // Encoder on v_mfma_f64_4x4x4_4b_f64: four independent 4x4x4 blocks per instruction = 16 output rows x 4
-      // trajectories x 4 k.  Operand lanes (probed, tools/ubench/mfma_f64_4x4.hip): A lane 16k + 4blk + i, B lane
-      // 16k + 4blk + j, D lane 16i + 4blk + j -- so the A-fragments are the SAME packed tiles the 16x16x4 path reads
-      // (lane = 16k + row in tile), B is the activation (k, j) replicated over the blocks (broadcast LDS read), and a
-      // tile's output comes back as row 4blk + i, column j.  On gfx950 this shape runs at the flop rate of the
-      // 16x16x4 one, so the lift costs the same f64 pipe time per trajectory as with 16 columns (the 16x16x4 shape with
-      // 8 columns wastes half of it).  NW = 4: wave w owns hidden tiles w and w + 4; NW = 8: tile w, multiplied with
-      // both groups of four columns (the fragment is loaded once).  Either way four independent accumulator chains
-      // per wave; the output tiles go to the waves from the top (the last wave has less hidden work when Hp = 112).
-      constexpr int CG = NW / 4;      // groups of four trajectory columns
-      constexpr int NT = 8 / NW;      // hidden tiles per wave (Hp <= 128: eight tiles)
-      const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
-      const int boff = (lane >> 4) * NC + (lane & 3);         // B operand: element (k, j) of a k-step (+ 4 cg)
-      const int drow = ((lane >> 2) & 3) * 4 + (lane >> 4);   // D: row within the tile
-      const int dcol = lane & 3;
-      const int th0 = wv, th1 = wv + NW;                      // hidden tiles of this wave
-      const bool vh0 = th0 < MTH, vh1 = NT > 1 && th1 < MTH;
-      const int to0 = NW - 1 - wv;                            // output tile of this wave
-      const bool vo0 = to0 < MTO;
-      double af[2][RO_KB2];  // double-buffered batches of A-fragments (one tile at a time: registers are scarce here)
-      // first layer: one k-step (K = n <= 4, W1 zero-padded to 4 columns), bias as the accumulator input
-      double a1[NT], c1[NT];
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int th = wv + t * NW;
-        const bool v = th < MTH;
-        a1[t] = v ? R.W1[4 * (16 * th + (lane & 15)) + (lane >> 4)] : 0.0;
-        c1[t] = v ? R.b1[16 * th + drow] : 0.0;
-      }
-      if (R.nhh > 0) { if (vh0) ro_load_afrags(R.Whp[0], KS, th0, 0, lane, af[0]); }
-      else if (vo0) ro_load_afrags(R.Wop, KS, to0, 0, lane, af[0]);
-      __syncthreads();  // every wave is done with its LDS region (previous step); x_k of the trajectories is in sXn
-#pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const int th = wv + t * NW;
-        if (th < MTH) {
-#pragma unroll
-          for (int cg = 0; cg < CG; ++cg) {
-            const double xb = sXn[(cg * 4 + (lane & 3)) * 4 + (lane >> 4)];
-            const double v = __builtin_amdgcn_mfma_f64_4x4x4f64(a1[t], xb, c1[t], 0, 0, 0);
-            sAct0[(16 * th + drow) * NC + cg * 4 + dcol] = v > 0.0 ? v : 0.0;
-          }
-        }
-      }
-      __syncthreads();
-      for (int h = 0; h <= R.nhh; ++h) {
-        const bool last = h == R.nhh;
-        const int t0 = last ? to0 : th0, t1 = th1;
-        const bool v0 = last ? vo0 : vh0, v1 = last ? false : vh1;
-        const double* act = (h & 1) ? sAct1 : sAct0;
-        double* actn = (h & 1) ? sAct0 : sAct1;
-        const double* Wp = last ? R.Wop : R.Whp[h & 1];
-        const double* bias = last ? R.bo : R.bh[h & 1];
-        double acc[NT][CG][2];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          const double bv = (t ? v1 : v0) ? bias[16 * (t ? t1 : t0) + drow] : 0.0;
-#pragma unroll
-          for (int cg = 0; cg < CG; ++cg) { acc[t][cg][0] = bv; acc[t][cg][1] = 0.0; }
-        }
-        constexpr int NB = 32 / RO_KB2;  // batches per tile (KS <= 32 k-steps)
-#pragma unroll
-        for (int g = 0; g < NT * NB; ++g) {  // batch g: tile g / NB, k-steps (g % NB) * 8 ..; batch g + 1 is requested first
-          const int tl = g / NB, kb = (g % NB) * RO_KB2;
-          if (g + 1 < NT * NB) {
-            const int tl2 = (g + 1) / NB, kb2 = ((g + 1) % NB) * RO_KB2;
-            if ((tl2 ? v1 : v0) && kb2 < KS) ro_load_afrags(Wp, KS, tl2 ? t1 : t0, kb2, lane, af[(g + 1) & 1]);
-          }
-          if ((tl ? v1 : v0) && kb < KS) {
-#pragma unroll
-            for (int i = 0; i < RO_KB2; ++i)
-              if (kb + i < KS) {
-#pragma unroll
-                for (int cg = 0; cg < CG; ++cg)
-                  acc[tl][cg][i & 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(af[g & 1][i], act[(kb + i) * 4 * NC + boff + 4 * cg],
-                                                                         acc[tl][cg][i & 1], 0, 0, 0);
-              }
-          }
-        }
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-          if (t ? v1 : v0) {
-            const int tt = t ? t1 : t0;
-#pragma unroll
-            for (int cg = 0; cg < CG; ++cg) {
-              const double v = acc[t][cg][0] + acc[t][cg][1];
-              if (last) sPsi[(16 * tt + drow) * NC + cg * 4 + dcol] = v;
-              else actn[(16 * tt + drow) * NC + cg * 4 + dcol] = v > 0.0 ? v : 0.0;
-            }
-          }
-        }
-        // the next layer's first fragments travel across the barrier
-        if (!last) {
-          if (h + 1 < R.nhh) { if (vh0) ro_load_afrags(R.Whp[h + 1], KS, th0, 0, lane, af[0]); }
-          else if (vo0) ro_load_afrags(R.Wop, KS, to0, 0, lane, af[0]);
-        }
-        __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
-      }
-      if (lane < L) psi_i = sPsi[lane * NC + wv];
-    } else {
-      // Cooperative encoder.  Wave w < Hp/16 owns hidden M tile w for the whole K range (two alternating
-      // accumulator chains), so bias + ReLU are applied on the accumulator registers and the result is written
-      // straight into the next layer's B-fragment layout: one barrier per layer, no partial sums.  The other
-      // waves only take part in the barriers.
-      const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
-      const bool hid = wv < MTH, out = wv < MTO;
-      // A-fragments in two alternating batches of 8 k-steps: the first batch of a layer is requested a layer ahead
-      // (it travels across the barrier), every further batch while the previous one is being multiplied
-      double af[2][RO_KB2];
-      if (R.nhh > 0) { if (hid) ro_load_afrags(R.Whp[0], KS, wv, 0, lane, af[0]); }
-      else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af[0]);
-      // ---- layer 1 (K = n <= 4: one k-step, W1 zero-padded to 4 columns): one MFMA per hidden tile, bias as the
-      //      accumulator input, straight into B-fragment layout.  Operands are requested before the barrier.
-      double a1 = 0.0;
-      d4_t c1 = {0.0, 0.0, 0.0, 0.0};
-      if (hid) {
-        a1 = R.W1[4 * (16 * wv + (lane & 15)) + (lane >> 4)];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) c1[r] = R.b1[16 * wv + (lane >> 4) + 4 * r];
-      }
-      __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all trajectories is in sXn
-      if (hid) {
-        c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sXn[4 * (lane & 15) + (lane >> 4)], c1, 0, 0, 0);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * wv + (lane >> 4) + 4 * r;
-          sAct0[(row >> 2) * 64 + ((row & 3) << 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
-        }
-      }
-      __syncthreads();
-      // ---- hidden -> hidden layers, then the output layer, all as: tile = wave, full K
-      for (int h = 0; h <= R.nhh; ++h) {
-        const bool last = h == R.nhh;
-        const bool mine = last ? out : hid;
-        const double* act = (h & 1) ? sAct1 : sAct0;
-        double* actn = (h & 1) ? sAct0 : sAct1;
-        const double* Wp = last ? R.Wop : R.Whp[h & 1];
-        const double* bias = last ? R.bo : R.bh[h & 1];
-        // accumulator register r of lane l holds row (l >> 4) + 4 r, column l & 15 of the tile
-        d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
-        if (mine) {  // the bias is the accumulator input of the first chain
-#pragma unroll
-          for (int r = 0; r < 4; ++r) acc0[r] = bias[16 * wv + (lane >> 4) + 4 * r];
-        }
-        if (mine) {
-#pragma unroll
-          for (int bt = 0; bt < 32 / RO_KB2; ++bt) {  // KS <= 32 k-steps in batches
-            const int kb = bt * RO_KB2;
-            if (kb + RO_KB2 < KS) ro_load_afrags(Wp, KS, wv, kb + RO_KB2, lane, af[(bt + 1) & 1]);
-#pragma unroll
-            for (int i = 0; i < RO_KB2; i += 2) {
-              if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i], act[(kb + i) * 64 + lane], acc0, 0, 0, 0);
-              if (kb + i + 1 < KS)
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
-            }
-          }
-        }
-        if (mine) {
-          const int col = lane & 15;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int row = 16 * wv + (lane >> 4) + 4 * r;
-            const double v = acc0[r] + acc1[r];
-            if (last) sPsi[row * 16 + col] = v;
-            else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
-          }
-        }
-        // the next layer's first fragments travel across the barrier
-        if (!last) {
-          if (h + 1 < R.nhh) { if (hid) ro_load_afrags(R.Whp[h + 1], KS, wv, 0, lane, af[0]); }
-          else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af[0]);
-        }
-        __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
-      }
-      if (lane < L) psi_i = sPsi[lane * 16 + wv];
-    }
-
-#ifdef KMPC_TRACE
-    if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 17] = wall_clock64();  // lift done
-    if (lane == 0 && b < 8192 && k == 0) kmpc_trace_buf[b * 32 + 19] = wall_clock64();
-#endif
-    if (live) {
-      int woff = wv * R.wstride, bk = b;
-      asm volatile("" : "+s"(woff), "+s"(bk));  // (as local_tid: keeps the step's address arithmetic inside the loop)
-      double* const wsm = smem + woff;
-      double* const psi_now = R.psi[cur];
-      if (lane < L) psi_now[(size_t)b * L + lane] = psi_i;  // (state of the handle; the step takes psi from the registers)
-      StepVar<double> sv;
-      sv.psi_now = psi_now;
-      sv.psi_prev = R.psi[cur ^ 1];
-      sv.psi_in_regs = 1;
-      sv.psi_now_v = psi_i;
-      sv.psi_prev_v = psi_prev_reg;
-      sv.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
-      sv.first_update = fresh ? 1 : 0;
-      sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
-      sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
-      sv.x_next = RBF ? nullptr : sXn + wv * 4;
-      step_body<double, 64, L_, N_, Q_>(a, sv, bk, wsm);
-      if (R.X_log) {
-        __threadfence_block();
-        if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
-      }
-    }
-#ifdef KMPC_TRACE
-    if (lane == 0 && b < 8192) {
-      const unsigned long long t18 = wall_clock64();
-      kmpc_trace_buf[b * 32 + 18] = t18;  // step k done
-      // whole-launch sums: barrier wait + lift, step body (k == 0 resets)
-      const unsigned long long dl = kmpc_trace_buf[b * 32 + 17] - kmpc_trace_buf[b * 32 + 16], db = t18 - kmpc_trace_buf[b * 32 + 17];
-      kmpc_trace_buf[b * 32 + 20] = (k == 0 ? 0ull : kmpc_trace_buf[b * 32 + 20]) + dl;
-      kmpc_trace_buf[b * 32 + 21] = (k == 0 ? 0ull : kmpc_trace_buf[b * 32 + 21]) + db;
-    }
-#endif
-    if (have_prev) fresh = false;
-    have_prev = true;
-    cur ^= 1;
-    psi_prev_reg = psi_i;
-  }
-  if (!RBF && live && (tid0 & 63) == 0) {  // (the host zeroed status / iters before the launch)
-    const int* const acc = reinterpret_cast<const int*>(sXn + wave * 4 + 2);
-    if (ra.s.status) ra.s.status[b] = acc[0];
-    if (ra.s.iters) ra.s.iters[b] = acc[1];
-  }
-}
-
-// waves (= trajectories) per workgroup of the fused roll-out.  MLP lift: 16 (one workgroup per CU) or 8 (two per
-// CU); the RBF lift needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.
-// 0: does not fit.
-static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves, int Lp, int* wstride) {
-  const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr) / sizeof(double) + 1) & ~(size_t)1;
-  if (wstride) *wstride = (int)per_wave;
-  size_t elems = per_wave * waves;
-  if (rbf) return elems;
-  const size_t scratch = waves == 4 ? RO_ACT + 128 * 4 : ro_scratch();  // (sAct1 sits RO_ACT behind sAct0)
-  if (elems < scratch) elems = scratch;
-  return elems + ro_keep(Lp, waves);
-}
-static int g_rollout_workgroup = 0;  // kmpc_set_rollout_workgroup
-void set_rollout_workgroup(int trajectories) { g_rollout_workgroup = trajectories; }
-static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
-  const size_t cap = 160 * 1024 / sizeof(double);
-  if (!rbf) {
-    static const char* env = getenv("KMPC_ROLLOUT_WAVES");  // measurement aid: force 4, 8 or 16
-    // workgroups of w trajectories that fit on one CU (LDS is handed out in 512-byte granules; 16 waves per CU)
-    auto wgs = [&](int w) -> int {
-      const size_t e = (rollout_lds_elems(n, L, q, N, false, w, Lp, nullptr) + 63) & ~(size_t)63;
-      const int k = (int)(cap / e);
-      return k * w > 16 ? 16 / w : k;
-    };
-    if (g_rollout_workgroup) return wgs(g_rollout_workgroup) > 0 ? g_rollout_workgroup : 0;
-    if (env && (atoi(env) == 4 || atoi(env) == 8 || atoi(env) == 16)) return wgs(atoi(env)) > 0 ? atoi(env) : 0;
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-    }
-    // Most trajectories per CU wins; ties go to the larger workgroup (cfg2 at B = 4096: 91.3 / 89.0 / 84.5 M steps/s
-    // with 16 / 8 / 4 trajectories per workgroup).  Batches that leave CUs without a 16-trajectory workgroup are
-    // spread as smaller ones (B = 2048: 43.5 vs 35.7 M steps/s with 8, B = 1024: 22.6 vs 18.4).
-    int best = 0, best_traj = 0;
-    for (int w = 16; w >= 4; w >>= 1) {
-      const int t = wgs(w) * w;
-      if (t > best_traj) { best = w; best_traj = t; }
-    }
-    if (best == 16 && wgs(8) * 8 >= 16 && (B + 15) / 16 < cus) return 8;
-    return best;
-  }
-  for (int w = 16; w >= 4; w >>= 1)
-    if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
-  return 0;
-}
-template <int L_, int N_, int Q_, int NW, int KS_>
-static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, size_t lds, hipStream_t s) {
-  static size_t configured = 0;
-  if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW, KS_>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
-  const int grid = (k.s.B + waves - 1) / waves;
-  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_>), dim3(grid), dim3(64 * waves), lds, s, k);
-  return hipGetLastError();
-}
-template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
-  RolloutArgs<double> k = a;
-  const bool rbf = a.lift_rbf != 0;
-  const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
-  if (waves == 0) return hipErrorInvalidValue;
-  step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2);
-  const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
-  k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp, waves));
-  const size_t lds = elems * sizeof(double);
-  if (lds > 160 * 1024) return hipErrorInvalidValue;
-  // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
-  const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
-  if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1>(k, waves, lds, s);
-  // (workgroup sizes whose per-wave regions alone exceed the LDS are not instantiated)
-  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
-  if constexpr (4 * pw <= cap)
-    if (waves == 4) return ks25 ? launch_rollout_nw<L_, N_, Q_, 4, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 4, 0>(k, waves, lds, s);
-  if constexpr (8 * pw <= cap)
-    if (waves == 8) return ks25 ? launch_rollout_nw<L_, N_, Q_, 8, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 8, 0>(k, waves, lds, s);
-  if constexpr (16 * pw <= cap)
-    if (waves == 16) return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0>(k, waves, lds, s);
-  return hipErrorInvalidValue;
-}
-
-template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
-  if (sizeof(T) != 8 || threads == 256 || n > 4) return false;
-  const bool inst = (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
-                    (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2) || (L == 10 && N == 20 && q == 1) ||
-                    (L == 20 && N == 30 && q == 2) || (L == 32 && N == 40 && q == 2) || (L == 32 && N == 40 && q == 1);
-  return inst && rollout_waves(n, L, q, N, rbf, 64) > 0;  // (Lp <= 64)
-}
-template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
-  if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
-  if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
-    return hipErrorInvalidValue;
-  if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
-#ifndef KMPC_DEV_CFG2_ONLY  // (development builds compile the cfg2 instantiations only)
-  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 2) return launch_rollout_impl<8, 10, 2>(a, s);
-  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 8) return launch_rollout_impl<8, 10, 8>(a, s);
-  if (a.s.L == 8 && a.s.N == 30 && a.s.q == 8) return launch_rollout_impl<8, 30, 8>(a, s);
-  if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);
-  if (a.s.L == 10 && a.s.N == 20 && a.s.q == 1) return launch_rollout_impl<10, 20, 1>(a, s);  // Tank_System.m dimensions
-  if (a.s.L == 20 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<20, 30, 2>(a, s);  // BASELINE cfg3 sizes, y = Cx
-  if (a.s.L == 32 && a.s.N == 40 && a.s.q == 2) return launch_rollout_impl<32, 40, 2>(a, s);  // BASELINE cfg4 sizes
-  if (a.s.L == 32 && a.s.N == 40 && a.s.q == 1) return launch_rollout_impl<32, 40, 1>(a, s);
-#endif
-  return hipErrorInvalidValue;
-}
-template <> hipError_t launch_rollout_fused<float>(const RolloutArgs<float>&, hipStream_t) { return hipErrorInvalidValue; }
-template bool rollout_fused_available<float>(int, int, int, int, int, bool);
-template bool rollout_fused_available<double>(int, int, int, int, int, bool);
 
 // ---------------------------------------------------------------------------------------
 // launcher
@@ -2247,3 +81,8 @@ template hipError_t launch_step<float>(const StepArgs<float>&, int, hipStream_t)
 template hipError_t launch_step<double>(const StepArgs<double>&, int, hipStream_t);
 
 }  // namespace kmpc
+
+#ifdef KMPC_TRACE
+// (measurement build: ONE translation unit, so that the phase stamps of both kernels land in the same buffer)
+#include "rollout_kernel.hip"
+#endif
