@@ -258,6 +258,50 @@ def test_solve_dare_and_dlqr_match_reference_vectors(torch_mod):
     assert solve_DARE(np.zeros((0, L, L)), np.zeros((0, L)), Q, 0.3).shape == (0, L, L)  # empty batch
 
 
+def test_dare_edge_sizes_and_errors(torch_mod, KM):
+    """L = 64 (the largest lift: 98 KB of LDS per model), L = 1, a float32 handle (refused: the reference's Riccati
+    iteration is float64), bad arguments."""
+    torch = torch_mod
+    from koopmpc import _ffi, dlqr, solve_DARE
+
+    rng = np.random.RandomState(64)
+    for L in (64, 1):
+        A = rng.randn(L, L)
+        A *= 0.8 / max(1e-12, np.abs(np.linalg.eigvals(A)).max())
+        B = rng.randn(L, 1)
+        Q = np.eye(L)
+        P, it = solve_DARE(A, B, Q, 0.5, eps=1e-10, return_iters=True)
+        Po, ito = ko.solve_dare(A, B, Q, 0.5, eps=1e-10)
+        assert abs(int(it.item()) - ito) <= 1
+        assert np.abs(P.cpu().numpy() - Po).max() <= 1e-8 * np.abs(Po).max()
+        assert np.abs(dlqr(A, B, Q, 0.5, eps=1e-10).cpu().numpy() - ko.dlqr(A, B, Q, 0.5, eps=1e-10)).max() <= 1e-8 * max(1.0, np.abs(Po).max())
+    m32 = KM(n=2, L=8, N=10, batch=2, lift="rbf", centres=rng.rand(8, 2), dtype=torch.float32)
+    with pytest.raises(RuntimeError):
+        m32.terminal_from_dare(np.eye(8), 0.01)
+    lib = _ffi.load()
+    assert lib.kmpc_solve_dare(None, None, None, 0.1, 10, 0.01, 1, 8, None, None, None, None) == -3
+    with pytest.raises(ValueError):
+        solve_DARE(np.eye(3), np.ones(3), np.eye(4), 1.0)
+
+
+def test_state_init_from_with_lifted_output(torch_mod, KM):
+    """kmpc_state_init_from for y = psi (no C): bar_X0 may be NULL; K = K_A0 P0 becomes every trajectory's model."""
+    rng = np.random.RandomState(12)
+    L, B = 8, 4
+    mpc = KM(n=2, L=L, N=10, batch=B, lift="rbf", centres=rng.rand(L, 2), output="lift", lb=-6.0, ub=6.0)
+    G = rng.randn(L + 1, L + 1)
+    P0 = np.linalg.inv(G @ G.T + np.eye(L + 1))
+    KA = rng.randn(L, L + 1)
+    mpc.state_init(K_A=KA, inv_K_G=P0, bar_X=None, bar_Q=np.eye(L))
+    A, Bm, Cm = mpc.get_model()
+    K = KA @ P0
+    assert Cm is None
+    assert np.abs(A.cpu().numpy()[B - 1] - K[:, :L]).max() <= 1e-12 * np.abs(K).max()
+    assert np.abs(Bm.cpu().numpy()[0][:, 0] - K[:, L]).max() <= 1e-12 * np.abs(K).max()
+    with pytest.raises(RuntimeError):
+        mpc.state_init(P0=-1.0)
+
+
 @pytest.mark.parametrize("L,N,output", [(20, 20, "Cx"), (8, 10, "lift")])
 def test_terminal_from_dare(torch_mod, KM, L, N, output):
     """kmpc_terminal_from_dare: P_N = Co solve_DARE(A, B, Q, R) Co' (Koopman_update.m:381 with the LQR stand-in) from
