@@ -43,9 +43,9 @@ def run(k0, n):
         X = m.plant_step("tank", X, u, switched=(k0 + k > 100))
 
 
-run(0, 20); torch.cuda.synchronize()
+run(0, 40); torch.cuda.synchronize()  # (the first ~20 steps of a fresh shared model are slow: few samples, ill-conditioned QPs)
 t0 = time.perf_counter()
-run(20, steps); torch.cuda.synchronize()
+run(40, steps); torch.cuda.synchronize()
 dt = time.perf_counter() - t0
 st = m.status.cpu().numpy()
 print("cfg4-like (shared model, delta-u tank) L=%d N=%d B=%d: %.2f M steps/s (%.1f us/step), last-step status!=0: %d of %d, finite %s, level median %.3f"
