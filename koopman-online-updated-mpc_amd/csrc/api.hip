@@ -80,6 +80,8 @@ struct Impl : kmpc_handle {
   T *dP = nullptr, *dK = nullptr, *dQ = nullptr, *dC = nullptr;
   T *dPsi[2] = {nullptr, nullptr};  // [B][L] trajectory-major: [cur], [prev]
   T* dUprev = nullptr;
+  T* dQpScr = nullptr;  // [B][N*N] fall-back tableau of the register QP solvers (global scratch, rarely touched)
+  int qp_scr_cap = 0;
   T* dWarm = nullptr;  // [N][B] last minimiser = start of the next solve (the reference restarts at zeros, duffing.py:634-635)
   int cur = 0;
   bool have_prev = false;  // a previous (psi, u) exists -> next step runs the RLS update
@@ -121,6 +123,8 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMalloc(&dPsi[0], sizeof(T) * (size_t)L * B));
     HIPCHK(hipMalloc(&dPsi[1], sizeof(T) * (size_t)L * B));
     HIPCHK(hipMalloc(&dUprev, sizeof(T) * (size_t)B));
+    HIPCHK(hipMalloc(&dQpScr, sizeof(T) * (size_t)B * N * N));
+    qp_scr_cap = B;
     HIPCHK(hipMalloc(&dWarm, sizeof(T) * (size_t)N * B));
     HIPCHK(hipMalloc(&dTmp, sizeof(T) * (size_t)(L * p + n * L + 64)));
     HIPCHK(hipMemset(dK, 0, sizeof(T) * sK * B));
@@ -154,7 +158,7 @@ struct Impl : kmpc_handle {
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
-                      (void*)dDareP, (void*)dDareIt, (void*)dWtB})
+                      (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -406,6 +410,7 @@ struct Impl : kmpc_handle {
     a.c_skip_first = cfg.c_skip_first ? 1 : 0;
     a.umin = (T)cfg.umin; a.umax = (T)cfg.umax;
     a.u_prev = dUprev;  // delta-u reads the absolute previous input in every phase
+    a.qp_scratch = dQpScr;
     a.plant = -1;
     return a;
   }
@@ -446,6 +451,13 @@ struct Impl : kmpc_handle {
     if (Bc == 0) return 0;  // empty batch: nothing to do
     if (Bc < 0 || !H || !f || !U) FAIL(-3, "kmpc_qp_solve: bad arguments");
     if (cfg.delta_u && Bc != B) FAIL(-3, "kmpc_qp_solve: with delta_u the batch must equal the handle's (per-trajectory u_prev)");
+    if (Bc > qp_scr_cap) {  // (a stateless solve may bring a larger batch than the handle's)
+      HIPCHK(hipStreamSynchronize(s));
+      (void)hipFree(dQpScr);
+      dQpScr = nullptr; qp_scr_cap = 0;
+      HIPCHK(hipMalloc(&dQpScr, sizeof(T) * (size_t)Bc * N * N));
+      qp_scr_cap = Bc;
+    }
     StepArgs<T> a = base_args(Bc);
     a.phases = PH_QP;
     a.H_in = (const T*)H; a.f_in = (const T*)f;

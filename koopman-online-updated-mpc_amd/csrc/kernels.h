@@ -50,6 +50,7 @@ struct StepArgs {
   T* U0;             // [B] or null
   T* u_store;        // [B] handle copy of u_k for the next RLS update, or null
   int32_t* status; int32_t* iters;
+  T* qp_scratch;   // [B][N*N] global scratch: tableau of the register solvers' fall-back (never touched otherwise)
   T* x_warm;       // [N][B] previous minimiser = start of the next solve, or null: start at clip(0) as the reference
                    // does (its pastRes_loc stays zeros, duffing.py:634-635, 859); same minimiser, less work
   const T* Wterm;  // q x q, PN - Qw I: terminal block of Q_bar (Koopman_update.m:381), or null
@@ -120,7 +121,7 @@ struct DareArgs {
 };
 hipError_t launch_dare(const DareArgs& a, hipStream_t s);
 
-size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2);
+size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2, bool lds_tableau = true);
 
 template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s);
 // true if (T, n, L, N, q, threads, lift kind) has a fused roll-out instantiation that fits in LDS

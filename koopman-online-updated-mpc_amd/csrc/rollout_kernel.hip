@@ -44,14 +44,18 @@ __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int til
 // uniform branch and waited for its own LDS read); 0: run-time width.
 // Register budget: the LDS decides how many trajectories (= waves) a CU holds; up to four waves per SIMD get 128
 // VGPRs each (cfg2: 16 trajectories per CU), dimension sets with large per-trajectory regions leave room for more.
-template <int L_, int N_, int Q_, int NW> constexpr int ro_max_threads() {
-  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
+template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads() {
+  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
   constexpr size_t wgs = cap / (pw * NW);
-  constexpr size_t waves = wgs * NW > 16 ? 16 : (wgs * NW < (size_t)NW ? (size_t)NW : wgs * NW);
+  constexpr size_t fit = wgs * NW > 16 ? 16 : (wgs * NW < (size_t)NW ? (size_t)NW : wgs * NW);
+  // long horizons with the MLP lift: at most 8 trajectories per CU, 256 registers each (the N = 30 solver keeps H and
+  // the tableau in registers; L = 8, N = 30: 24.6 M steps/s like this, 18.7 M with 16 trajectories at 128 registers and
+  // 173 of them spilled.  With the RBF lift the same step measures the other way round -- 90 against 60 M steps/s)
+  constexpr size_t waves = (KS_ >= 0 && N_ > 24 && fit > 8) ? 8 : fit;
   return waves > 8 ? 1024 : (waves > 4 ? 512 : 256);  // 4 / 2 / 1 waves per SIMD
 }
 template <int L_, int N_, int Q_, int NW, int KS_>
-__global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_kernel(const RolloutArgs<double> ra) {
+__global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollout_kernel(const RolloutArgs<double> ra) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* const smem = reinterpret_cast<double*>(smem_raw);
   constexpr int NC = NW == 4 ? 4 : 16;  // trajectory columns of the cooperative encoder
@@ -347,7 +351,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW>())) void rollout_ke
 // CU); the RBF lift needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.
 // 0: does not fit.
 static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves, int Lp, int* wstride) {
-  const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr) / sizeof(double) + 1) & ~(size_t)1;
+  const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr, !tableau_saves_lds(N, L)) / sizeof(double) + 1) & ~(size_t)1;
   if (wstride) *wstride = (int)per_wave;
   size_t elems = per_wave * waves;
   if (rbf) return elems;
@@ -365,7 +369,8 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     auto wgs = [&](int w) -> int {
       const size_t e = (rollout_lds_elems(n, L, q, N, false, w, Lp, nullptr) + 63) & ~(size_t)63;
       const int k = (int)(cap / e);
-      return k * w > 16 ? 16 / w : k;
+      const int maxw = N > 24 ? 8 : 16;  // (long horizons: see ro_max_threads)
+      return k * w > maxw ? maxw / w : k;
     };
     if (g_rollout_workgroup) return wgs(g_rollout_workgroup) > 0 ? g_rollout_workgroup : 0;
     if (env && (atoi(env) == 4 || atoi(env) == 8 || atoi(env) == 16)) return wgs(atoi(env)) > 0 ? atoi(env) : 0;
@@ -377,15 +382,18 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     // Most trajectories per CU wins; ties go to the larger workgroup (cfg2 at B = 4096: 91.3 / 89.0 / 84.5 M steps/s
     // with 16 / 8 / 4 trajectories per workgroup).  Batches that leave CUs without a 16-trajectory workgroup are
     // spread as smaller ones (B = 2048: 43.5 vs 35.7 M steps/s with 8, B = 1024: 22.6 vs 18.4).
+    // (four-trajectory workgroups only where they at least double the residency: their lifts expose the L2 round
+    //  trips of the weight fragments, L = 8, N = 30: 17.8 M steps/s with 3 x 4 against 24.6 M with 1 x 8)
     int best = 0, best_traj = 0;
-    for (int w = 16; w >= 4; w >>= 1) {
+    for (int w = 16; w >= 8; w >>= 1) {
       const int t = wgs(w) * w;
       if (t > best_traj) { best = w; best_traj = t; }
     }
+    if (wgs(4) * 4 >= 2 * best_traj && wgs(4) > 0) { best = 4; best_traj = wgs(4) * 4; }
     if (best == 16 && wgs(8) * 8 >= 16 && (B + 15) / 16 < cus) return 8;
     return best;
   }
-  for (int w = 16; w >= 4; w >>= 1)
+  for (int w = 16; w >= 4; --w)  // (RBF lift: the waves of a workgroup never meet, any number of them will do)
     if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
   return 0;
 }
@@ -407,7 +415,8 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   const bool rbf = a.lift_rbf != 0;
   const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
   if (waves == 0) return hipErrorInvalidValue;
-  step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2);
+  step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));
+  if (!a.s.qp_scratch) return hipErrorInvalidValue;
   const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
   k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp, waves));
   const size_t lds = elems * sizeof(double);
@@ -416,7 +425,7 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
   if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1>(k, waves, lds, s);
   // (workgroup sizes whose per-wave regions alone exceed the LDS are not instantiated)
-  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
+  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
   if constexpr (4 * pw <= cap)
     if (waves == 4) return ks25 ? launch_rollout_nw<L_, N_, Q_, 4, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 4, 0>(k, waves, lds, s);
   if constexpr (8 * pw <= cap)

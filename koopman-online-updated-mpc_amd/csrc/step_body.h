@@ -35,9 +35,15 @@ static constexpr int vec_elems(int n, int L, int q, int N) {
 }
 
 static constexpr int step_region1(int L, int N) { return (imax(imax((L + 1) * (L + 1), L * L), N * N) + 1) & ~1; }
-static constexpr int step_region2(int n, int L, int N) { return (imax(L * (L + 1) + n * L, N * N) + 1) & ~1; }
-static constexpr size_t step_lds_elems(int n, int L, int q, int N) {
-  return (size_t)step_region1(L, N) + step_region2(n, L, N) + vec_elems(n, L, q, N);
+// lds_tableau: the region also has to hold the N x N tableau of the LDS solver (run-time dimensions).  The register
+// solvers (static N) only need that tableau in their rare fall-back, which then works in a per-trajectory global
+// scratch block instead: for long horizons this region was most of a trajectory's LDS (N = 30, L = 8: 19 -> 12.7 KB,
+// 8 -> 12 trajectories per CU).
+static constexpr int step_region2(int n, int L, int N, bool lds_tableau = true) {
+  return (imax(L * (L + 1) + n * L, lds_tableau ? N * N : 0) + 1) & ~1;
+}
+static constexpr size_t step_lds_elems(int n, int L, int q, int N, bool lds_tableau = true) {
+  return (size_t)step_region1(L, N) + step_region2(n, L, N, lds_tableau) + vec_elems(n, L, q, N);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -94,6 +100,15 @@ template <int TPB, int COUNT, typename F> __device__ __forceinline__ void for_st
     int i = 0;
     for (int e = tid; e < count; e += TPB, ++i) f(e, i);
   }
+}
+
+// true: the tableau region of this instantiation is in LDS -- the LDS solver (run-time dimensions), or a register
+// solver whose model block [K, C] is at least as large as N^2 anyway (cfg2: nothing to save, and the fall-back code
+// with a global pointer costs the fused kernel registers: 95 -> 91 M steps/s when tried); false: a register solver with
+// a long horizon, whose fall-back tableau lives in global scratch (StepArgs::qp_scratch)
+static constexpr bool tableau_saves_lds(int N, int L) { return N * N > L * (L + 1) + 4 * L; }
+template <int TPB, int N_, int L_> constexpr bool step_tableau_in_lds() {
+  return !(N_ > 0 && L_ > 0 && ((TPB == 64 && N_ <= 40) || (TPB == 256 && N_ <= 64)) && tableau_saves_lds(N_, L_));
 }
 
 template <typename T> struct Tol;
@@ -1097,7 +1112,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   T* const sK = sY;
   T* const sC = sY + L * p;
   T* const sH = sX;
-  T* const sM = sY;
+  T* const sM = sY;  // LDS solver; the register solvers' fall-back works in global scratch instead (computed there)
   T* const vec = sY + a.r2;
   T* const red = vec;          // 16  reduction scratch (+ the 64-bit set mask at red[8])
   T* const sf = red + 16;      // N   (lives condense -> QP)
@@ -1709,14 +1724,34 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
       if (qp_regs<T, N_>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
         block_sync<TPB>();
-        qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
+        if constexpr (step_tableau_in_lds<TPB, N_, L_>()) {
+          qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
+        } else {
+          // no tableau region in LDS: H moves to this trajectory's global scratch block (read-only from here on,
+          // coalesced reads) and the tableau takes H's place in LDS, where the sweeps' read-modify-writes belong
+          T* const Hg = a.qp_scratch + (size_t)b * N * N;
+          for (int e = tid; e < N * N; e += TPB) Hg[e] = sH[e];
+          __threadfence_block();
+          block_sync<TPB>();
+          qp_lds<T, TPB>(Hg, sf, sX, qx, qxa, qg, red, a, sv, b, N, true);
+        }
       }
     } else if constexpr (N_ > 0 && N_ <= 64 && TPB == 256) {
       // four-wave register tableau; the workspace is the vector area behind qx / qxa / qg (dead set A of the phase)
       static_assert(L_ == 0 || 2 * (L_ + 1) + 6 * L_ + 1 + 2 * N_ * Q_ >= 3 * N_ + 324, "qp_regs256 workspace");
       if (qp_regs256<T, N_>(sH, sf, a, sv, b, red, qg + N, qx, up)) {
         block_sync<TPB>();
-        qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
+        if constexpr (step_tableau_in_lds<TPB, N_, L_>()) {
+          qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
+        } else {
+          // no tableau region in LDS: H moves to this trajectory's global scratch block (read-only from here on,
+          // coalesced reads) and the tableau takes H's place in LDS, where the sweeps' read-modify-writes belong
+          T* const Hg = a.qp_scratch + (size_t)b * N * N;
+          for (int e = tid; e < N * N; e += TPB) Hg[e] = sH[e];
+          __threadfence_block();
+          block_sync<TPB>();
+          qp_lds<T, TPB>(Hg, sf, sX, qx, qxa, qg, red, a, sv, b, N, true);
+        }
       }
     } else {
       qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, false);

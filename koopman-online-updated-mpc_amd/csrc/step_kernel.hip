@@ -17,10 +17,10 @@
 
 namespace kmpc {
 
-size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2) {
+size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2, bool lds_tableau) {
   if (r1) *r1 = step_region1(L, N);
-  if (r2) *r2 = step_region2(n, L, N);
-  return step_lds_elems(n, L, q, N) * elem;
+  if (r2) *r2 = step_region2(n, L, N, lds_tableau);
+  return step_lds_elems(n, L, q, N, lds_tableau) * elem;
 }
 
 // one workgroup of TPB threads per trajectory
@@ -36,7 +36,9 @@ __global__ __launch_bounds__(TPB, (TPB == 256 ? 2 : 1)) void step_kernel(const S
 // ---------------------------------------------------------------------------------------
 template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_impl(const StepArgs<T>& a, hipStream_t s) {
   StepArgs<T> k = a;
-  const size_t lds = step_lds_bytes(a.n, a.L, a.q, a.N, sizeof(T), &k.r1, &k.r2);
+  constexpr bool TAB = step_tableau_in_lds<TPB, N_, L_>();
+  if (!TAB && !a.qp_scratch && (a.phases & PH_QP)) return hipErrorInvalidValue;
+  const size_t lds = step_lds_bytes(a.n, a.L, a.q, a.N, sizeof(T), &k.r1, &k.r2, TAB);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {

@@ -32,7 +32,7 @@ Xs, Ys, Us = [], [], []
 for i in range(100):
     xn = tank(xc, Ub[i]); Xs.append(xc); Ys.append(xn); Us.append(Ub[i]); xc = xn
 m.offline_fit(np.concatenate(Xs, 1), np.concatenate(Ys, 1), np.concatenate(Us, 0), ridge=1e-9)
-r = np.ones((1, N))
+r = torch.ones(1, N, dtype=torch.float64, device="cuda:0")  # (a device tensor: a NumPy reference is copied to the device at every step)
 X = torch.tensor(np.abs(rng.rand(2, B)), dtype=torch.float64, device="cuda:0")
 
 
