@@ -38,7 +38,13 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
   StepArgs<T> k = a;
   constexpr bool TAB = step_tableau_in_lds<TPB, N_, L_>();
   if (!TAB && !a.qp_scratch && (a.phases & PH_QP)) return hipErrorInvalidValue;
-  const size_t lds = step_lds_bytes(a.n, a.L, a.q, a.N, sizeof(T), &k.r1, &k.r2, TAB);
+  size_t lds = step_lds_bytes(a.n, a.L, a.q, a.N, sizeof(T), &k.r1, &k.r2, TAB);
+  // a solve-only launch of a register solver (kmpc_qp_solve, the shared-model step) touches neither the model block
+  // nor a tableau region: without it more trajectories fit on a CU (cfg4 sizes: 25 -> 16 KB each)
+  if (!TAB && (a.phases & (PH_RLS | PH_CONDENSE)) == 0) {
+    lds -= (size_t)k.r2 * sizeof(T);
+    k.r2 = 0;
+  }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t configured = 0;
   if (lds > 64 * 1024 && lds > configured) {
