@@ -67,3 +67,27 @@ def offline_edmd(lift, plant=duffing_rk4, n_steps=100, n_traj=100, seed=101):
     K = PY @ np.linalg.pinv(np.concatenate([PX, U], 0))
     C = X @ np.linalg.pinv(PX)
     return K[:, :-1].copy(), K[:, -1:].copy(), C
+
+
+def tank_map(x, u, switched=False):
+    """Cascaded tanks, one sample: Tank_System.m:9-10 (nominal), :194-195 (after step 100), clipped at 0 (:211)."""
+    x1 = np.maximum(x[0], 0.0)
+    x2 = np.maximum(x[1], 0.0)
+    if switched:
+        xn = np.stack([x1 - 0.53 * np.sqrt(x1) + 0.3 * u, x2 + 0.1 * np.sqrt(x1) - 0.35 * np.sqrt(x2)])
+    else:
+        xn = np.stack([x1 - 0.5 * np.sqrt(x1) + 0.4 * u, x2 + 0.2 * np.sqrt(x1) - 0.3 * np.sqrt(x2)])
+    return np.maximum(xn, 0.0)
+
+
+def tank_offline_data(n_steps=100, n_traj=100, seed=101):
+    """Tank_System.m:29-49: random inputs in [-5, 5], initial levels in [0, 2]."""
+    rng = np.random.RandomState(seed)
+    U0 = 10.0 * rng.rand(n_steps, n_traj) - 5.0
+    x = np.maximum(4.0 * rng.rand(2, n_traj) - 2.0, 0.0)
+    Xs, Ys, Us = [], [], []
+    for i in range(n_steps):
+        xn = tank_map(x, U0[i])
+        Xs.append(x); Ys.append(xn); Us.append(U0[i])
+        x = xn
+    return np.concatenate(Xs, 1), np.concatenate(Ys, 1), np.concatenate(Us, 0)

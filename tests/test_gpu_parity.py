@@ -1275,3 +1275,30 @@ def test_cfg2_full_size_properties(torch_mod, KM):
         Xs = sub.plant_step("duffing", Xs.clone(), us)
     A_, B_, C_ = mpc.get_model()
     assert bool(torch.isfinite(A_).all()) and bool(torch.isfinite(C_).all())
+
+
+@pytest.mark.parametrize("script,args", [
+    ("duffing", ["--weights", "weights_duffing.npz", "--batch", "5", "--steps", "30"]),
+    ("vanderpol", ["--weights", "weights_vdp.npz", "--batch", "1", "--steps", "30"]),
+    ("vanderpol_RBF", ["--batch", "6", "--steps", "25", "--horizon", "30"]),
+    ("tank", ["--weights", "weights_tank.npz", "--batch", "4", "--steps", "30"]),
+    ("tank", ["--batch", "8", "--steps", "12", "--shared", "--Nlift", "32", "--horizon", "40"]),
+])
+def test_reference_loop_scripts_run(torch_mod, tmp_path, monkeypatch, script, args):
+    """koopmpc/scripts/*.py are the reference's experiment loops (duffing.py, vanderpol.py, vanderpol_RBF.py,
+    Tank_System.m) on this library: each one runs, logs finite inputs inside its box and leaves finite states."""
+    import importlib
+    import sys
+
+    gdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    argv = [a if not a.endswith(".npz") else os.path.join(gdir, a) for a in args]
+    out = str(tmp_path / "log.npz")
+    monkeypatch.setattr(sys, "argv", [script] + argv + ["--out", out])
+    mod = importlib.import_module("koopmpc.scripts." + script)
+    mod.main()
+    log = np.load(out)
+    U = log["logUloc"]
+    bound = {"duffing": 2.0, "vanderpol": 6.0, "vanderpol_RBF": 2.0, "tank": 8.0}[script]
+    assert np.isfinite(U).all() and np.abs(U).max() <= bound + 1e-9
+    if "logXloc" in log.files:
+        assert np.isfinite(log["logXloc"]).all()
