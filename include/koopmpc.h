@@ -159,10 +159,17 @@ int kmpc_step(kmpc_handle* h, const void* X_dev, const void* ref_dev, int ref_pe
  * sharded over GPUs the only exchange of the path is the sum of `delta_gram` over ranks between the two
  * stages (ncclAllReduce / torch.distributed.all_reduce on the caller's side; (p+L+n)*p float64 values).   */
 int64_t kmpc_gram_elems(const kmpc_handle* h);
+/* the exchange itself for native callers: delta_gram_dev <- sum over the ranks of `nccl_comm` (an
+ * ncclComm_t of the RCCL the caller loaded; ncclAllReduce, float64, sum) on `stream`.  RCCL is looked up in
+ * the process at run time (-4: none found); Python callers use torch.distributed.all_reduce instead
+ * (KoopmanMPC.shared_step).                                                                     */
+int kmpc_allreduce_gram(kmpc_handle* h, double* delta_gram_dev, void* nccl_comm, void* stream);
 /* stage 1: lift x_k; delta_gram_dev (float64, overwritten) = Gram sums of THIS rank's transitions
  * (psi_{k-1}, u_{k-1}) -> (psi_k, x_k), rows [Z Z' (p x p); Ylift Z' (L x p); X Z' (n x p)]; zeros on the
  * first call (no transition yet).  The contraction runs on v_mfma_f64_16x16x4_f64.                        */
 int kmpc_shared_local_gram(kmpc_handle* h, const void* X_dev, double* delta_gram_dev, void* stream);
+/* the same entry point under the name SURVEY.md 8b lists for it */
+int kmpc_gram_accumulate(kmpc_handle* h, const void* X_dev, double* delta_gram_dev, void* stream);
 /* stage 2: G <- lambda G + delta_gram (already summed over ranks); model from G; condensed QP of the shared
  * model (H, F, f0 with f_b = F psi_b + f0); box QP of every trajectory.  ref_dev (q x N) is shared.        */
 int kmpc_shared_solve(kmpc_handle* h, const double* delta_gram_dev, const void* ref_dev, void* U0_dev,

@@ -10,6 +10,7 @@
 
 #include "../../include/koopmpc.h"
 #include "kernels.h"
+#include <dlfcn.h>
 
 using namespace kmpc;
 
@@ -892,7 +893,29 @@ int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs
 int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NN(h); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
 int kmpc_offline_fit(kmpc_handle* h, const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A, void* B, void* C, void* s) { NN(h); return h->offline_fit(X, Y, U, M, ridge, init_rls, A, B, C, (hipStream_t)s); }
 int64_t kmpc_gram_elems(const kmpc_handle* h) { return h ? h->gram_elems() : -1; }
+// The one collective of the path for native callers: sum of the per-rank Gram blocks over an RCCL communicator.
+// RCCL is resolved at run time from the process (the caller created the communicator with the RCCL it loaded; under
+// PyTorch that is torch's own copy and KoopmanMPC.shared_step goes through torch.distributed instead) -- the library
+// itself does not link against it.
+int kmpc_allreduce_gram(kmpc_handle* h, double* delta, void* nccl_comm, void* s) {
+  NN(h);
+  if (!delta || !nccl_comm) return -3;
+  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  static allreduce_fn fn = nullptr;
+  if (!fn) {
+    fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    if (!fn) {
+      void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (lib) fn = (allreduce_fn)dlsym(lib, "ncclAllReduce");
+    }
+    if (!fn) return -4;  // no RCCL in this process
+  }
+  const int rc = fn(delta, delta, (size_t)h->gram_elems(), /*ncclDouble*/ 8, /*ncclSum*/ 0, nccl_comm, (hipStream_t)s);
+  return rc == 0 ? 0 : -(2000 + rc);
+}
 int kmpc_shared_local_gram(kmpc_handle* h, const void* X, double* delta, void* s) { NN(h); return h->shared_local_gram(X, delta, (hipStream_t)s); }
+int kmpc_gram_accumulate(kmpc_handle* h, const void* X, double* delta, void* s) { return kmpc_shared_local_gram(h, X, delta, s); }
 int kmpc_shared_solve(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->shared_solve(delta, ref, U0, Useq, st, it, (hipStream_t)s); }
 int kmpc_shared_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->shared_get_model(A, B, C, (hipStream_t)s); }
 int64_t kmpc_state_bytes(const kmpc_handle* h) { return h ? h->state_bytes() : -1; }

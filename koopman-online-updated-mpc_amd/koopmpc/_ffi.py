@@ -59,7 +59,9 @@ SIGNATURES = {
     "kmpc_step": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_offline_fit": (_I, [_VP, _VP, _VP, _VP, _I, _D, _I, _VP, _VP, _VP, _VP]),
     "kmpc_gram_elems": (_I64, [_VP]),
+    "kmpc_allreduce_gram": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_shared_local_gram": (_I, [_VP, _VP, _VP, _VP]),
+    "kmpc_gram_accumulate": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_shared_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_shared_get_model": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "kmpc_plant_step": (_I, [_VP, _I, _VP, _VP, _D, _I, _I, _VP]),

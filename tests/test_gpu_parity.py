@@ -726,6 +726,52 @@ def test_shared_model_delta_u_tank_vs_oracle(torch_mod, KM, L, N, B):
     assert np.all(np.abs(u) <= 8.0) and np.all(np.abs(dU) <= 0.5 + 1e-12)
 
 
+def test_allreduce_gram_with_a_one_rank_communicator(torch_mod, KM):
+    """kmpc_allreduce_gram (the native entry point of the path's only collective): a one-rank RCCL communicator made
+    with the RCCL that is loaded in this process; the sum over one rank leaves the block unchanged, bad arguments are
+    refused.  (Two ranks sum their blocks: covered with gloo on the host and by the two-shard test below.)"""
+    import ctypes as C
+    import glob
+
+    torch = torch_mod
+    from koopmpc import _ffi
+
+    lib = _ffi.load()
+    cands = glob.glob(os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so*")) + ["librccl.so", "librccl.so.1"]
+    rccl = None
+    for c in cands:
+        try:
+            rccl = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            break
+        except OSError:
+            continue
+    if rccl is None:
+        pytest.skip("no RCCL library found")
+
+    class UniqueId(C.Structure):
+        _fields_ = [("internal", C.c_char * 128)]
+
+    uid = UniqueId()
+    assert rccl.ncclGetUniqueId(C.byref(uid)) == 0
+    comm = C.c_void_p()
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UniqueId, C.c_int]
+    assert rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0) == 0
+    try:
+        mpc = KM(n=2, L=8, N=10, batch=4, lift="rbf", centres=np.random.RandomState(0).rand(8, 2))
+        ne = int(lib.kmpc_gram_elems(mpc.h))
+        d = torch.arange(ne, dtype=torch.float64, device="cuda:0") * 0.5 - 3.0
+        want = d.clone()
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        assert lib.kmpc_allreduce_gram(mpc.h, C.c_void_p(d.data_ptr()), comm, s) == 0
+        torch.cuda.synchronize()
+        assert torch.equal(d, want)
+        assert lib.kmpc_allreduce_gram(mpc.h, None, comm, s) == -3
+        assert lib.kmpc_allreduce_gram(mpc.h, C.c_void_p(d.data_ptr()), None, s) == -3
+    finally:
+        rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+        rccl.ncclCommDestroy(comm)
+
+
 def test_shared_model_two_shards_equal_one_batch(torch_mod, KM):
     """The batch split over two handles (two 'ranks' on one GPU) with the Gram sums added by hand -- the job
     ncclAllReduce does between the two stages -- gives the same shared model and controls as one handle."""
