@@ -148,7 +148,9 @@ int kmpc_qp_solve(kmpc_handle* h, const void* H_dev, const void* f_dev, void* U_
  * (duffing.py:847-984): lift x_k; if a previous transition exists, RLS-update the model with
  * (psi_{k-1}, u_{k-1}, psi_k, x_k); condense; solve; u_k.  X_dev (n x B), ref as above,
  * U0_dev (B), Useq_dev (N x B, may be NULL), status_dev / iters_dev [B] (may be NULL).
- * The handle keeps psi_k and u_k for the next call.                                         */
+ * The handle keeps psi_k and u_k for the next call.  One kernel launch where the fused roll-out has
+ * an instantiation (float64, MLP lift, static dimension set: the roll-out kernel with one step and no
+ * plant), else the lift kernel followed by the step kernel.                                   */
 int kmpc_step(kmpc_handle* h, const void* X_dev, const void* ref_dev, int ref_per_traj,
               void* U0_dev, void* Useq_dev, int32_t* status_dev, int32_t* iters_dev, void* stream);
 

@@ -470,6 +470,14 @@ struct Impl : kmpc_handle {
   int step(const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it,
            hipStream_t s) override {
     if (!X || !ref || !U0) FAIL(-3, "kmpc_step: null pointer");
+    // Configurations with a fused roll-out instantiation and the MLP lift take ONE launch for the step as well: the
+    // roll-out kernel with a single step and no plant (encoder inside on MFMA, no separate lift kernel, psi handed
+    // over in registers).  Same results up to the summation order of the encoder.
+    if (fuse_plant < 0 && !accumulate && cfg.lift_kind == KMPC_LIFT_MLP && fused_rollout_ok()) {
+      static const bool two = getenv("KMPC_STEP_TWO_KERNELS") != nullptr;  // measurement aid
+      if (!two)
+        return rollout_fused(-1, const_cast<void*>(X), ref, rpt, 1, 0, -1, 0.05, nullptr, nullptr, st, it, s, U0, Useq);
+    }
     hipEvent_t e0 = nullptr, e1 = nullptr, e2 = nullptr;
     const bool rec = prof && ev_used + 3 <= EV_CAP;
     if (rec) {
@@ -541,14 +549,15 @@ struct Impl : kmpc_handle {
     return !off && n == 2 && rollout_fused_available<T>(n, L, N, q, threads, cfg.lift_kind != KMPC_LIFT_MLP);
   }
   int rollout_fused(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
-                    void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) {
+                    void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s, void* U0out = nullptr,
+                    void* Useqout = nullptr) {
     int rc = check_lift_ready();
     if (rc) return rc;
     RolloutArgs<T> r{};
     r.s = base_args(B);
     r.s.u_prev = dUprev; r.s.x_now = (const T*)X;
     r.s.ref = (const T*)ref; r.s.ref_per_traj = rpt;
-    r.s.U0 = dU0; r.s.Useq = nullptr; r.s.u_store = dUprev; r.s.status = st; r.s.iters = it;
+    r.s.U0 = U0out ? (T*)U0out : dU0; r.s.Useq = (T*)Useqout; r.s.u_store = dUprev; r.s.status = st; r.s.iters = it;
     r.s.x_warm = cfg.cold_start ? nullptr : dWarm;
     r.s.plant = plant; r.s.plant_h = (T)hs; r.s.X_rw = (T*)X;
     r.s.pp_sl = 1; r.s.pp_sb = L; r.s.pn_sl = 1; r.s.pn_sb = L;

@@ -985,29 +985,35 @@ def _set_uprev(mpc, sd, uk):
     mpc.load_state_dict({"blob": blob})
 
 
-def test_step_matches_separate_ops_bitwise(torch_mod, KM):
-    """The fused kmpc_step equals lift -> rls_update -> condense -> qp_solve called one by one."""
+@pytest.mark.parametrize("lift", ["rbf", "mlp"])
+def test_step_matches_separate_ops(torch_mod, KM, lift):
+    """kmpc_step equals lift -> rls_update -> condense -> qp_solve called one by one.  RBF lift: kmpc_step is the lift
+    kernel + the step kernel, bitwise the same.  MLP lift with a fused instantiation: kmpc_step is ONE launch of the
+    roll-out kernel (single step, no plant), whose in-kernel encoder sums the K dimension in another order than the
+    stand-alone lift kernel: equal to 1e-9."""
     torch = torch_mod
     from koopmpc.synth import random_mlp_weights
 
     rng = np.random.RandomState(8)
     L, N, B = 20, 20, 37
-    w = random_mlp_weights(2, 100, 3, L, seed=3)
+    kw = dict(weights=random_mlp_weights(2, 100, 3, L, seed=3)) if lift == "mlp" else dict(lift="rbf", centres=4 * rng.rand(L, 2) - 2)
     A, Bm, Cm = _rand_model(rng, L, 2)
-    m1 = KM(n=2, L=L, N=N, batch=B, weights=w, cold_start=True)  # kmpc_qp_solve is stateless: it starts at clip(0)
-    m2 = KM(n=2, L=L, N=N, batch=B, weights=w)
+    m1 = KM(n=2, L=L, N=N, batch=B, cold_start=True, **kw)  # kmpc_qp_solve is stateless: it starts at clip(0)
+    m2 = KM(n=2, L=L, N=N, batch=B, **kw)
     m1.set_model(A, Bm, Cm); m2.set_model(A, Bm, Cm)
     r = np.tile(np.array([[1.0], [0.0]]), (1, N))
     X = _t(torch, 4 * rng.rand(2, B) - 2)
     psi_prev, u_prev = None, None
+    same = (lambda a, b: torch.equal(a, b)) if lift == "rbf" else (lambda a, b: float((a - b).abs().max()) < 1e-9)
     for k in range(5):
         u1 = m1.step(X, r).clone()
         psi = m2.Encoder(X)
         if psi_prev is not None:
             m2.Koopman_update(psi_prev, u_prev, psi, X)
         U2, st, it = m2.mpc_solve(psi, r)
-        assert torch.equal(u1, U2[0])
-        assert torch.equal(m1.Useq, U2)
+        assert same(u1, U2[0]), k
+        assert same(m1.Useq, U2), k
+        assert int(m1.status.max().item()) == 0 and int(st.max().item()) == 0
         psi_prev, u_prev = psi, U2[0].clone()
         X = m1.plant_step("duffing", X.clone(), u1, switched=(k > 2))
 
