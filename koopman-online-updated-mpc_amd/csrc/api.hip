@@ -575,6 +575,7 @@ struct Impl : kmpc_handle {
     r.steps = steps; r.step0 = step0; r.switch_step = switch_step;
     r.have_prev = have_prev ? 1 : 0; r.rls_fresh = rls_fresh ? 1 : 0;
     r.U_log = (T*)Ulog; r.X_log = (T*)Xlog;
+    rollout_schedule(&r.dyn_group, &r.dyn_timeout);
     const bool rec = prof && ev_used + 3 <= EV_CAP;
     if (rec) {
       while (ev.size() < ev_used + 3) {
@@ -884,6 +885,11 @@ int kmpc_rollout_is_fused(const kmpc_handle* h) { NN(h); return h->rollout_is_fu
 int kmpc_set_rollout_workgroup(int trajectories) {
   if (trajectories != 0 && trajectories != 4 && trajectories != 8 && trajectories != 16) return -1;
   kmpc::set_rollout_workgroup(trajectories);
+  return 0;
+}
+int kmpc_set_rollout_schedule(int group, int timeout_ticks) {
+  if (group < -1 || group > 4 || (group > 0 && timeout_ticks < 1)) return -1;
+  kmpc::set_rollout_schedule(group, timeout_ticks);
   return 0;
 }
 int kmpc_reset(kmpc_handle* h, void* s) { NN(h); return h->reset((hipStream_t)s); }

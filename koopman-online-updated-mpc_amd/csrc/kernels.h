@@ -89,6 +89,9 @@ template <typename T> struct RolloutArgs {
   int wstride;              // per-wave LDS region in elements
   int keep_off;             // LDS offset (elements) of the part the lift scratch does not overlay
   T* U_log; T* X_log;       // optional (steps x B), (steps x n x B)
+  // > 0: the kernel without a per-step workgroup barrier (rollout_dyn.h): lift groups of up to dyn_group (<= 4) waves
+  // are formed at run time; dyn_timeout = how long the queue head waits for a full group, in 10 ns ticks
+  int dyn_group, dyn_timeout;
 };
 
 // K7: Gram sums of one step's transitions (rows [psi_prev; u_prev; psi_now; x_now] against [psi_prev; u_prev])
@@ -128,6 +131,10 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf);
 template <typename T> hipError_t launch_rollout_fused(const RolloutArgs<T>& a, hipStream_t s);
 void set_rollout_workgroup(int trajectories);  // 0 = automatic, else 4 / 8 / 16 (process-wide)
+// scheduling of the fused roll-out with the MLP lift: group = 0: one cooperative lift per step behind a workgroup barrier;
+// 1..4: lift groups formed at run time, no barrier (rollout_dyn.h); timeout in 10 ns ticks (process-wide)
+void set_rollout_schedule(int group, int timeout_ticks);
+void rollout_schedule(int* group, int* timeout_ticks);
 template <typename T> hipError_t launch_pack_afrag(const T* src, int Mp, int Hp, int KS, T* dst, hipStream_t s);
 template <typename T> hipError_t launch_lift_mlp(const LiftArgs<T>& a, hipStream_t s);
 template <typename T> hipError_t launch_lift_rbf(const LiftArgs<T>& a, hipStream_t s);

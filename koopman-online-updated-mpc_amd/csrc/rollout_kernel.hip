@@ -347,6 +347,10 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
   }
 }
 
+}  // namespace kmpc
+#include "rollout_dyn.h"
+namespace kmpc {
+
 // waves (= trajectories) per workgroup of the fused roll-out.  MLP lift: 16 (one workgroup per CU) or 8 (two per
 // CU); the RBF lift needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.
 // 0: does not fit.
@@ -361,6 +365,19 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
 }
 static int g_rollout_workgroup = 0;  // kmpc_set_rollout_workgroup
 void set_rollout_workgroup(int trajectories) { g_rollout_workgroup = trajectories; }
+static int g_dyn_group = -1, g_dyn_timeout = 300;  // kmpc_set_rollout_schedule (-1: not set, take the default / environment)
+void set_rollout_schedule(int group, int timeout_ticks) { g_dyn_group = group; g_dyn_timeout = timeout_ticks; }
+void rollout_schedule(int* group, int* timeout_ticks) {
+  if (g_dyn_group < 0) {  // measurement aids: KMPC_ROLLOUT_DYN = 0..4, KMPC_ROLLOUT_DYN_TIMEOUT in 10 ns ticks
+    const char* e = getenv("KMPC_ROLLOUT_DYN");
+    const char* t = getenv("KMPC_ROLLOUT_DYN_TIMEOUT");
+    g_dyn_group = e ? atoi(e) : 0;
+    if (g_dyn_group < 0 || g_dyn_group > 4) g_dyn_group = 0;
+    if (t && atoi(t) > 0) g_dyn_timeout = atoi(t);
+  }
+  *group = g_dyn_group;
+  *timeout_ticks = g_dyn_timeout;
+}
 static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
   const size_t cap = 160 * 1024 / sizeof(double);
   if (!rbf) {
@@ -410,9 +427,40 @@ static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, siz
   hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_>), dim3(grid), dim3(64 * waves), lds, s, k);
   return hipGetLastError();
 }
+// the kernel without a per-step workgroup barrier (rollout_dyn.h); 16 trajectories per workgroup
+template <int L_, int N_, int Q_, int KS_> static hipError_t launch_rollout_dyn(const RolloutArgs<double>& a, hipStream_t s) {
+  RolloutArgs<double> k = a;
+  step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));
+  const size_t elems = rollout_dyn_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, a.Lp, &k.wstride);
+  k.keep_off = k.wstride * 16;
+  const size_t lds = elems * sizeof(double);
+  if (lds > 160 * 1024 || (size_t)k.wstride < (size_t)2 * a.Hp * 4) return hipErrorInvalidValue;
+  static size_t configured = 0;
+  if (lds > 64 * 1024 && lds > configured) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_dyn_kernel<L_, N_, Q_, KS_>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    configured = lds;
+  }
+  hipLaunchKernelGGL((rollout_dyn_kernel<L_, N_, Q_, KS_>), dim3((a.s.B + 15) / 16), dim3(1024), lds, s, k);
+  return hipGetLastError();
+}
+// dimension sets with a barrier-free instantiation (MLP lift only; the RBF lift never had a barrier)
+static bool rollout_dyn_available(int n, int L, int N, int q, int Hp, int Lp) {
+  if (!(L == 20 && N == 20 && q == 2)) return false;
+  int ws = 0;
+  return rollout_dyn_lds_elems(n, L, q, N, Lp, &ws) * sizeof(double) <= 160 * 1024 && ws >= 2 * Hp * 4;
+}
+
 template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
   RolloutArgs<double> k = a;
   const bool rbf = a.lift_rbf != 0;
+  if constexpr (L_ == 20 && N_ == 20 && Q_ == 2) {
+    if (!rbf && a.dyn_group > 0 && rollout_dyn_available(a.s.n, a.s.L, a.s.N, a.s.q, a.Hp, a.Lp)) {
+      if (!a.s.qp_scratch) return hipErrorInvalidValue;
+      return (a.KS == 25 && a.Hp == 112) ? launch_rollout_dyn<L_, N_, Q_, 25>(a, s) : launch_rollout_dyn<L_, N_, Q_, 0>(a, s);
+    }
+  }
   const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
   if (waves == 0) return hipErrorInvalidValue;
   step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));

@@ -6,7 +6,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "koopman-online-updated-mpc_amd"))
 import numpy as np, torch
 from koopmpc import _ffi
-_ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), "libkoopmpc_trace.so")
+_ffi.LIB_PATH = os.path.join(os.path.dirname(_ffi.LIB_PATH), os.environ.get("KMPC_TRACE_LIB", "libkoopmpc_trace.so"))
 from koopmpc import KoopmanMPC
 from koopmpc.synth import random_mlp_weights, initial_states, offline_data
 
@@ -80,6 +80,13 @@ if fused:
     sl, sb = t[:, 20] / 100.0 / steps, t[:, 21] / 100.0 / steps
     print("whole launch, per wave and step: wait+lift mean %.2f (median %.2f) us, body mean %.2f (median %.2f, p90 %.2f) us"
           % (sl.mean(), np.median(sl), sb.mean(), np.median(sb), np.percentile(sb, 90)))
+    if t[:, 23].any():  # barrier-free kernel: time in the queue until the lift group was formed
+        sq = t[:, 23] / 100.0 / steps
+        print("  of which queueing for a lift group: mean %.2f (median %.2f, p90 %.2f) us; the group's lift itself: mean %.2f us"
+              % (sq.mean(), np.median(sq), np.percentile(sq, 90), (sl - sq).mean()))
+    if t[:, 25].any():
+        print("  lift timeline since the group was formed (mean us): layer 1 done %.2f, synced %.2f | hidden 1 done %.2f, synced %.2f | rest (summed) done %.2f synced %.2f"
+              % tuple((t[:, i] / 100.0 / steps).mean() for i in (24, 25, 26, 27, 28, 29)))
     fin = (t[:, 18] - t[:, 19].min()) / 100.0
     order = np.argsort(fin)
     for lo, hi in ((0, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)):
