@@ -1,21 +1,29 @@
 #!/usr/bin/env python3
 """MPC steps/s of the Koopman online-updated MPC hot path (lift -> RLS-EDMD update -> condensed QP ->
-box-QP) on MI355X, BASELINE.json configs[1]: Duffing, 20-dim MLP lift, N = 20, batch = 4096
-trajectories per GPU.
+box-QP) on MI355X.  Default workload: BASELINE.json configs[1] (cfg2: Duffing, 20-dim MLP lift, N = 20,
+4096 trajectories per GPU); --config cfg3 | cfg4 | cfg5 run the other BASELINE configurations with the
+same JSON shape.
 
     python bench.py --gpus 1 --steps 200 --warmup 20
+    python bench.py --gpus 8 --steps 200 --warmup 20          # starts its own 8 ranks (torch.distributed.run)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 \
            --master-port 29500 bench.py --gpus 8 --steps 200 --warmup 20
 
-A "step" is one closed-loop control step of every trajectory: kmpc_step (lift of the current state,
-RLS update with the previous transition, condensed-QP build, exact box-QP solve) followed by the RK4
-plant on the device; the whole loop is enqueued from C++ (kmpc_rollout), inputs are resident in HBM.
-Multi-GPU: trajectories are independent, every rank owns its own 4096 (weak scaling), no collective on
-the step path; the timed region is bracketed by barrier + synchronize and the MAX over ranks is used.
+A "step" is one closed-loop control step of every trajectory: lift of the current state, RLS update with
+the previous transition, condensed-QP build, exact box-QP solve, plant on the device; the whole loop is
+enqueued from C++ (kmpc_rollout; cfg4: one Python call per stage of the shared-model step), inputs are
+resident in HBM.  Multi-GPU: every rank owns its own trajectories (weak scaling); per-trajectory models
+(cfg2/3/5) need no collective on the step path, the shared model of cfg4 all-reduces its Gram block (RCCL)
+once per step.  The timed region is bracketed by barrier + synchronize, the MAX over ranks is used.
 
-Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel (step_kernel): algorithmic bytes
-(SURVEY.md 8d formula, kmpc_algorithmic_bytes_per_step) x trajectories per launch / its average
-duration measured with HIP events on the launch stream.  `cpu_baseline` times the NumPy oracle run the
+Controller state at the start of the timed region: --settle closed-loop steps after the RLS reset
+(duffing.py:927-930) are part of the set-up -- the reference loop runs 10 000 steps (duffing.py:823), the
+first few dozen after the reset are a transient of its estimator, not its operating regime; the same
+measurement right after the reset is reported beside the headline as `post_reset`.
+
+Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: algorithmic bytes (SURVEY.md 8d
+formula, kmpc_algorithmic_bytes_per_step) x trajectories x steps per launch / its duration measured with
+HIP events on the launch stream in the timed pass itself.  `cpu_baseline` times the NumPy oracle run the
 way the reference runs (per-trajectory Python loop, SciPy L-BFGS-B on the shooting cost,
 duffing.py:857-859) on a bounded sample of the same workload: one worker process per host core of the
 box's CPU share (16), forked before the GPU is touched; the single-core figure is reported beside it.
@@ -23,6 +31,8 @@ box's CPU share (16), forked before the GPU is touched; the single-core figure i
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,18 +40,71 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 for p in (ROOT, os.path.join(ROOT, "koopman-online-updated-mpc_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
+for v in ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS"):  # (before NumPy loads its BLAS: the CPU
+    os.environ.setdefault(v, "1")                                           #  baseline is one thread per worker)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
+# BASELINE.json configs[1..4] as workloads (per-GPU batch = the config's batch / the GPUs it names)
+CONFIGS = {
+    "cfg2": dict(L=20, N=20, B=4096, plant="duffing", lift="mlp", layers=3, output="Cx", lb=-2.0, ub=2.0, P0=1e4, barQ0=100.0,
+                 settle=200, text="BASELINE cfg2: Duffing closed loop, 20-dim MLP lift (2-100-100-100-20, random init seed 2024), "
+                                  "horizon N=20, box +-2, per-trajectory RLS, RK4 plant on device, parameter switch at step 102"),
+    "cfg3": dict(L=8, N=30, B=16384, plant="vdp", lift="rbf", output="Cx", lb=-2.0, ub=2.0, P0=1e5, barQ0=1e5, settle=60,
+                 text="BASELINE cfg3: Van der Pol closed loop as vanderpol_RBF.py (8 thin-plate RBF observables, y = C x, box +-2, "
+                      "model continued from the offline Gram = its 'storage' update :434-438), horizon N=30, RK4 plant on device, "
+                      "parameter switch at step 102"),
+    "cfg4": dict(L=32, N=40, B=8192, plant="tank", lift="mlp", layers=2, shared=True, settle=40,
+                 text="BASELINE cfg4: cascaded tanks (Tank_System.m), 32-dim MLP lift (2-100-100-32, random init seed 9), N=40, "
+                      "delta-u form with Cy = [0 1], ONE model for all trajectories of all ranks from the all-reduced EDMD Gram "
+                      "block (the only collective), plant switch at step 100; 65536 / 8 trajectories per GPU"),
+    "cfg5": dict(L=64, N=50, B=32768, plant="duffing", lift="mlp", layers=3, output="Cx", lb=-2.0, ub=2.0, P0=1e4, barQ0=100.0,
+                 settle=60, text="BASELINE cfg5: Duffing with time-varying parameters (switch at step 102), 64-dim MLP lift "
+                                 "(2-100-100-100-64, random init seed 2024), N=50, input box +-2, per-trajectory RLS, fp64; "
+                                 "262144 / 8 trajectories per GPU"),
+}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# workload definition shared by the GPU run and the CPU baseline
+# ------------------------------------------------------------------------------------------------------------------
+def workload_inputs(name, L, N):
+    """Host-side set-up data of a configuration: encoder / centres, offline samples, reference, plant name."""
+    from koopmpc.synth import offline_data, random_mlp_weights, tank_offline_data, vdp_rk4
+
+    c = CONFIGS[name]
+    w = {"cfg": c, "L": L, "N": N, "weights": None, "centres": None}
+    if name == "cfg4":
+        w["weights"] = random_mlp_weights(2, 100, 2, L, seed=9)
+        w["data"] = tank_offline_data()
+        w["ref"] = np.ones((1, N))
+    elif name == "cfg3":
+        X, Y, U = offline_data(plant=vdp_rk4)
+        rng = np.random.RandomState(0)
+        w["centres"] = X[:, rng.choice(X.shape[1], L, replace=False)].T.copy()  # (vanderpol_RBF.py:44-46 takes k-means centres of the data)
+        w["data"] = (X, Y, U)
+        w["ref"] = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    else:
+        w["weights"] = random_mlp_weights(2, 100, 3, L, seed=2024)
+        w["data"] = offline_data()
+        w["ref"] = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    return w
+
+
+def initial_states_for(name, B, seed):
+    from koopmpc.synth import initial_states
+
+    if name == "cfg4":
+        return np.abs(np.random.RandomState(seed).rand(2, B))  # tank levels in [0, 1]
+    return initial_states(B, seed=seed)
+
 
 def _cpu_worker(args):
-    """One host core: per-trajectory loop, lift -> solve -> plant -> RLS in the reference's order (duffing.py:823-1012)
-    through the oracle, for `budget_s` seconds.  Returns (trajectory-steps done, seconds)."""
-    os.environ["OMP_NUM_THREADS"] = "1"  # (one core means one core: no BLAS threads behind the loop)
-    weights, A0, B0, C0, x0s, L, N, budget_s, solver, steps_per_traj = args
+    """One host core: per-trajectory loop in the reference's order (duffing.py:823-1012) through the oracle, for
+    `budget_s` seconds.  Returns (trajectory-steps done, seconds)."""
+    name, L, N, x0s, budget_s, solver, spt = args
     from oracle import koopman_oracle as ko
 
     try:
@@ -50,46 +113,140 @@ def _cpu_worker(args):
         threadpoolctl.threadpool_limits(1)
     except Exception:
         pass
-    lift = lambda x: ko.mlp_lift(weights, x)
-    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    w = workload_inputs(name, L, N)
+    c = w["cfg"]
+    X, Y, U = w["data"]
+    if c["lift"] == "rbf":
+        lift = lambda x: ko.rbf_lift(x, w["centres"])
+    else:
+        lift = lambda x: ko.mlp_lift(w["weights"], x)
+    PX, PY = lift(X), lift(Y)
+    Z = np.concatenate([PX, U[None, :]], 0)
+    K0 = PY @ np.linalg.pinv(Z)  # the reference's one-off fit (duffing.py:152-177)
+    A0, B0, C0 = K0[:, :-1], K0[:, -1:], X @ np.linalg.pinv(PX)
+    r = w["ref"]
     t0 = time.perf_counter()
     done = 0
+    if name == "cfg4":
+        # Tank_System.m:170-291 for a small pool of trajectories that share ONE model (pooled Gram sums, Koopman_update.m:94-101)
+        nb = x0s.shape[1]
+        sh = ko.SharedEdmd(L, 2, P0=1e4, barQ0=1e4)
+        ctl = [ko.OracleDeltaUController(lift, L, 2, N, A0, B0, C0) for _ in range(nb)]
+        xs = x0s.copy()
+        prev = None
+        for k in range(spt):
+            Psi = lift(xs)
+            if prev is not None:
+                sh.add(*ko.SharedEdmd.gram(prev[0], prev[1], Psi, xs))
+                A, Bm, C = sh.model()
+                for cc in ctl:
+                    cc.A, cc.B, cc.C = A, Bm, C
+            us = np.zeros(nb)
+            for t in range(nb):
+                cc = ctl[t]
+                At, Bt, Co, xt = cc.qp(Psi[:, t])
+                _, _, H, f, _ = ko.condense(At, Bt, Co, xt, r, N, cc.Qw, cc.Rw)
+                lbv = np.full(N, cc.lb); ubv = np.full(N, cc.ub)
+                lbv[0] = max(cc.lb, cc.umin - cc.u); ubv[0] = min(cc.ub, cc.umax - cc.u)
+                try:
+                    dU, _ = ko.qp_exact(H, f, lbv, ubv)  # (quadprog of the MATLAB loop is an exact solver too)
+                except np.linalg.LinAlgError:  # (a pooled model of the first steps can make H numerically singular: keep the input)
+                    dU = np.zeros(N)
+                cc.u += float(dU[0]); us[t] = cc.u
+                xs[:, t] = ko.tank_step(xs[:, t], cc.u)
+                done += 1
+            prev = (Psi, us.copy())
+            if time.perf_counter() - t0 > budget_s:
+                break
+        return done, time.perf_counter() - t0
     for t in range(x0s.shape[1]):
-        ctl = ko.OracleController(lift, L, 2, N, -2.0, 2.0, A0, B0, C0, solver=solver)
+        ctl = ko.OracleController(lift, L, 2, N, c["lb"], c["ub"], A0, B0, C0, P0=c["P0"], barQ0=c["barQ0"], solver=solver)
+        if name == "cfg3":  # continue from the offline Gram (vanderpol_RBF.py:434-438 in recursive form)
+            ctl.rls.K_A = PY @ Z.T
+            ctl.rls.P = np.linalg.pinv(Z @ Z.T)
+            ctl.rls.bar_X = X @ PX.T
+            ctl.rls.bar_Q = np.linalg.pinv(PX @ PX.T)
         x = x0s[:, t].copy()
-        for k in range(steps_per_traj):
+        for k in range(spt):
             u, _, _ = ctl.step(x, r)
-            x = ko.plant_step("duffing", x, u)
+            x = ko.plant_step(c["plant"], x, u)
             done += 1
+            if time.perf_counter() - t0 > budget_s:
+                break
         if time.perf_counter() - t0 > budget_s:
             break
     return done, time.perf_counter() - t0
 
 
-def cpu_baseline(weights, x0s, L, N, budget_s):
-    """The reference's path on the host cores, timed BEFORE this process touches the GPU (the workers are forked):
-    the NumPy oracle run the way the reference runs -- per-trajectory Python loop, SciPy L-BFGS-B on the shooting cost
-    (duffing.py:857-859) -- on one core and on the box's CPU share (one trajectory stream per core, trajectories are
-    independent); the exact-QP variant of the oracle on one core beside it.  Bounded by `budget_s` per leg."""
+def cpu_baseline(name, L, N, x0s, budget_s):
+    """The reference's path on the host cores, timed BEFORE this process touches the GPU (the workers are forked): on one core
+    and on the box's CPU share (one trajectory stream per core); the exact-QP variant of the oracle on one core beside it."""
     import multiprocessing as mp
 
-    from koopmpc.synth import offline_edmd
-    from oracle import koopman_oracle as ko
-
-    A0, B0, C0 = offline_edmd(lambda X: ko.mlp_lift(weights, X))  # the reference's one-off fit (duffing.py:152-177)
     spt = 8
     cores = max(1, min(16, os.cpu_count() or 1))  # a one-GPU box comes with 16 host cores
-    one = _cpu_worker((weights, A0, B0, C0, x0s, L, N, budget_s / 3.0, "lbfgsb", spt))
-    exact = _cpu_worker((weights, A0, B0, C0, x0s, L, N, budget_s / 3.0, "exact", spt))
-    per = max(1, x0s.shape[1] // cores)
-    jobs = [(weights, A0, B0, C0, x0s[:, i * per:(i + 1) * per], L, N, budget_s, "lbfgsb", spt) for i in range(cores)]
+    solver = "exact" if name == "cfg4" else "lbfgsb"
+    one = _cpu_worker((name, L, N, x0s[:, :64], budget_s / 3.0, solver, spt))
+    exact = _cpu_worker((name, L, N, x0s[:, :64], budget_s / 3.0, "exact", spt)) if solver != "exact" else one
+    per = max(1, min(64 if name == "cfg4" else 1 << 30, x0s.shape[1] // cores))
+    jobs = [(name, L, N, x0s[:, i * per:(i + 1) * per], budget_s, solver, spt) for i in range(cores)]
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
     done = sum(d for d, _ in res)
     return {"all": (done / wall, done, wall, cores), "one": (one[0] / one[1], one[0], one[1]),
-            "exact": (exact[0] / exact[1], exact[0], exact[1]), "spt": spt}
+            "exact": (exact[0] / exact[1], exact[0], exact[1]), "spt": spt, "solver": solver}
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as children (before this process has made any
+    GPU call -- a process that has initialised the GPU must not be replaced or forked) and hand back their exit code."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+class Loop:
+    """One configuration's closed loop on one GPU: controller + state, advance(steps, step0)."""
+
+    def __init__(self, name, w, B, dtype, dev, rank, cold=False, threads=0):
+        import torch
+        from koopmpc import KoopmanMPC
+
+        c = w["cfg"]
+        self.name, self.c, self.B, self.dev, self.torch = name, c, B, dev, torch
+        L, N = w["L"], w["N"]
+        if name == "cfg4":
+            self.m = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=w["weights"], layers=2, lb=-0.5, ub=0.5, umin=-8.0, umax=8.0, Qw=10.0,
+                                Rw=1e-3, P0=1e4, barQ0=1e4, delta_u=True, out_row0=1, out_rows=1, dtype=dtype, device=dev,
+                                cold_start=cold, threads=threads)
+            self.m.offline_fit(*w["data"], ridge=1e-9)
+        elif name == "cfg3":
+            self.m = KoopmanMPC(n=2, L=L, N=N, batch=B, lift="rbf", centres=w["centres"], output="Cx", lb=c["lb"], ub=c["ub"],
+                                P0=c["P0"], barQ0=c["barQ0"], dtype=dtype, device=dev, cold_start=cold, threads=threads)
+            self.m.offline_fit(*w["data"], ridge=1e-9, init_rls=True)
+        else:
+            self.m = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=w["weights"], dtype=dtype, threads=threads, device=dev,
+                                cold_start=cold, lb=c["lb"], ub=c["ub"])
+            self.m.offline_fit(*w["data"])
+        self.X = torch.tensor(initial_states_for(name, B, 101 + rank), dtype=dtype, device=dev).contiguous()
+        self.r = torch.tensor(w["ref"], dtype=dtype, device=dev)
+        self.shared = bool(c.get("shared"))
+
+    def advance(self, steps, step0):
+        if not self.shared:
+            self.m.rollout(self.c["plant"], self.X, self.r, steps, step0=step0)
+            return
+        for k in range(step0, step0 + steps):  # shared model: local Gram sums -> all-reduce -> model, QPs; plant
+            u = self.m.shared_step(self.X, self.r)
+            self.X = self.m.plant_step("tank", self.X, u, switched=(k > 100))
 
 
 def main():
@@ -97,32 +254,40 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--batch", type=int, default=4096, help="trajectories per GPU")
-    ap.add_argument("--L", type=int, default=20)
-    ap.add_argument("--N", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0: the configuration's)")
+    ap.add_argument("--L", type=int, default=0)
+    ap.add_argument("--N", type=int, default=0)
     ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--settle", type=int, default=-1,
+                    help="closed-loop steps after the RLS reset that belong to the set-up (-1: the configuration's default)")
     ap.add_argument("--cold-start", action="store_true",
                     help="start every QP at clip(0) like the reference instead of at the previous minimiser")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
     ap.add_argument("--spin-seconds", type=float, default=1.0,
                     help="untimed GPU activity on a scratch copy of the workload before the warm-up, so that the "
                          "clocks have left their idle state when the W warm-up steps start")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cold-start and post-reset measurements")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.gpus != world:
-        if args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d "
-                     "(WORLD_SIZE=%d)" % (args.gpus, args.gpus, world))
+        sys.exit("bench.py --gpus %d inside a %d-rank job" % (args.gpus, world))
+    name = args.config
+    c = CONFIGS[name]
+    L, N, B = args.L or c["L"], args.N or c["N"], args.batch or c["B"]
+    settle = c["settle"] if args.settle < 0 else args.settle
     # ---- CPU baseline first (rank 0 at N = 1 only): its worker processes are forked before anything touches the GPU
     cpu = None
     if world == 1 and args.cpu_seconds > 0:
-        from koopmpc.synth import initial_states as _init, random_mlp_weights as _rw
+        cpu = cpu_baseline(name, L, N, initial_states_for(name, min(B, 4096), 101), args.cpu_seconds)
+    import torch
 
-        cpu = cpu_baseline(_rw(2, 100, 3, args.L, seed=2024), _init(args.batch, seed=101), args.L, args.N, args.cpu_seconds)
     if not torch.cuda.is_available():
         if cpu is not None:
             print("cpu_baseline (no GPU here, nothing else measured): %s" % json.dumps(cpu), file=sys.stderr)
@@ -135,20 +300,10 @@ def main():
 
         dist.init_process_group("nccl", device_id=dev)
 
-    from koopmpc import KoopmanMPC, max_over_ranks
-    from koopmpc.synth import initial_states, offline_data, random_mlp_weights
+    from koopmpc import max_over_ranks
 
-    L, N, B = args.L, args.N, args.batch
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
-    weights = random_mlp_weights(2, 100, 3, L, seed=2024)
-    mpc = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev,
-                     cold_start=args.cold_start)
-    # one-off offline EDMD fit (duffing.py:152-177) on the device: lift, MFMA Gram sums, p x p solve; identical on
-    # every rank; the fitted model is handed to every trajectory
-    A0, B0, C0 = [t.cpu().numpy() for t in mpc.offline_fit(*offline_data())]
-    x0 = initial_states(B, seed=101 + rank)
-    X = torch.tensor(x0, dtype=dtype, device=dev).contiguous()
-    r = torch.tensor(np.tile(np.array([[1.0], [0.0]]), (1, N)), dtype=dtype, device=dev)
+    w = workload_inputs(name, L, N)
 
     def sync_all():
         torch.cuda.synchronize(dev)
@@ -156,89 +311,105 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    # ---- warm-up (untimed), then EXACTLY --steps timed steps
-    mpc.rollout("duffing", X, r, args.warmup, step0=0)
-    torch.cuda.synchronize(dev)
-    replay = args.steps <= 4096
-    sd0, X0 = mpc.state_to(), X.clone()  # device-side snapshot of the state the timed region starts from
-    # ---- bring the GPU out of its idle power state: a scratch controller runs the timed region's own steps from
-    #      the snapshot (same launches as the timed one, so a rocprofv3 --stats average over the process is
-    #      comparable with the number reported below); it does not touch the workload's controller
-    if args.spin_seconds > 0:
-        scratch = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=weights, dtype=dtype, threads=args.threads, device=dev,
-                             cold_start=args.cold_start)
-        Xs = X.clone()
-        t_spin = time.perf_counter()
-        while time.perf_counter() - t_spin < args.spin_seconds:
-            scratch.state_from(sd0)
-            Xs.copy_(X0)
-            scratch.rollout("duffing", Xs, r, args.steps, step0=args.warmup)
-            torch.cuda.synchronize(dev)
-        del scratch, Xs
-    sync_all()
-    t0 = time.perf_counter()
-    mpc.rollout("duffing", X, r, args.steps, step0=args.warmup)
-    torch.cuda.synchronize(dev)
-    if dist is not None:
-        dist.barrier()
-    torch.cuda.synchronize(dev)
-    dt = max_over_ranks(time.perf_counter() - t0, device=dev)
-    worst_status = int(mpc.status.max().item())
-    newton_per_step = float(mpc.iters.double().mean().item()) / max(1, args.steps)
-    newton_max = int(mpc.iters.max().item())
+    def timed(loop, steps, step0, profile=False):
+        """barrier + synchronize | steps | synchronize + barrier; MAX over ranks"""
+        sync_all()
+        if profile:
+            loop.m.profile(True)
+        t0 = time.perf_counter()
+        loop.advance(steps, step0)
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+        return max_over_ranks(time.perf_counter() - t0, device=dev)
 
-    # ---- kernel durations for the roofline: the timed region's steps replayed from the snapshot (same
-    #      states, same models, bitwise the same controls) with HIP events around every lift / step kernel on
-    #      the launch stream.  Kept out of the timed pass itself: the event packets cost ~10 % of a step.
-    X_timed = X.clone()
-    fused = mpc.rollout_is_fused()
-    if replay:
-        step0 = args.warmup
-        nprof = args.steps
-    else:
-        step0 = args.warmup + args.steps
-        nprof = 1000
-    # (the first replay follows host-side work -- status read-back, snapshot restore -- and runs at a lower
-    #  clock; it is discarded, the next two are averaged)
-    for rep in range(3 if replay else 1):
-        if replay:
-            mpc.state_from(sd0)
-            X.copy_(X0)
-        if rep == (1 if replay else 0):
-            mpc.profile(True)
-        mpc.rollout("duffing", X, r, nprof, step0=step0)
+    def spin(loop, seconds, steps, step0, snap):
+        """bring the GPU out of its idle power state with the timed region's own launches on a scratch controller"""
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < seconds:
+            if snap is not None:
+                loop.m.state_from(snap[0]); loop.X.copy_(snap[1])
+            loop.advance(steps, step0)
+            torch.cuda.synchronize(dev)
+
+    # ---- the workload's controller: set-up (offline fit, settle), warm-up (untimed), then EXACTLY --steps timed steps
+    main_loop = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
+    main_loop.advance(settle, 0)
+    main_loop.advance(args.warmup, settle)
     torch.cuda.synchronize(dev)
-    pr = mpc.profile_read()
-    mpc.profile(False)
-    if replay and not torch.equal(X_timed, X):
-        sys.exit("bench.py: the replayed region did not reproduce the timed region's states")
-    # fused roll-out: ONE launch covers all nprof steps (lift inside); otherwise one lift + one step kernel per step
-    steps_per_launch = nprof if fused else 1
-    launch_ms = pr["step_ms"] / max(1, pr["count"]) * steps_per_launch
-    lift_ms = pr["lift_ms"] / max(1, pr["count"])
+    step0 = settle + args.warmup
+    can_snap = not main_loop.shared
+    snap = (main_loop.m.state_to(), main_loop.X.clone()) if can_snap else None
+    scratch = None
+    if args.spin_seconds > 0 or not args.no_extras:
+        scratch = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
+        if args.spin_seconds > 0:
+            if not can_snap:
+                scratch.advance(settle + args.warmup, 0)
+            spin(scratch, args.spin_seconds, args.steps, step0, snap)
+    dt = timed(main_loop, args.steps, step0, profile=True)
+    pr = main_loop.m.profile_read()
+    main_loop.m.profile(False)
+    mpc = main_loop.m
+    worst_status = int(mpc.status.max().item())
+    newton_per_step = float(mpc.iters.double().mean().item()) / (max(1, args.steps) if not main_loop.shared else 1)
+    newton_max = int(mpc.iters.max().item())
+    x_ok = bool(torch.isfinite(main_loop.X).all().item())
+    fused = bool(mpc.rollout_is_fused()) and not main_loop.shared
+    # dominant kernel: the timed pass's own launches between HIP events on the launch stream
+    steps_per_launch = args.steps if fused else 1
+    launches = max(1, pr["count"] // steps_per_launch)
+    launch_ms = pr["step_ms"] / launches
+    lift_ms = pr["lift_ms"] / launches
     bytes_per_traj = mpc.algorithmic_bytes_per_step()
     bytes_per_launch = bytes_per_traj * B * steps_per_launch
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
-    x_ok = bool(torch.isfinite(X).all().item())
+
+    # ---- beside the headline: every solve started at clip(0) as the reference does; the same window right after the reset
+    extras = {}
+    if not args.no_extras and scratch is not None:
+        if can_snap and not args.cold_start:
+            cold = Loop(name, w, B, dtype, dev, rank, cold=True, threads=args.threads)
+            cold.m.state_from(snap[0]); cold.X.copy_(snap[1])
+            dtc = timed(cold, args.steps, step0)
+            extras["cold_start"] = {"value": B * world * args.steps / dtc, "ms_per_step": dtc / args.steps * 1e3,
+                                    "mean_newton_solves_per_step": float(cold.m.iters.double().mean().item()) / max(1, args.steps),
+                                    "note": "same state, every QP started at clip(0) like the reference (duffing.py:634-635, 859): same minimiser, more work"}
+            del cold
+        fresh = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
+        fresh.advance(args.warmup, 0)
+        dtp = timed(fresh, args.steps, args.warmup)
+        extras["post_reset"] = {"value": B * world * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3,
+                                "mean_newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if not fresh.shared else 1),
+                                "note": "the same %d timed steps after %d warm-up steps counted from the RLS reset (no settle steps): the estimator's "
+                                        "start-up transient, ill-conditioned QPs with many active-set changes" % (args.steps, args.warmup)}
+        del fresh
 
     if dist is not None:
         flag = torch.tensor([worst_status, 0 if x_ok else 1], device=dev)
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         worst_status, x_ok = int(flag[0].item()), int(flag[1].item()) == 0
 
-    # HBM bytes per launch from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
-    # own-pattern calibration): collected offline with tools/one_phase.py, committed in profiles/
+    # HBM bytes per trajectory-step from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
+    # own-pattern calibration), collected with tools/profile_bench.sh and committed in profiles/
     traffic, traffic_note = None, "not collected for this configuration"
-    tp = os.path.join(ROOT, "profiles", "r1_traffic_fused.json" if fused else "r1_traffic.json")
-    if os.path.exists(tp) and (L, N, B, args.dtype) == (20, 20, 4096, "f64"):
-        tj = json.load(open(tp))
-        if not fused or tj.get("steps_per_launch") == steps_per_launch:
-            traffic = tj["traffic_bytes_per_launch"]
-            traffic_note = "bytes per launch, rocprofv3 PMC passes recorded in profiles/%s (FETCH x %.3f own-pattern calibration + WRITE)" % (
-                os.path.basename(tp), tj["fetch_calibration"])
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        tj = json.load(open(tp)).get("%s:%s:%s" % (name, args.dtype, "fused" if fused else "steps"))
+        if tj and (tj["L"], tj["N"]) == (L, N):
+            traffic = tj["bytes_per_trajectory_step"] * B * steps_per_launch
+            traffic_note = "bytes per launch = %.0f B per trajectory-step (rocprofv3 PMC passes at B = %d, %s) x trajectories x steps per launch" % (
+                tj["bytes_per_trajectory_step"], tj["B"], tj["source"])
 
     if rank == 0:
         total = B * world
+        if main_loop.shared:
+            kname = "step_kernel (box QPs of the shared model, %d blocks x 64 threads); lift, Gram (MFMA), model solve and condense are separate launches" % B
+        elif fused:
+            kname = "rollout_kernel (lift + RLS + condense + QP + plant, all %d steps in one launch), %d workgroups" % (steps_per_launch, (B + 15) // 16)
+        else:
+            kname = "step_kernel (RLS + condense + QP + plant), %d blocks x %d threads" % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64))
         out = {
             "metric": "MPC steps/s (lift+EDMD-update+QP, N=%d, %d-dim lift)" % (N, L),
             "value": total * args.steps / dt,
@@ -253,25 +424,23 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE cfg2: Duffing closed loop, %d-dim MLP lift (2-100-100-100-%d, random init seed 2024), "
-                            "horizon N=%d, box +-2, %d trajectories per GPU x %d GPU(s), per-trajectory RLS, "
-                            "RK4 plant on device, parameter switch at step 102; arithmetic in %s (the config line names fp32; the "
-                            "reference computes in float64 and the 1e-6 bar on u needs it, DESIGN.md 4.1)" % (L, L, N, B, world, args.dtype),
+                "workload": "%s; %d trajectories per GPU x %d GPU(s); controller state: %d closed-loop steps after the RLS reset (set-up) + the "
+                            "warm-up; arithmetic in %s%s" % (c["text"], B, world, settle, args.dtype,
+                                                            " (the config line names fp32; the reference computes in float64 and the 1e-6 bar on u needs it, DESIGN.md 4.1)" if name == "cfg2" else ""),
                 "global_batch": total,
-                "parallelism": "trajectory-sharded x%d, no collective on the step path" % world,
+                "parallelism": ("trajectory-sharded x%d, one RCCL all-reduce of the %d-element Gram block per step" % (world, (2 * L + 3) * (L + 1))) if main_loop.shared
+                               else "trajectory-sharded x%d, no collective on the step path" % world,
                 "qp": "exact box-QP (projected Newton), %s; mean Newton solves/step %.2f, worst trajectory total %d"
                       % ("each solve started at clip(0) like the reference" if args.cold_start else
                          "each solve started at the previous minimiser (the reference restarts at zeros: same minimiser, more work)",
                          newton_per_step, newton_max),
                 "worst_qp_status": worst_status,
                 "finite": x_ok,
+                "u_tolerance": "controls within 1e-6 of the oracle in float64 (Van der Pol with P0 = 1e5: 1e-4, the re-association floor of the reference's own K_A inv_K_G product, DESIGN.md 2)",
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": ("rollout_kernel (lift + RLS + condense + QP + plant, all %d steps in one launch), %d workgroups x 1024 threads"
-                           % (steps_per_launch, (B + 15) // 16)) if fused else
-                          ("step_kernel (RLS + condense + QP), %d blocks x %d threads"
-                           % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64))),
+                "kernel": kname,
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -283,8 +452,10 @@ def main():
                 "steps_per_launch": steps_per_launch,
                 "avg_kernel_ms": launch_ms,
                 "avg_lift_kernel_ms": lift_ms,
+                "kernel_time_source": "HIP events around the launches of the timed pass itself",
             },
         }
+        out.update(extras)
         if cpu is not None:
             v, done, secs, cores = cpu["all"]
             v1, done1, secs1 = cpu["one"]
@@ -295,9 +466,11 @@ def main():
                 "cores": cores,
                 "kind": "port",
                 "sample": "%d worker processes (one per core), each the first trajectories of its slice of the same workload x %d "
-                          "closed-loop steps: %d trajectory-steps in %.1f s; NumPy oracle with SciPy L-BFGS-B exactly as "
-                          "duffing.py:857-859, one BLAS thread per worker; host reports %d cores"
-                          % (cores, cpu["spt"], done, secs, os.cpu_count()),
+                          "closed-loop steps: %d trajectory-steps in %.1f s; NumPy oracle, %s, one BLAS thread per worker; host reports %d cores"
+                          % (cores, cpu["spt"], done, secs,
+                             "SciPy L-BFGS-B exactly as duffing.py:857-859" if cpu["solver"] == "lbfgsb" else
+                             "exact active-set QP in place of quadprog (Tank_System.m:190), one pooled model per worker's 64 trajectories",
+                             os.cpu_count()),
                 "single_core_value": v1,
                 "single_core_sample": "%d trajectory-steps in %.1f s" % (done1, secs1),
                 "exact_qp_variant_single_core_value": ve,

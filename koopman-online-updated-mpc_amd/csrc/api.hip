@@ -700,7 +700,22 @@ struct Impl : kmpc_handle {
     a.psi_now = dPsi[cur]; a.pn_sl = 1; a.pn_sb = L;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
     a.x_warm = cfg.cold_start ? nullptr : dWarm;
+    const bool rec = prof && ev_used + 3 <= EV_CAP;  // (profiling: the QP launch of the shared-model step)
+    if (rec) {
+      while (ev.size() < ev_used + 3) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreate(&e));
+        ev.push_back(e);
+      }
+      HIPCHK(hipEventRecord(ev[ev_used], s));
+      HIPCHK(hipEventRecord(ev[ev_used + 1], s));
+    }
     HIPCHK(launch_step<T>(a, threads, s));
+    if (rec) {
+      HIPCHK(hipEventRecord(ev[ev_used + 2], s));
+      ev_used += 3;
+      prof_steps += 1;
+    }
     have_prev = true;
     cur ^= 1;
     return 0;
