@@ -88,6 +88,9 @@ int kmpc_version(void);
 /* ---- parameters (host pointers, float64, row-major; one-off uploads) ---------------- */
 /* net.Encoder layer `layer` (0-based): y = W x + b, W rows x cols   duffing.py:21-28,
  * Encoder_Duffing.m:2-6 */
+int kmpc_set_encoder(kmpc_handle* h, int layer, const double* W_host, const double* b_host,
+                     int rows, int cols);
+/* (the same call under its round-1 name) */
 int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W_host, const double* b_host,
                            int rows, int cols);
 /* RBF centres cx (L x n)                                             vanderpol_RBF.py:44-46 */
@@ -136,6 +139,22 @@ int kmpc_get_model(kmpc_handle* h, void* A_dev, void* B_dev, void* C_dev, void* 
  * ref_per_traj == 0, else [B][q][N].                                                        */
 int kmpc_condense(kmpc_handle* h, const void* psi_dev, const void* ref_dev, int ref_per_traj,
                   void* H_dev, void* f_dev, int B, void* stream);
+/* ... with the constant as well: c_dev [B] such that u'Hu + f'u + c IS costFunction(u) (duffing.py:540-581);
+ * c + the optimal value of the QP is the `result.fun` of duffing.py:859.  c_dev may be NULL.                 */
+int kmpc_condense_cost(kmpc_handle* h, const void* psi_dev, const void* ref_dev, int ref_per_traj,
+                       void* H_dev, void* f_dev, void* c_dev, int B, void* stream);
+
+/* The MPC solve wrapper as a stateless call (duffing.py:857-861 with the model as an argument; SURVEY 8b
+ * mpc_solve(A, B, C, xlift, r, lb, ub, Q, R[, P_N])): condensed QP of the GIVEN models and exact box-QP, nothing of
+ * the handle's estimator state is read or written.  A_dev [B][L][L], B_dev [B][L], C_dev [B][n][L] (NULL for
+ * KMPC_OUT_LIFT), or ONE model for the batch when model_shared = 1; psi_dev (L x B); ref as in kmpc_condense;
+ * lb, ub, Qw, Rw override the handle's for this call; PN_host (q x q, may be NULL) the terminal block.
+ * Outputs: U_dev (N x B), U0_dev [B] (may be NULL), fun_dev [B] = J at the minimiser (may be NULL), status / iters.
+ * Every solve starts at clip(0) like the reference.  B must equal the handle's batch.                          */
+int kmpc_mpc_solve(kmpc_handle* h, const void* A_dev, const void* B_dev, const void* C_dev, int model_shared,
+                   const void* psi_dev, const void* ref_dev, int ref_per_traj, double lb, double ub, double Qw,
+                   double Rw, const double* PN_host, void* U_dev, void* U0_dev, void* fun_dev, int32_t* status_dev,
+                   int32_t* iters_dev, int B, void* stream);
 
 /* Box QP  min u'Hu + f'u, lb <= u <= ub  -- replaces optimize.minimize(..., bounds=...)
  * duffing.py:857-861 and quadprog(2H, f, ...) Koopman_update.m:214.  H_dev [B][N][N],
@@ -190,6 +209,19 @@ int kmpc_shared_get_model(kmpc_handle* h, void* A_dev, void* B_dev, void* C_dev,
  * K_A = 0 (the Python scripts' behaviour, duffing.py:927-930, which init_rls = 0 keeps).                    */
 int kmpc_offline_fit(kmpc_handle* h, const void* X_dev, const void* Y_dev, const void* U_dev, int M,
                      double ridge, int init_rls, void* A_dev, void* B_dev, void* C_dev, void* stream);
+/* Data generation + offline fit as ONE device pipeline (data_generate.py:17-79 -> duffing.py:152-177):
+ * n_traj trajectories start at X0_dev (n x n_traj) and take n_steps plant steps (RK4 Duffing / Van der Pol, tank map;
+ * nominal parameters) with the inputs U_dev (n_steps x n_traj) -- the caller draws x0 and u (the reference uses
+ * np.random with seed 101) --, the M = n_traj * n_steps transitions are lifted, their Gram sums formed on MFMA and the
+ * model solved exactly as kmpc_offline_fit does; nothing returns to the host in between.  X_out_dev / Y_out_dev
+ * (n x M, sample i * n_traj + t; may be NULL) receive the generated samples.                                       */
+int kmpc_generate_and_fit(kmpc_handle* h, int plant, const void* X0_dev, const void* U_dev, int n_traj, int n_steps,
+                          double hstep, double ridge, int init_rls, void* A_dev, void* B_dev, void* C_dev,
+                          void* X_out_dev, void* Y_out_dev, void* stream);
+
+/* The input that was APPLIED at the last step, when it is not the u_k kmpc_step returned (actuator limits, a logged
+ * trajectory that is being followed): U_dev [B]; the next RLS update regresses on it (z = [psi; u], duffing.py:900). */
+int kmpc_set_applied_input(kmpc_handle* h, const void* U_dev, int B, void* stream);
 
 /* ---- adjacent to the path: the plant on the device ---------------- */
 /* X <- RK4(f, X, U, h) in place: duffing.py:250-261 / vanderpol_RBF.py:113; `switched`

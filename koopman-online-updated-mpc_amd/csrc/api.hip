@@ -11,6 +11,7 @@
 #include "../../include/koopmpc.h"
 #include "kernels.h"
 #include <dlfcn.h>
+#include <rccl/rccl.h>  // types and enumerators only (ncclDouble, ncclSum): the library resolves ncclAllReduce at run time
 
 using namespace kmpc;
 
@@ -33,11 +34,18 @@ struct kmpc_handle {
   virtual int lift(const void* X, void* Psi, int B, hipStream_t s) = 0;
   virtual int rls_update(const void* psi, const void* u, const void* psin, const void* xn, int B, hipStream_t s) = 0;
   virtual int get_model(void* A, void* B, void* C, hipStream_t s) = 0;
-  virtual int condense(const void* psi, const void* ref, int rpt, void* H, void* f, int B, hipStream_t s) = 0;
+  virtual int condense(const void* psi, const void* ref, int rpt, void* H, void* f, void* c, int B, hipStream_t s) = 0;
+  virtual int mpc_solve(const void* A, const void* Bv, const void* C, int shared, const void* psi, const void* ref, int rpt,
+                        double lb, double ub, double Qw, double Rw, const double* PN, void* U, void* U0, void* fun,
+                        int32_t* st, int32_t* it, int B, hipStream_t s) = 0;
+  virtual int generate_and_fit(int plant, const void* X0, const void* U, int n_traj, int n_steps, double hs, double ridge,
+                               int init_rls, void* A, void* B, void* C, void* Xo, void* Yo, hipStream_t s) = 0;
+  int device = 0;
   virtual int qp_solve(const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, hipStream_t s) = 0;
   virtual int step(const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it,
                    hipStream_t s) = 0;
   virtual int plant_step(int plant, void* X, const void* U, double h, int sw, int B, hipStream_t s) = 0;
+  virtual int set_applied_input(const void* U, int B, hipStream_t s) = 0;
   virtual int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
                       void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) = 0;
   virtual int offline_fit(const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A,
@@ -159,7 +167,8 @@ struct Impl : kmpc_handle {
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
-                      (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr})
+                      (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -436,16 +445,76 @@ struct Impl : kmpc_handle {
     return 0;
   }
 
-  int condense(const void* psi, const void* ref, int rpt, void* H, void* f, int Bc, hipStream_t s) override {
+  int condense(const void* psi, const void* ref, int rpt, void* H, void* f, void* c, int Bc, hipStream_t s) override {
     if (Bc != B) FAIL(-3, "kmpc_condense: B must equal the handle's batch");
     if (!psi || !ref || !H || !f) FAIL(-3, "kmpc_condense: null pointer");
     StepArgs<T> a = base_args(Bc);
     a.phases = PH_CONDENSE;
     a.psi_now = (const T*)psi; a.pn_sl = Bc; a.pn_sb = 1;
     a.ref = (const T*)ref; a.ref_per_traj = rpt;
-    a.H_out = (T*)H; a.f_out = (T*)f;
+    a.H_out = (T*)H; a.f_out = (T*)f; a.c_out = (T*)c;
     HIPCHK(launch_step<T>(a, threads, s));
     return 0;
+  }
+
+  // kmpc_mpc_solve: the solve wrapper with the model as an argument; scratch model blocks, H, f, c are the handle's
+  T *dMsK = nullptr, *dMsC = nullptr, *dMsH = nullptr, *dMsf = nullptr, *dMsc = nullptr, *dMsW = nullptr;
+  int mpc_solve(const void* A, const void* Bv, const void* C, int shared, const void* psi, const void* ref, int rpt,
+                double lb_, double ub_, double Qw_, double Rw_, const double* PN, void* U, void* U0, void* fun,
+                int32_t* st, int32_t* it, int Bc, hipStream_t s) override {
+    if (Bc != B) FAIL(-3, "kmpc_mpc_solve: B must equal the handle's batch");
+    if (!A || !Bv || !psi || !ref || !U) FAIL(-3, "kmpc_mpc_solve: null pointer");
+    if (cfg.output_kind == KMPC_OUT_CX && !C) FAIL(-3, "kmpc_mpc_solve: C is required for KMPC_OUT_CX");
+    if (cfg.delta_u) FAIL(-3, "kmpc_mpc_solve: not available in the delta-u form (its state includes the handle's u_prev)");
+    if (!(ub_ > lb_)) FAIL(-3, "kmpc_mpc_solve: need lb < ub");
+    if (!dMsK) {
+      HIPCHK(hipMalloc(&dMsK, sizeof(T) * (size_t)sK * B));
+      HIPCHK(hipMalloc(&dMsC, sizeof(T) * (size_t)sC * B));
+      HIPCHK(hipMalloc(&dMsH, sizeof(T) * (size_t)B * N * N));
+      HIPCHK(hipMalloc(&dMsf, sizeof(T) * (size_t)B * N));
+      HIPCHK(hipMalloc(&dMsc, sizeof(T) * (size_t)B));
+      HIPCHK(hipMalloc(&dMsW, sizeof(T) * (size_t)q * q));
+    }
+    HIPCHK(launch_import_model<T>((const T*)A, (const T*)Bv, (const T*)C, shared, n, L, B, dMsK, sK,
+                                  cfg.output_kind == KMPC_OUT_CX ? dMsC : nullptr, sC, s));
+    if (PN) {
+      std::vector<T> w((size_t)q * q);
+      for (int r = 0; r < q; ++r)
+        for (int c2 = 0; c2 < q; ++c2) w[(size_t)r * q + c2] = (T)(PN[(size_t)r * q + c2] - (r == c2 ? Qw_ : 0.0));
+      HIPCHK(hipMemcpyAsync(dMsW, w.data(), w.size() * sizeof(T), hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));  // (the host vector goes out of scope)
+    }
+    StepArgs<T> a = base_args(B);
+    a.K = dMsK; a.C = dMsC;
+    a.lb = (T)lb_; a.ub = (T)ub_; a.Qw = (T)Qw_; a.Rw = (T)Rw_;
+    a.Wterm = PN ? dMsW : nullptr; a.wterm_per_traj = 0;
+    a.phases = PH_CONDENSE | PH_QP;
+    a.psi_now = (const T*)psi; a.pn_sl = B; a.pn_sb = 1;
+    a.ref = (const T*)ref; a.ref_per_traj = rpt;
+    a.H_out = fun ? dMsH : nullptr; a.f_out = fun ? dMsf : nullptr; a.c_out = fun ? dMsc : nullptr;
+    a.Useq = (T*)U; a.U0 = (T*)U0; a.status = st; a.iters = it;
+    HIPCHK(launch_step<T>(a, threads, s));
+    if (fun) HIPCHK(launch_qp_value<T>(dMsH, dMsf, dMsc, (const T*)U, N, B, (T*)fun, s));
+    return 0;
+  }
+
+  int generate_and_fit(int plant, const void* X0, const void* U, int n_traj, int n_steps, double hs, double ridge,
+                       int init_rls, void* A, void* Bm, void* C, void* Xo, void* Yo, hipStream_t s) override {
+    if (!X0 || !U || n_traj < 1 || n_steps < 1) FAIL(-3, "kmpc_generate_and_fit: bad arguments");
+    if (n != 2) FAIL(-3, "plants are two-state systems");
+    if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
+    const size_t M = (size_t)n_traj * n_steps;
+    T *gx = nullptr, *gy = nullptr;
+    if (!Xo) HIPCHK(hipMalloc(&gx, sizeof(T) * 2 * M));
+    if (!Yo) { hipError_t e = hipMalloc(&gy, sizeof(T) * 2 * M); if (e != hipSuccess) { if (gx) (void)hipFree(gx); HIPCHK(e); } }
+    T* Xp = Xo ? (T*)Xo : gx; T* Yp = Yo ? (T*)Yo : gy;
+    int rc = 0;
+    hipError_t e = launch_datagen<T>(plant, (T)hs, (const T*)X0, (const T*)U, n_traj, n_steps, Xp, Yp, s);
+    if (e != hipSuccess) { err = std::string("kmpc_generate_and_fit: ") + hipGetErrorString(e); rc = -(int)(1000 + (int)e); }
+    if (!rc) rc = offline_fit(Xp, Yp, U, (int)M, ridge, init_rls, A, Bm, C, s);  // (synchronises the stream before it returns)
+    if (gx) (void)hipFree(gx);
+    if (gy) (void)hipFree(gy);
+    return rc;
   }
 
   int qp_solve(const void* H, const void* f, void* U, int32_t* st, int32_t* it, int Bc, hipStream_t s) override {
@@ -514,6 +583,14 @@ struct Impl : kmpc_handle {
     if (have_prev) rls_fresh = false;
     have_prev = true;
     cur ^= 1;
+    return 0;
+  }
+
+  // the input that was actually applied at the last step, when it is not the one kmpc_step returned (actuator limits, a
+  // logged trajectory that is being followed): the next RLS update regresses on it (z = [psi; u], duffing.py:900)
+  int set_applied_input(const void* U, int Bc, hipStream_t s) override {
+    if (!U || Bc != B) FAIL(-3, "kmpc_set_applied_input: U must hold one input per trajectory of the handle");
+    HIPCHK(hipMemcpyAsync(dUprev, U, sizeof(T) * (size_t)B, hipMemcpyDeviceToDevice, s));
     return 0;
   }
 
@@ -682,6 +759,8 @@ struct Impl : kmpc_handle {
   int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
                    hipStream_t s) override {
     if (!delta || !ref || !U0) FAIL(-3, "kmpc_shared_solve: null pointer");
+    if (have_wterm && wterm_from_dare && wterm_per_traj)
+      FAIL(-3, "kmpc_shared_solve: per-trajectory terminal blocks do not apply to the shared model (kmpc_terminal_from_dare with per_trajectory = 0)");
     int rc = shared_alloc();
     if (rc) return rc;
     if (have_prev) {
@@ -692,7 +771,7 @@ struct Impl : kmpc_handle {
     }
     HIPCHK(launch_shared_condense<T>(dKs, dCs, (const T*)ref, L, n, q, N,
                                      cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX, cfg.Qw, cfg.Rw, dHs, dFs,
-                                     df0s, s, (have_wterm && !wterm_from_dare) ? dWt : nullptr, cfg.delta_u ? 1 : 0,
+                                     df0s, s, !have_wterm ? nullptr : (wterm_from_dare ? (const T*)dWtB : dWt), cfg.delta_u ? 1 : 0,
                                      cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0));
     StepArgs<T> a = base_args(B);
     a.phases = PH_QP;
@@ -773,43 +852,96 @@ struct Impl : kmpc_handle {
     return 0;
   }
 
-  // ---- state blob: header | P | K | Q | C | psi_prev | last minimiser | u_prev
-  struct BlobHeader { int32_t magic, dtype, n, L, N, B, have_prev, rls_fresh; };
+  // ---- state blob (version 2): header | P | K | Q | C | psi_prev | last minimiser | u_prev
+  //      | shared-model section (Gram sums, shared [A B], C) when the handle has one
+  //      | terminal-weight section (PN - Qw I: one block, or the Riccati blocks of kmpc_terminal_from_dare)
+  struct BlobHeader {
+    int32_t magic, version, dtype, n, L, N, B, have_prev, rls_fresh;
+    int32_t has_shared, shared_has_samples, have_wterm, wterm_from_dare, wterm_per_traj, wterm_blocks, reserved;
+    double P0, barQ0;
+  };
+  int64_t base_elems() const { return (sP + sK + sQ + sC) * (int64_t)B + (int64_t)L * B + B + (int64_t)N * B; }
+  int64_t shared_bytes() const { return dGram ? (int64_t)sizeof(double) * gram_elems() + (int64_t)sizeof(T) * ((int64_t)L * p + (int64_t)n * L) : 0; }
+  int64_t wterm_blocks() const { return !have_wterm ? 0 : (wterm_from_dare ? (wterm_per_traj ? B : 1) : 1); }
+  int64_t wterm_bytes() const { return !have_wterm ? 0 : (wterm_from_dare ? (int64_t)sizeof(double) : (int64_t)sizeof(T)) * wterm_blocks() * q * q; }
   int64_t state_bytes() const override {
-    return (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * ((sP + sK + sQ + sC) * (int64_t)B + (int64_t)L * B + B + (int64_t)N * B);
+    return (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * base_elems() + shared_bytes() + wterm_bytes();
   }
   int state_export(void* blob, int64_t bytes) override {
     if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_export: buffer too small");
     HIPCHK(hipDeviceSynchronize());
-    BlobHeader hd{0x4b4d5043, cfg.dtype, n, L, N, B, have_prev ? 1 : 0, rls_fresh ? 1 : 0};
+    BlobHeader hd{};
+    hd.magic = 0x4b4d5043; hd.version = 2; hd.dtype = cfg.dtype; hd.n = n; hd.L = L; hd.N = N; hd.B = B;
+    hd.have_prev = have_prev ? 1 : 0; hd.rls_fresh = rls_fresh ? 1 : 0;
+    hd.has_shared = dGram ? 1 : 0; hd.shared_has_samples = shared_has_samples ? 1 : 0;
+    hd.have_wterm = have_wterm ? 1 : 0; hd.wterm_from_dare = wterm_from_dare ? 1 : 0; hd.wterm_per_traj = wterm_per_traj ? 1 : 0;
+    hd.wterm_blocks = (int32_t)wterm_blocks();
+    hd.P0 = cfg.P0; hd.barQ0 = cfg.barQ0;
     char* o = (char*)blob;  // host or device memory (unified addressing)
     HIPCHK(hipMemcpy(o, &hd, sizeof(hd), hipMemcpyDefault)); o += sizeof(hd);
-    struct { const T* ptr; size_t cnt; } parts[] = {{dP, (size_t)sP * B}, {dK, (size_t)sK * B}, {dQ, (size_t)sQ * B},
-                                                    {dC, (size_t)sC * B}, {dPsi[cur ^ 1], (size_t)L * B},
-                                                    {dWarm, (size_t)N * B}, {dUprev, (size_t)B}};
+    struct { const void* ptr; size_t bytes; } parts[] = {
+        {dP, sizeof(T) * (size_t)sP * B}, {dK, sizeof(T) * (size_t)sK * B}, {dQ, sizeof(T) * (size_t)sQ * B},
+        {dC, sizeof(T) * (size_t)sC * B}, {dPsi[cur ^ 1], sizeof(T) * (size_t)L * B}, {dWarm, sizeof(T) * (size_t)N * B},
+        {dUprev, sizeof(T) * (size_t)B},
+        {dGram, dGram ? sizeof(double) * (size_t)gram_elems() : 0}, {dKs, dGram ? sizeof(T) * (size_t)L * p : 0},
+        {dCs, dGram ? sizeof(T) * (size_t)n * L : 0},
+        {have_wterm ? (wterm_from_dare ? (const void*)dWtB : (const void*)dWt) : nullptr, (size_t)wterm_bytes()}};
     for (auto& pt : parts) {
-      HIPCHK(hipMemcpy(o, pt.ptr, pt.cnt * sizeof(T), hipMemcpyDefault));
-      o += pt.cnt * sizeof(T);
+      if (!pt.bytes) continue;
+      HIPCHK(hipMemcpy(o, pt.ptr, pt.bytes, hipMemcpyDefault));
+      o += pt.bytes;
     }
     return 0;
   }
   int state_import(const void* blob, int64_t bytes) override {
-    if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_import: buffer too small");
+    if (bytes < (int64_t)sizeof(BlobHeader) || !blob) FAIL(-3, "kmpc_state_import: buffer too small");
     BlobHeader hd;
     const char* o = (const char*)blob;
     HIPCHK(hipMemcpy(&hd, o, sizeof(hd), hipMemcpyDefault)); o += sizeof(hd);
-    if (hd.magic != 0x4b4d5043 || hd.dtype != cfg.dtype || hd.n != n || hd.L != L || hd.N != N || hd.B != B)
+    if (hd.magic != 0x4b4d5043 || hd.version != 2 || hd.dtype != cfg.dtype || hd.n != n || hd.L != L || hd.N != N || hd.B != B)
       FAIL(-3, "kmpc_state_import: blob does not match this handle");
+    const int64_t wb = !hd.have_wterm ? 0 : (hd.wterm_from_dare ? (int64_t)sizeof(double) : (int64_t)sizeof(T)) * hd.wterm_blocks * q * q;
+    const int64_t sb = hd.has_shared ? (int64_t)sizeof(double) * gram_elems() + (int64_t)sizeof(T) * ((int64_t)L * p + (int64_t)n * L) : 0;
+    if (bytes < (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * base_elems() + sb + wb) FAIL(-3, "kmpc_state_import: buffer too small");
     HIPCHK(hipDeviceSynchronize());
-    struct { T* ptr; size_t cnt; } parts[] = {{dP, (size_t)sP * B}, {dK, (size_t)sK * B}, {dQ, (size_t)sQ * B},
-                                              {dC, (size_t)sC * B}, {dPsi[cur ^ 1], (size_t)L * B},
-                                              {dWarm, (size_t)N * B}, {dUprev, (size_t)B}};
+    if (hd.has_shared) { int rc = shared_alloc(); if (rc) return rc; }
+    if (hd.have_wterm) {
+      if (hd.wterm_from_dare) {
+        if (dare_cap < hd.wterm_blocks) {
+          if (dDareP) (void)hipFree(dDareP);
+          if (dDareIt) (void)hipFree(dDareIt);
+          if (dWtB) (void)hipFree(dWtB);
+          dDareP = nullptr; dDareIt = nullptr; dWtB = nullptr; dare_cap = 0;
+          HIPCHK(hipMalloc(&dDareP, sizeof(double) * (size_t)hd.wterm_blocks * L * L));
+          HIPCHK(hipMalloc(&dDareIt, sizeof(int32_t) * (size_t)hd.wterm_blocks));
+          HIPCHK(hipMalloc(&dWtB, sizeof(double) * (size_t)hd.wterm_blocks * q * q));
+          dare_cap = hd.wterm_blocks;
+        }
+      } else if (!dWt) {
+        HIPCHK(hipMalloc(&dWt, sizeof(T) * (size_t)q * q));
+      }
+    }
+    struct { void* ptr; size_t bytes; } parts[] = {
+        {dP, sizeof(T) * (size_t)sP * B}, {dK, sizeof(T) * (size_t)sK * B}, {dQ, sizeof(T) * (size_t)sQ * B},
+        {dC, sizeof(T) * (size_t)sC * B}, {dPsi[cur ^ 1], sizeof(T) * (size_t)L * B}, {dWarm, sizeof(T) * (size_t)N * B},
+        {dUprev, sizeof(T) * (size_t)B},
+        {dGram, hd.has_shared ? sizeof(double) * (size_t)gram_elems() : 0}, {dKs, hd.has_shared ? sizeof(T) * (size_t)L * p : 0},
+        {dCs, hd.has_shared ? sizeof(T) * (size_t)n * L : 0},
+        {hd.have_wterm ? (hd.wterm_from_dare ? (void*)dWtB : (void*)dWt) : nullptr, (size_t)wb}};
     for (auto& pt : parts) {
-      HIPCHK(hipMemcpy(pt.ptr, o, pt.cnt * sizeof(T), hipMemcpyDefault));
-      o += pt.cnt * sizeof(T);
+      if (!pt.bytes) continue;
+      HIPCHK(hipMemcpy(pt.ptr, o, pt.bytes, hipMemcpyDefault));
+      o += pt.bytes;
     }
     have_prev = hd.have_prev != 0;
     rls_fresh = hd.rls_fresh != 0;
+    if (hd.has_shared) shared_has_samples = hd.shared_has_samples != 0;
+    else if (dGram) {  // the blob comes from a handle that never ran a shared-model step
+      HIPCHK(hipMemset(dGram, 0, sizeof(double) * (size_t)gram_elems()));
+      shared_has_samples = false;
+    }
+    have_wterm = hd.have_wterm != 0; wterm_from_dare = hd.wterm_from_dare != 0; wterm_per_traj = hd.wterm_per_traj != 0;
+    cfg.P0 = hd.P0; cfg.barQ0 = hd.barQ0;
     return 0;
   }
 
@@ -841,6 +973,13 @@ struct Impl : kmpc_handle {
   }
 };
 
+// every entry point runs on the device the handle was created on (lazy allocations and launches included), whatever
+// the caller's current device is, and leaves the caller's device as it found it
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
 // ---------------------------------------------------------------------------------------
 extern "C" {
 
@@ -860,15 +999,22 @@ int kmpc_create(const kmpc_config* cfg, kmpc_handle** out) {
   else if (cfg->dtype == KMPC_F32) { auto* i = new Impl<float>(); rc = i->init(*cfg); h = i; }
   else { g_create_error = "kmpc_create: dtype must be KMPC_F32 or KMPC_F64"; return -2; }
   if (rc) { g_create_error = h->err; delete h; return rc; }
+  if (hipGetDevice(&h->device) != hipSuccess) h->device = 0;
   *out = h;
   return 0;
 }
 
-int kmpc_destroy(kmpc_handle* h) { delete h; return 0; }
+int kmpc_destroy(kmpc_handle* h) {
+  if (!h) return 0;
+  DeviceGuard g(h->device);
+  delete h;
+  return 0;
+}
 const char* kmpc_last_error(const kmpc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
-#define NN(h) if (!(h)) return -1
-int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { NN(h); return h->set_encoder_layer(layer, W, b, rows, cols); }
+#define NN(h) if (!(h)) return -1; DeviceGuard dev_guard_((h)->device)
+int kmpc_set_encoder(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { NN(h); return h->set_encoder_layer(layer, W, b, rows, cols); }
+int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { return kmpc_set_encoder(h, layer, W, b, rows, cols); }
 int kmpc_set_centres(kmpc_handle* h, const double* cx, int L, int n) { NN(h); return h->set_centres(cx, L, n); }
 int kmpc_set_model(kmpc_handle* h, const double* A, const double* B, const double* C) { NN(h); return h->set_model(A, B, C); }
 int kmpc_set_terminal_weight(kmpc_handle* h, const double* PN) { NN(h); return h->set_terminal_weight(PN); }
@@ -916,9 +1062,22 @@ int kmpc_state_init_from(kmpc_handle* h, const double* K_A0, const double* P0, c
 int kmpc_lift(kmpc_handle* h, const void* X, void* Psi, int B, void* s) { NN(h); return h->lift(X, Psi, B, (hipStream_t)s); }
 int kmpc_rls_update(kmpc_handle* h, const void* psi, const void* u, const void* psin, const void* xn, int B, void* s) { NN(h); return h->rls_update(psi, u, psin, xn, B, (hipStream_t)s); }
 int kmpc_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->get_model(A, B, C, (hipStream_t)s); }
-int kmpc_condense(kmpc_handle* h, const void* psi, const void* ref, int rpt, void* H, void* f, int B, void* s) { NN(h); return h->condense(psi, ref, rpt, H, f, B, (hipStream_t)s); }
+int kmpc_condense(kmpc_handle* h, const void* psi, const void* ref, int rpt, void* H, void* f, int B, void* s) { NN(h); return h->condense(psi, ref, rpt, H, f, nullptr, B, (hipStream_t)s); }
+int kmpc_condense_cost(kmpc_handle* h, const void* psi, const void* ref, int rpt, void* H, void* f, void* c, int B, void* s) { NN(h); return h->condense(psi, ref, rpt, H, f, c, B, (hipStream_t)s); }
+int kmpc_mpc_solve(kmpc_handle* h, const void* A, const void* Bv, const void* C, int shared, const void* psi, const void* ref, int rpt,
+                   double lb, double ub, double Qw, double Rw, const double* PN, void* U, void* U0, void* fun, int32_t* st, int32_t* it,
+                   int B, void* s) {
+  NN(h);
+  return h->mpc_solve(A, Bv, C, shared, psi, ref, rpt, lb, ub, Qw, Rw, PN, U, U0, fun, st, it, B, (hipStream_t)s);
+}
+int kmpc_generate_and_fit(kmpc_handle* h, int plant, const void* X0, const void* U, int n_traj, int n_steps, double hs, double ridge,
+                          int init_rls, void* A, void* B, void* C, void* Xo, void* Yo, void* s) {
+  NN(h);
+  return h->generate_and_fit(plant, X0, U, n_traj, n_steps, hs, ridge, init_rls, A, B, C, Xo, Yo, (hipStream_t)s);
+}
 int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, void* s) { NN(h); return h->qp_solve(H, f, U, st, it, B, (hipStream_t)s); }
 int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
+int kmpc_set_applied_input(kmpc_handle* h, const void* U, int B, void* s) { NN(h); return h->set_applied_input(U, B, (hipStream_t)s); }
 int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NN(h); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
 int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NN(h); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
 int kmpc_offline_fit(kmpc_handle* h, const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A, void* B, void* C, void* s) { NN(h); return h->offline_fit(X, Y, U, M, ridge, init_rls, A, B, C, (hipStream_t)s); }
@@ -930,7 +1089,7 @@ int64_t kmpc_gram_elems(const kmpc_handle* h) { return h ? h->gram_elems() : -1;
 int kmpc_allreduce_gram(kmpc_handle* h, double* delta, void* nccl_comm, void* s) {
   NN(h);
   if (!delta || !nccl_comm) return -3;
-  typedef int (*allreduce_fn)(const void*, void*, size_t, int, int, void*, hipStream_t);
+  typedef ncclResult_t (*allreduce_fn)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   static allreduce_fn fn = nullptr;
   if (!fn) {
     fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
@@ -941,8 +1100,8 @@ int kmpc_allreduce_gram(kmpc_handle* h, double* delta, void* nccl_comm, void* s)
     }
     if (!fn) return -4;  // no RCCL in this process
   }
-  const int rc = fn(delta, delta, (size_t)h->gram_elems(), /*ncclDouble*/ 8, /*ncclSum*/ 0, nccl_comm, (hipStream_t)s);
-  return rc == 0 ? 0 : -(2000 + rc);
+  const ncclResult_t rc = fn(delta, delta, (size_t)h->gram_elems(), ncclDouble, ncclSum, (ncclComm_t)nccl_comm, (hipStream_t)s);
+  return rc == ncclSuccess ? 0 : -(2000 + (int)rc);
 }
 int kmpc_shared_local_gram(kmpc_handle* h, const void* X, double* delta, void* s) { NN(h); return h->shared_local_gram(X, delta, (hipStream_t)s); }
 int kmpc_gram_accumulate(kmpc_handle* h, const void* X, double* delta, void* s) { return kmpc_shared_local_gram(h, X, delta, s); }

@@ -72,6 +72,71 @@ __global__ __launch_bounds__(256) void export_model_kernel(const T* K, long stri
   }
 }
 
+template <typename T> __global__ __launch_bounds__(64) void qp_value_kernel(const T* H, const T* f, const T* c, const T* U, int N, int B, T* fun) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const T* Hb = H + (size_t)b * N * N;
+  T acc = c[b];
+  for (int i = 0; i < N; ++i) {
+    const T ui = U[(size_t)i * B + b];
+    T hu = f[(size_t)b * N + i];
+    for (int j = 0; j < N; ++j) hu += Hb[i * N + j] * U[(size_t)j * B + b];
+    acc += ui * hu;
+  }
+  fun[b] = acc;
+}
+template <typename T> hipError_t launch_qp_value(const T* H, const T* f, const T* c, const T* U, int N, int B, T* fun, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((qp_value_kernel<T>), dim3((B + 63) / 64), dim3(64), 0, s, H, f, c, U, N, B, fun);
+  return hipGetLastError();
+}
+
+// the inverse of export_model_kernel: dense A, B, C blocks -> state layout (kmpc_mpc_solve)
+template <typename T>
+__global__ __launch_bounds__(256) void import_model_kernel(const T* A, const T* Bv, const T* C, int shared, int n, int L, T* K,
+                                                           long strideK, T* Cs, long strideC) {
+  const int b = blockIdx.x, p = L + 1;
+  const size_t m = shared ? 0 : (size_t)b;
+  T* Kb = K + (size_t)b * strideK;
+  for (int e = threadIdx.x; e < L * p; e += blockDim.x) {
+    const int r = e / p, c = e - r * p;
+    Kb[e] = c < L ? A[m * L * L + (size_t)r * L + c] : Bv[m * L + r];
+  }
+  if (C && Cs) {
+    T* Cb = Cs + (size_t)b * strideC;
+    for (int e = threadIdx.x; e < n * L; e += blockDim.x) Cb[e] = C[m * n * L + e];
+  }
+}
+template <typename T>
+hipError_t launch_import_model(const T* A, const T* Bv, const T* C, int shared, int n, int L, int B, T* K, long strideK,
+                               T* Cs, long strideC, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((import_model_kernel<T>), dim3(B), dim3(256), 0, s, A, Bv, C, shared, n, L, K, strideK, Cs, strideC);
+  return hipGetLastError();
+}
+
+// data_generate.py:17-79 on the device: one thread per trajectory walks its n_steps plant steps (sequential in
+// time, parallel over trajectories) and leaves the transition pairs in the panels the offline fit reads
+template <typename T>
+__global__ __launch_bounds__(256) void datagen_kernel(int plant, T h, const T* X0, const T* U, int n_traj, int n_steps, T* X, T* Y) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_traj) return;
+  const size_t M = (size_t)n_traj * n_steps;
+  T x1 = X0[t], x2 = X0[(size_t)n_traj + t];
+  for (int i = 0; i < n_steps; ++i) {
+    const size_t c = (size_t)i * n_traj + t;
+    X[c] = x1; X[M + c] = x2;
+    plant_apply<T>(plant, 0, h, x1, x2, U[c]);
+    Y[c] = x1; Y[M + c] = x2;
+  }
+}
+template <typename T>
+hipError_t launch_datagen(int plant, T h, const T* X0, const T* U, int n_traj, int n_steps, T* X, T* Y, hipStream_t s) {
+  if (n_traj <= 0 || n_steps <= 0) return hipSuccess;
+  hipLaunchKernelGGL((datagen_kernel<T>), dim3((n_traj + 255) / 256), dim3(256), 0, s, plant, h, X0, U, n_traj, n_steps, X, Y);
+  return hipGetLastError();
+}
+
 template <typename T>
 hipError_t launch_export_model(const T* K, long strideK, const T* C, long strideC, int n, int L, int B, T* A_out,
                                T* B_out, T* C_out, hipStream_t s) {
@@ -107,7 +172,11 @@ hipError_t launch_axpby(double* g, const double* d, double a, int count, hipStre
   template hipError_t launch_fill_state<T>(T*, long, int, T, T*, long, int, T, T*, long, T*, long, int, int,        \
                                            hipStream_t);                                                             \
   template hipError_t launch_broadcast<T>(T*, long, const T*, int, int, hipStream_t);                                \
-  template hipError_t launch_export_model<T>(const T*, long, const T*, long, int, int, int, T*, T*, T*, hipStream_t);
+  template hipError_t launch_export_model<T>(const T*, long, const T*, long, int, int, int, T*, T*, T*, hipStream_t); \
+  template hipError_t launch_import_model<T>(const T*, const T*, const T*, int, int, int, int, T*, long, T*, long,   \
+                                             hipStream_t);                                                           \
+  template hipError_t launch_datagen<T>(int, T, const T*, const T*, int, int, T*, T*, hipStream_t);                  \
+  template hipError_t launch_qp_value<T>(const T*, const T*, const T*, const T*, int, int, T*, hipStream_t);
 INST(float)
 INST(double)
 

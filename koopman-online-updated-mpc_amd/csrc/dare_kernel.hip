@@ -121,7 +121,8 @@ hipError_t launch_dare(const DareArgs& a, hipStream_t s) {
   if (a.nb <= 0) return hipSuccess;
   if (a.L < 1 || a.L > 64) return hipErrorInvalidValue;
   const size_t lds = sizeof(double) * ((size_t)3 * a.L * a.L + 5 * a.L + 16);
-  static size_t configured = 0;
+  static size_t configured_dev[16] = {};  // (function attributes are per device)
+  size_t& configured = configured_dev[device_slot()];
   if (lds > 64 * 1024 && lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&dare_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;

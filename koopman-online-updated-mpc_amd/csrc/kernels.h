@@ -42,6 +42,7 @@ struct StepArgs {
   // condense
   const T* ref;      // (q x N) or [B][q][N]
   T* H_out; T* f_out;        // optional exports  [B][N*N], [B][N]
+  T* c_out;                  // optional [B]: the constant of the cost, J(u) = u'Hu + f'u + c (result.fun of duffing.py:859)
   const T* H_in; const T* f_in;  // QP-only mode inputs
   int h_shared;                  // H_in is ONE matrix for the whole batch (shared-model mode)
   const T* F_in; const T* f0_in; // shared-model mode: f_b = F psi_b + f0 (F: N x L), psi from psi_now
@@ -152,6 +153,18 @@ template <typename T> hipError_t launch_shared_condense(const T* K, const T* C, 
                                                         hipStream_t s, const T* Wterm = nullptr, int du_mode = 0,
                                                         int cy0 = 0);
 template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s);
+// [A B] and C given as dense per-trajectory blocks (A [B][L][L], Bv [B][L], C [B][n][L]; stride 0 = one model for all)
+// into the step kernel's state layout K [B][L(L+1)], Cs [B][nL]
+template <typename T> hipError_t launch_import_model(const T* A, const T* Bv, const T* C, int shared, int n, int L, int B,
+                                                    T* K, long strideK, T* Cs, long strideC, hipStream_t s);
+// the reference's training set on the device (data_generate.py:17-79): n_traj trajectories x n_steps plant steps from
+// X0 (2 x n_traj) with the inputs U (n_steps x n_traj); panels X, Y (2 x M), M = n_steps * n_traj, sample i * n_traj + t
+template <typename T> hipError_t launch_datagen(int plant, T h, const T* X0, const T* U, int n_traj, int n_steps, T* X, T* Y,
+                                                hipStream_t s);
+// fun[b] = u'Hu + f'u + c at U (N x B panel): the value of costFunction at the returned input sequence
+template <typename T> hipError_t launch_qp_value(const T* H, const T* f, const T* c, const T* U, int N, int B, T* fun, hipStream_t s);
+// index of the current device, 0..15 (per-device launch attribute caches)
+inline int device_slot() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0) d = 0; return d & 15; }
 template <typename T> hipError_t launch_export_model(const T* K, long strideK, const T* C, long strideC, int n, int L,
                                                      int B, T* A_out, T* B_out, T* C_out, hipStream_t s);
 

@@ -391,7 +391,8 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     };
     if (g_rollout_workgroup) return wgs(g_rollout_workgroup) > 0 ? g_rollout_workgroup : 0;
     if (env && (atoi(env) == 4 || atoi(env) == 8 || atoi(env) == 16)) return wgs(atoi(env)) > 0 ? atoi(env) : 0;
-    static int cus = 0;
+    static int cus_dev[16] = {};
+    int& cus = cus_dev[device_slot()];
     if (!cus) {
       int dev = 0;
       if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -416,7 +417,8 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
 }
 template <int L_, int N_, int Q_, int NW, int KS_>
 static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, size_t lds, hipStream_t s) {
-  static size_t configured = 0;
+  static size_t configured_dev[16] = {};  // (function attributes are per device)
+  size_t& configured = configured_dev[device_slot()];
   if (lds > 64 * 1024 && lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW, KS_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -435,7 +437,8 @@ template <int L_, int N_, int Q_, int KS_> static hipError_t launch_rollout_dyn(
   k.keep_off = k.wstride * 16;
   const size_t lds = elems * sizeof(double);
   if (lds > 160 * 1024 || (size_t)k.wstride < (size_t)2 * a.Hp * 4) return hipErrorInvalidValue;
-  static size_t configured = 0;
+  static size_t configured_dev[16] = {};  // (function attributes are per device)
+  size_t& configured = configured_dev[device_slot()];
   if (lds > 64 * 1024 && lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_dyn_kernel<L_, N_, Q_, KS_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

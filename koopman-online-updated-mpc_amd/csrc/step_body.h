@@ -125,6 +125,8 @@ template <> struct Tol<float> {
   static __device__ __forceinline__ float slack() { return 1e-6f; }
 };
 
+__device__ __forceinline__ double tfma(double a, double b, double c) { return __builtin_fma(a, b, c); }
+__device__ __forceinline__ float tfma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 template <typename T> __device__ __forceinline__ T tabs(T v) { return v < T(0) ? -v : v; }
 template <typename T> __device__ __forceinline__ T tclip(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
@@ -1232,18 +1234,19 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       const int i = e / p, j = e - i * p;
       Pw[e] = (sX[e] - (sPz[i] * sPz[j]) * dinv) * linv;
     });
-    // innovation  y - K z
+    // innovation  y - K z.  The reference keeps K_A = sum y z' undiscounted and discounts inv_K_G only
+    // (Koopman_update.m:270-274); with K = K_A inv_K_G that is  K <- (K - K z g') / lam + y g',  g = Pz / d, i.e.
+    // K / lam + (e / lam + y (1 - 1/lam)) g'  with e = y - K z  (lam = 1: K + e g', duffing.py:927-938)
     for (int r = tid; r < L; r += TPB) {
       T acc = sy[r];
 #pragma unroll
       for (int j = 0; j < p; ++j) acc -= sK[r * p + j] * sz[j];
-      sE[r] = acc;
+      sE[r] = acc * linv + sy[r] * (T(1) - linv);
     }
     block_sync<TPB>();
-    // K <- K + (y - K z) g',  g = Pz / d                            duffing.py:927-938
     for_strided<TPB, LP_>(tid, L * p, [&](int e, int) {
       const int r = e / p, j = e - r * p;
-      const T v = sK[e] + sE[r] * (sPz[j] * dinv);
+      const T v = tfma(sE[r], sPz[j] * dinv, sK[e] * linv);  // (one rounding, as K + e g' always was at lam = 1)
       sK[e] = v;
       Kg[e] = v;
     });
@@ -1290,12 +1293,13 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       block_sync<TPB>();
       T part2 = T(0);
       for (int i = tid; i < L; i += TPB) part2 += sz[i] * sPz[i];
-      const T dc = a.lam + block_sum<T, TPB>(part2, red);
+      // (bar_Q carries no forgetting factor: duffing.py:947-951 is the only form of this estimator the reference has)
+      const T dc = T(1) + block_sum<T, TPB>(part2, red);
       const T dcinv = T(1) / dc;
       T* Qw = a.Qb + (size_t)b * a.strideQ;
       for_strided<TPB, LL_>(tid, L * L, [&](int e, int) {
         const int i = e / L, j = e - i * L;
-        Qw[e] = (sX[e] - (sPz[i] * sPz[j]) * dcinv) * linv;
+        Qw[e] = sX[e] - (sPz[i] * sPz[j]) * dcinv;
       });
       for (int e = tid; e < n * L; e += TPB) {
         const int r = e / L, j = e - r * L;
@@ -1683,6 +1687,20 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     if (a.f_out) {
       T* fg = a.f_out + (size_t)b * N;
       for (int e = tid; e < N; e += TPB) fg[e] = sf[e];
+    }
+    if (a.c_out) {
+      // the constant of the cost: c = Qw sum_j |e_j|^2 (+ e_N' W e_N with a terminal block), e_j = Co A^j psi - r_{j-1}
+      // (sEr), so that u'Hu + f'u + c is costFunction(u) (duffing.py:540-581) and c + the QP's optimal value result.fun
+      T part = T(0);
+      for (int e = tid; e < q * N; e += TPB) part += sEr[e] * sEr[e];
+      part *= a.Qw;
+      if (a.Wterm) {
+        const T* const Wt = a.Wterm + (a.wterm_per_traj ? (size_t)b * q * q : (size_t)0);
+        const T* eN = sEr + (N - 1) * q;
+        for (int e = tid; e < q * q; e += TPB) part += eN[e / q] * Wt[e] * eN[e % q];
+      }
+      const T csum = block_sum<T, TPB>(part, red);
+      if (tid == 0) a.c_out[b] = csum;
     }
   } else if (sv.phases & PH_QP) {
     const T* Hg = a.H_in + (a.h_shared ? (size_t)0 : (size_t)b * N * N);

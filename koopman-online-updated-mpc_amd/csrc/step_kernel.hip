@@ -46,7 +46,8 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
     k.r2 = 0;
   }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static size_t configured = 0;
+  static size_t configured_dev[16] = {};  // (function attributes are per device)
+  size_t& configured = configured_dev[device_slot()];
   if (lds > 64 * 1024 && lds > configured) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, TPB, L_, N_, Q_>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -40,6 +40,7 @@ SIGNATURES = {
     "kmpc_destroy": (_I, [_VP]),
     "kmpc_last_error": (C.c_char_p, [_VP]),
     "kmpc_version": (_I, []),
+    "kmpc_set_encoder": (_I, [_VP, _I, _DP, _DP, _I, _I]),
     "kmpc_set_encoder_layer": (_I, [_VP, _I, _DP, _DP, _I, _I]),
     "kmpc_set_centres": (_I, [_VP, _DP, _I, _I]),
     "kmpc_set_model": (_I, [_VP, _DP, _DP, _DP]),
@@ -56,15 +57,19 @@ SIGNATURES = {
     "kmpc_rls_update": (_I, [_VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "kmpc_get_model": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "kmpc_condense": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _I, _VP]),
+    "kmpc_condense_cost": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _I, _VP]),
+    "kmpc_mpc_solve": (_I, [_VP, _VP, _VP, _VP, _I, _VP, _VP, _I, _D, _D, _D, _D, _DP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "kmpc_qp_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _I, _VP]),
     "kmpc_step": (_I, [_VP, _VP, _VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_offline_fit": (_I, [_VP, _VP, _VP, _VP, _I, _D, _I, _VP, _VP, _VP, _VP]),
+    "kmpc_generate_and_fit": (_I, [_VP, _I, _VP, _VP, _I, _I, _D, _D, _I, _VP, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_gram_elems": (_I64, [_VP]),
     "kmpc_allreduce_gram": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_shared_local_gram": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_gram_accumulate": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_shared_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_shared_get_model": (_I, [_VP, _VP, _VP, _VP, _VP]),
+    "kmpc_set_applied_input": (_I, [_VP, _VP, _I, _VP]),
     "kmpc_plant_step": (_I, [_VP, _I, _VP, _VP, _D, _I, _I, _VP]),
     "kmpc_rollout": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_state_bytes": (_I64, [_VP]),

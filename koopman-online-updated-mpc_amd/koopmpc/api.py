@@ -151,8 +151,7 @@ class KoopmanMPC:
         for k, (W, b) in enumerate(weights):
             W = np.ascontiguousarray(W, dtype=np.float64)
             b = np.ascontiguousarray(np.reshape(b, -1), dtype=np.float64)
-            self._chk(self.lib.kmpc_set_encoder_layer(self.h, k, _dptr(W), _dptr(b), W.shape[0], W.shape[1]),
-                      "kmpc_set_encoder_layer")
+            self._chk(self.lib.kmpc_set_encoder(self.h, k, _dptr(W), _dptr(b), W.shape[0], W.shape[1]), "kmpc_set_encoder")
 
     def set_centres(self, cx):
         cx = np.ascontiguousarray(cx, dtype=np.float64)
@@ -208,6 +207,27 @@ class KoopmanMPC:
         self._chk(self.lib.kmpc_offline_fit(self.h, self._p(Xd), self._p(Yd), self._p(Ud), M, float(ridge), int(bool(init_rls)), self._p(A),
                                             self._p(Bm), self._p(Cm), self._stream()), "kmpc_offline_fit")
         return A, Bm, Cm
+
+    def generate_and_fit(self, kind, x0, U, ridge=0.0, init_rls=False, h=0.05, return_data=False):
+        """data_generate.py:17-79 -> duffing.py:152-177 as one device pipeline: from the initial states x0 (n, n_traj) and the
+        inputs U (n_steps, n_traj) (drawn by the caller, the reference uses np.random with seed 101) the plant roll-out,
+        the lift of the n_traj * n_steps transitions, their Gram sums (MFMA) and the model solve run without returning to the
+        host.  Returns (A, B, C) [+ (X, Y) panels (n, M) with return_data=True]; the model becomes every trajectory's."""
+        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP, "tank": _ffi.KMPC_PLANT_TANK}[kind]
+        Ud = self._dev(U)
+        n_steps, n_traj = Ud.shape
+        X0 = self._dev(x0, (self.n, n_traj))
+        M = n_steps * n_traj
+        A = torch.empty(self.L, self.L, dtype=self.dtype, device=self.device)
+        Bm = torch.empty(self.L, 1, dtype=self.dtype, device=self.device)
+        Cm = torch.empty(self.n, self.L, dtype=self.dtype, device=self.device)
+        Xo = torch.empty(self.n, M, dtype=self.dtype, device=self.device) if return_data else None
+        Yo = torch.empty(self.n, M, dtype=self.dtype, device=self.device) if return_data else None
+        self._chk(self.lib.kmpc_generate_and_fit(self.h, plant, self._p(X0), self._p(Ud), n_traj, n_steps, float(h), float(ridge),
+                                                 int(bool(init_rls)), self._p(A), self._p(Bm), self._p(Cm),
+                                                 self._p(Xo) if return_data else None, self._p(Yo) if return_data else None,
+                                                 self._stream()), "kmpc_generate_and_fit")
+        return (A, Bm, Cm, Xo, Yo) if return_data else (A, Bm, Cm)
 
     def state_init(self, P0=None, barQ0=None, K_A=None, inv_K_G=None, bar_X=None, bar_Q=None):
         """Start of the online update.  Scales only: K_A = 0, inv_K_G = P0 I, bar_X = 0, bar_Q = barQ0 I
@@ -274,16 +294,18 @@ class KoopmanMPC:
             return r.reshape(self.q, self.N).contiguous(), 0
         return r.reshape(self.B, self.q, self.N).contiguous(), 1
 
-    def condense(self, psi, r):
-        """H [B,N,N], f [B,N] of the current model: J(u) = u'Hu + f'u + const is the reference's
-        costFunction (duffing.py:540-581; Koopman_update.m:455-471).  r: (q,N) or (B,q,N)."""
+    def condense(self, psi, r, return_const=False):
+        """H [B,N,N], f [B,N] of the current model: J(u) = u'Hu + f'u + c is the reference's
+        costFunction (duffing.py:540-581; Koopman_update.m:455-471).  r: (q,N) or (B,q,N).
+        return_const=True also returns c [B] (so that c + the QP's optimal value is `result.fun`, duffing.py:859)."""
         ps = self._dev(psi, (self.L, self.B))
         rr, per = self._ref(r)
         H = torch.empty(self.B, self.N, self.N, dtype=self.dtype, device=self.device)
         f = torch.empty(self.B, self.N, dtype=self.dtype, device=self.device)
-        self._chk(self.lib.kmpc_condense(self.h, self._p(ps), self._p(rr), per, self._p(H), self._p(f), self.B,
-                                         self._stream()), "kmpc_condense")
-        return H, f
+        c = torch.empty(self.B, dtype=self.dtype, device=self.device) if return_const else None
+        self._chk(self.lib.kmpc_condense_cost(self.h, self._p(ps), self._p(rr), per, self._p(H), self._p(f),
+                                              self._p(c) if return_const else None, self.B, self._stream()), "kmpc_condense_cost")
+        return (H, f, c) if return_const else (H, f)
 
     def qp_solve(self, H, f):
         """Exact box-QP (replaces optimize.minimize duffing.py:857-861 / quadprog Koopman_update.m:214).
@@ -298,11 +320,44 @@ class KoopmanMPC:
                                          self._stream()), "kmpc_qp_solve")
         return U, st, it
 
-    def mpc_solve(self, psi, r):
-        """result.x of the reference's solve for the current model: (N,B) input sequences."""
-        H, f = self.condense(psi, r)
-        U, st, it = self.qp_solve(H, f)
-        return U, st, it
+    def mpc_solve(self, *args, lb=None, ub=None, Q=None, R=None, P_N=None):
+        """The MPC solve wrapper (duffing.py:857-861).
+
+        mpc_solve(psi, r): `result.x` for the handle's current model -> (U (N,B), status, iters).
+        mpc_solve(A, B, C, xlift, r[, lb, ub, Q, R, P_N]): stateless, the model is an argument -- A (L,L) or
+        (B,L,L), B (L,) / (L,1) / (B,L[,1]), C (n,L) / (B,n,L) or None for output="lift"; xlift (L,B); scalar weights
+        Q, R and bounds default to the handle's; P_N (q,q) replaces the last block of the output weight
+        (Koopman_update.m:381) -> (U (N,B), u0 (B,), status (B,), fun (B,) = J at the minimiser)."""
+        if len(args) == 2:
+            H, f = self.condense(args[0], args[1])
+            return self.qp_solve(H, f)
+        if len(args) < 5:
+            raise TypeError("mpc_solve(psi, r) or mpc_solve(A, B, C, xlift, r[, lb, ub, Q, R, P_N])")
+        A, Bm, Cm, xlift, r = args[:5]
+        rest = list(args[5:]) + [None] * 5
+        lb = rest[0] if lb is None else lb; ub = rest[1] if ub is None else ub
+        Q = rest[2] if Q is None else Q; R = rest[3] if R is None else R; P_N = rest[4] if P_N is None else P_N
+        A = self._dev(A); shared = A.dim() == 2
+        A = A.reshape(-1, self.L, self.L).contiguous()
+        nb = A.shape[0]
+        if nb not in (1, self.B):
+            raise ValueError("A must be (L,L) or (B,L,L)")
+        Bv = self._dev(Bm).reshape(nb, self.L).contiguous()
+        Cd = self._dev(Cm).reshape(nb, self.n, self.L).contiguous() if Cm is not None else None
+        ps = self._dev(xlift, (self.L, self.B))
+        rr, per = self._ref(r)
+        U = torch.empty(self.N, self.B, dtype=self.dtype, device=self.device)
+        u0 = torch.empty(self.B, dtype=self.dtype, device=self.device)
+        fun = torch.empty(self.B, dtype=self.dtype, device=self.device)
+        st = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        it = torch.empty(self.B, dtype=torch.int32, device=self.device)
+        pn = _dptr(np.reshape(P_N, (self.q, self.q))) if P_N is not None else None
+        self._chk(self.lib.kmpc_mpc_solve(self.h, self._p(A), self._p(Bv), self._p(Cd) if Cd is not None else None, 1 if (shared or nb == 1) else 0,
+                                          self._p(ps), self._p(rr), per, float(self.cfg.lb if lb is None else lb),
+                                          float(self.cfg.ub if ub is None else ub), float(self.cfg.Qw if Q is None else np.ravel(Q)[0]),
+                                          float(self.cfg.Rw if R is None else np.ravel(R)[0]), pn, self._p(U), self._p(u0), self._p(fun),
+                                          self._p(st), self._p(it), self.B, self._stream()), "kmpc_mpc_solve")
+        return U, u0, st, fun
 
     def step(self, x, r):
         """One loop iteration (duffing.py:847-984) for all trajectories: returns u_k (B,) (a view of
@@ -312,6 +367,12 @@ class KoopmanMPC:
         self._chk(self.lib.kmpc_step(self.h, self._p(X), self._p(rr), per, self._p(self.U0), self._p(self.Useq),
                                      self._p(self.status), self._p(self.iters), self._stream()), "kmpc_step")
         return self.U0
+
+    def set_applied_input(self, u):
+        """The input that was actually applied at the last step when it is not the returned u_k (actuator limits, a logged
+        trajectory that is being followed): the next update regresses on it (z = [psi; u], duffing.py:900).  u: (B,) or scalar."""
+        uu = self._dev(np.broadcast_to(np.asarray(u, dtype=np.float64), (self.B,)) if not torch.is_tensor(u) else u, (self.B,))
+        self._chk(self.lib.kmpc_set_applied_input(self.h, self._p(uu), self.B, self._stream()), "kmpc_set_applied_input")
 
     # ------------------------------------------------------------------ shared-model mode (SURVEY 8e)
     def shared_local_gram(self, x):

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)       # maxStep (duffing.py:629 uses 10000)
     ap.add_argument("--Nlift", type=int, default=8)          # duffing.py:66
     ap.add_argument("--horizon", type=int, default=10)       # MPCHorizon = ControlHorizon, duffing.py:632-633
+    ap.add_argument("--model", default=None, help=".npz with A0, B0, C0: the offline model instead of fitting one here")
     ap.add_argument("--out", default=None, help="np.savez the logs here (logXloc, logUloc, like duffing.py:1015)")
     a = ap.parse_args()
 
@@ -36,7 +37,11 @@ def main():
         weights = random_mlp_weights(2, 100, 3, Nlift)
     B, N = a.batch, a.horizon
     mpc = KoopmanMPC(n=2, L=Nlift, N=N, batch=B, weights=weights, lb=-2.0, ub=2.0)  # bounds duffing.py:636
-    mpc.offline_fit(*offline_data())            # duffing.py:152-177 (fit) and :811-813 (Aloc_d, Bloc_d, Cloc_d = A, B, C)
+    if a.model:
+        d = np.load(a.model)
+        mpc.set_model(d["A0"], d["B0"], d["C0"])    # duffing.py:811-813 (Aloc_d, Bloc_d, Cloc_d = A, B, C)
+    else:
+        mpc.offline_fit(*offline_data())        # duffing.py:152-177 (fit) on the device
 
     init = np.array([-2.0, -2.0])                                                   # duffing.py:649
     x0 = np.tile(init[:, None], (1, B)) if B == 1 else initial_states(B)

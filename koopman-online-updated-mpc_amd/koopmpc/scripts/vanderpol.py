@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--Nlift", type=int, default=8)
     ap.add_argument("--horizon", type=int, default=10)
+    ap.add_argument("--model", default=None, help=".npz with A0, B0, C0: the offline model instead of fitting one here")
     ap.add_argument("--out", default=None)
     a = ap.parse_args()
     if a.weights:
@@ -31,7 +32,11 @@ def main():
         Nlift, weights = a.Nlift, random_mlp_weights(2, 100, 3, a.Nlift)
     B, N = a.batch, a.horizon
     mpc = KoopmanMPC(n=2, L=Nlift, N=N, batch=B, weights=weights, output="lift", lb=-6.0, ub=6.0, P0=1e5, barQ0=1e5)
-    mpc.offline_fit(*offline_data(plant=vdp_rk4))                              # vanderpol.py:150-175
+    if a.model:
+        d = np.load(a.model)
+        mpc.set_model(d["A0"], d["B0"], d["C0"])                                # vanderpol.py:726-728
+    else:
+        mpc.offline_fit(*offline_data(plant=vdp_rk4))                          # vanderpol.py:150-175
     goal = mpc.Encoder(np.array([[1.0], [0.0]]))                               # check_goal, vanderpol.py:668-675
     goal = goal.cpu().numpy() if torch.is_tensor(goal) else np.asarray(goal)
     r = np.tile(goal.reshape(Nlift, 1), (1, N))                                # the same lifted reference at every stage

@@ -133,15 +133,17 @@ def rls_update_reference(st, xlift, u, ylift, x_next, lam=1.0):
 
 
 def rls_update_gain(K, P, z, y, lam=1.0):
-    """Algebraically identical gain form  K += (y - K z) g',  g = P z / (lam + z' P z),
-    P <- (P - g (P z)') / lam   (expand K_A_new P_new with K = K_A P, P symmetric).
-    This is the form the HIP kernel evaluates; the tests check it against rls_update_reference."""
+    """Gain form of rls_update_reference, algebraically identical for every lam: with K = K_A P, P symmetric,
+    g = P z / (lam + z' P z) one has P_new z = g, so K_A_new P_new = (K - K z g') / lam + y g'
+    (K_A is NOT discounted, Koopman_update.m:270-274); lam = 1: K += (y - K z) g'.
+    P <- (P - g (P z)') / lam.  This is the form the HIP kernel evaluates; the tests check it against
+    rls_update_reference (also at lam < 1)."""
     z = np.reshape(z, (-1, 1))
     y = np.reshape(y, (-1, 1))
     Pz = P @ z
     d = lam + float((z.T @ Pz)[0, 0])
     g = Pz / d
-    Kn = K + (y - K @ z) @ g.T
+    Kn = (K - (K @ z) @ g.T) / lam + y @ g.T if lam != 1.0 else K + (y - K @ z) @ g.T
     Pn = (P - Pz @ Pz.T / d) / lam
     return Kn, Pn
 

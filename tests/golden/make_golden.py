@@ -90,7 +90,13 @@ def worker(script, steps, out):
 
     def __extra__(loc):
         # bar_X / bar_Q only exist in the RLS scripts (the *_RBF.py files use the storage method)
-        return {k: loc[k] for k in ("bar_X", "bar_Q") if k in loc}
+        out = {k: loc[k] for k in ("bar_X", "bar_Q") if k in loc}
+        if "XU_EX" in loc:
+            # the *_RBF.py "storage" update (vanderpol_RBF.py:434-438) refits from ALL stored samples at every step; what it
+            # needs of the 10 000+ stored columns are their Gram sums -- data computed from the reference's own arrays
+            out.update(stor_KG=loc["K_G"], stor_GX=loc["X_EX"] @ loc["X_EX"].T, stor_XXE=loc["X"] @ loc["X_EX"].T,
+                       stor_M=float(loc["X_EX"].shape[1]))
+        return out
 
     g = globals()
     g["__snap__"] = __snap__

@@ -970,19 +970,13 @@ def test_warm_start_is_the_same_minimiser_with_less_work(torch_mod, KM, L, N, ou
 
 
 def _copy_uprev(dst, src):
-    """u_{k} of `src` (tail of its state blob) into `dst`, so that both see the same transition."""
-    sb, db = src.state_dict()["blob"], dst.state_dict()["blob"].copy()
-    nb = src.B * 8
-    db[-nb:] = sb[-nb:]
-    dst.load_state_dict({"blob": db})
+    """u_{k} of `src` into `dst`, so that both see the same transition."""
+    dst.set_applied_input(src.U0)
 
 
 def _set_uprev(mpc, sd, uk):
-    """Replace the stored u_{k} of every trajectory in a state blob (tail of the blob) and load it back."""
-    blob = sd["blob"].copy()
-    tail = np.full(mpc.B, uk, dtype=np.float64)
-    blob[-tail.nbytes:] = tail.view(np.uint8)
-    mpc.load_state_dict({"blob": blob})
+    """Replace the stored u_{k} of every trajectory (the input that was applied on the followed trajectory)."""
+    mpc.set_applied_input(uk)
 
 
 @pytest.mark.parametrize("lift", ["rbf", "mlp"])
