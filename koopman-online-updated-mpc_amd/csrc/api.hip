@@ -421,6 +421,8 @@ struct Impl : kmpc_handle {
     a.umin = (T)cfg.umin; a.umax = (T)cfg.umax;
     a.u_prev = dUprev;  // delta-u reads the absolute previous input in every phase
     a.qp_scratch = dQpScr;
+    static const int predict = getenv("KMPC_QP_PREDICT") ? atoi(getenv("KMPC_QP_PREDICT")) : 1;  // measurement aid: 0 = plain projected Newton
+    a.qp_predict = predict;
     a.plant = -1;
     return a;
   }

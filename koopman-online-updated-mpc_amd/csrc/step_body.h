@@ -426,6 +426,8 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   const unsigned long long ownmask = __ballot(own);
   unsigned long long Smask = 0ull;  // lane-space mask of the variables swept into T
   int it = 0, status = 1, refresh = 0, polish = 0;
+  int rtot = 0;            // prediction rounds of the solve: each is a Newton solve on a smaller face (reported with `it`)
+  bool nopredict = false;  // the last predicted point was refused: this pass of the loop is a plain projected-Newton step
   KTRACE(8);
 
   while (true) {
@@ -462,68 +464,105 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     unsigned long long Fmask = ~Imask & ownmask;
     if (it == 0) KTRACE(9);
 
+    // Active-set prediction (on top of Bertsekas' iteration): when the Newton point of the free set F carries free
+    // variables beyond a bound, the worst offender is fixed at that bound, swept out of the tableau (one O(N^2) sweep) and the
+    // Newton point of the smaller face is recomputed -- repeated until the Newton point is feasible.  Plain projected Newton
+    // finds such variables one ITERATION at a time (projection, Armijo, a new KKT pass: ~4x the work of a round); on the
+    // bench workload that is 2.1 -> 1.06 iterations per solve right after the RLS reset, and the slowest of 16 trajectories --
+    // whom the workgroup waits for -- needs 1.7 instead of 7.8 (tools/qp_study.py on QPs collected from the device).  The
+    // predicted point is taken only if it lowers the true cost; otherwise this iteration falls back to the projected Armijo
+    // step, so convergence is that of the plain method and termination is still the KKT test at the top.
+    // (a predicted variable's bound waits in LDS, qx_out[variable]; nothing is written or kept when no round happens)
+    bool predict = !nopredict && a.qp_predict != 0;
+    int rounds = 0;
     bool broke = false;
-    for (int pass = 0; pass < 2; ++pass) {
-      const unsigned long long diff = Smask ^ Fmask;
-      // One straight-line block per variable, in owner-lane order ((k&7)*8 + (k>>3), the order of the bit scan):
-      // with k a compile-time constant the block index, the pivot lane and the owner tests fold, and the tableau
-      // stays in the same registers from block to block (a run-time switch over the block index cost ~20 register
-      // moves per sweep).  Blocks of variables that do not change sides are skipped by a uniform branch.
+    T pdir = T(0);
+    bool isF = false;
+    while (true) {
+      broke = false;
+      for (int pass = 0; pass < 2; ++pass) {
+        const unsigned long long diff = Smask ^ Fmask;
+        // One straight-line block per variable, in owner-lane order ((k&7)*8 + (k>>3), the order of the bit scan):
+        // with k a compile-time constant the block index, the pivot lane and the owner tests fold, and the tableau
+        // stays in the same registers from block to block (a run-time switch over the block index cost ~20 register
+        // moves per sweep).  Blocks of variables that do not change sides are skipped by a uniform branch.
 #pragma unroll
-      for (int kt = 0; kt < 8; ++kt) {
+        for (int kt = 0; kt < 8; ++kt) {
 #pragma unroll
-        for (int kr = 0; kr < RM; ++kr) {
-          if (kt + 8 * kr < N_) {
-            const int kl = kt * 8 + kr;
-            if ((diff >> kl) & 1ull) {
-              const bool rev = (Smask >> kl) & 1ull;
-              const T d = lane_bcast(Tm[kr][kr], kt * 9);
-              if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
-                broke = true;
-                if (pass == 1) Fmask &= ~(1ull << kl);
-              } else {
-                sweep_regs_at<T, N_>(Tm, kr, kt, rev, d, ti, tj);
-                Smask ^= (1ull << kl);
+          for (int kr = 0; kr < RM; ++kr) {
+            if (kt + 8 * kr < N_) {
+              const int kl = kt * 8 + kr;
+              if ((diff >> kl) & 1ull) {
+                const bool rev = (Smask >> kl) & 1ull;
+                const T d = lane_bcast(Tm[kr][kr], kt * 9);
+                if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
+                  broke = true;
+                  if (pass == 1) Fmask &= ~(1ull << kl);
+                } else {
+                  sweep_regs_at<T, N_>(Tm, kr, kt, rev, d, ti, tj);
+                  Smask ^= (1ull << kl);
+                }
               }
             }
           }
         }
+        if (!broke || pass == 1) break;
+        ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+          for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
+        Smask = 0ull;
       }
-      if (!broke || pass == 1) break;
-      ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
-#pragma unroll
-      for (int r = 0; r < RM; ++r)
-#pragma unroll
-        for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
-      Smask = 0ull;
-    }
-    Fmask = Smask;
-    if (it == 0) KTRACE(10);
+      Fmask = Smask;
+      if (it == 0 && rounds == 0) KTRACE(10);
 
-    // Newton direction on F: p_i = sum_{j in F} T_ij g_j ; straight to the bound on I
-    const bool isF = own && ((Fmask >> tid) & 1ull);
-    const T gm = isF ? g : T(0);
-    T pdir = T(0);
-    {
-      T gc[RM];
+      // Newton direction on F: p_i = sum_{j in F} T_ij g_j
+      isF = own && ((Fmask >> tid) & 1ull);
+      const T gm = isF ? g : T(0);
+      {
+        T gc[RM];
 #pragma unroll
-      for (int c = 0; c < RM; ++c) gc[c] = __shfl(gm, tj * 8 + c, 64);  // owner of variable tj + 8c
+        for (int c = 0; c < RM; ++c) gc[c] = __shfl(gm, tj * 8 + c, 64);  // owner of variable tj + 8c
 #pragma unroll
-      for (int r = 0; r < RM; ++r) {
-        T s0 = T(0);
+        for (int r = 0; r < RM; ++r) {
+          T s0 = T(0);
 #pragma unroll
-        for (int c = 0; c < RM; ++c) s0 += Tm[r][c] * gc[c];
-        s0 = allreduce8(s0);
-        if (tj == r) pdir = s0;
+          for (int c = 0; c < RM; ++c) s0 += Tm[r][c] * gc[c];
+          s0 = allreduce8(s0);
+          if (tj == r) pdir = s0;
+        }
       }
+      if (!predict || broke || rounds >= N_) break;
+      // the free variable whose Newton value lies furthest outside the box (free variables still sit at x)
+      const T cand = x + pdir;
+      const T over = isF ? (cand - ub > lb - cand ? cand - ub : lb - cand) : T(-1);
+      if (__ballot(over > T(0)) == 0ull) break;  // (the usual case: the Newton point is feasible)
+      const T worst = wave_max_x(over);
+      const int jl = __ffsll((long long)__ballot(over == worst)) - 1;  // its owner lane
+      const T bj = cand > ub ? ub : lb;
+      const T delta = lane_bcast(bj - x, jl);
+      if (tid == jl) qx_out[myvar] = bj;
+      // gradient at the new base point: g += 2 H[:, j] delta (H is intact in LDS)
+      const int jv = (jl >> 3) + 8 * (jl & 7);
+      if (own) g += T(2) * sH[myvar * N_ + jv] * delta;
+      Fmask &= ~(1ull << jl);
+      ++rounds;
     }
-    if (!isF) pdir = own ? ((g > T(0) ? lb : (g < T(0) ? ub : x)) - x) : T(0);
-
     if (it == 0) KTRACE(11);
-    // projected Armijo search on the true cost
+
     T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
+    bool redo = false;
     while (true) {
-      xa = own ? tclip(x + alpha * pdir, lb, ub) : T(0);
+      // free variables move along the Newton direction of the (predicted) face, the bound set of the KKT pass goes onto its
+      // bounds (sign of the gradient at x, which the rounds have not kept), predicted variables onto theirs
+      T dstep = pdir;
+      if (!isF) {
+        const T g0 = T(2) * hx + fi;
+        dstep = own ? ((g0 > T(0) ? lb : (g0 < T(0) ? ub : x)) - x) : T(0);
+        if (rounds > 0 && own && !inI) dstep = qx_out[myvar] - x;
+      }
+      xa = own ? tclip(x + alpha * dstep, lb, ub) : T(0);
       T xc[RM];
 #pragma unroll
       for (int c = 0; c < RM; ++c) xc[c] = __shfl(xa, tj * 8 + c, 64);
@@ -536,6 +575,12 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
         if (tj == r) hxa = s0;
       }
       T pJa = own ? xa * (hxa + fi) : T(0);
+      if (rounds > 0) {
+        // a predicted point: accepted if it lowers the cost, else the iteration is redone as a plain projected-Newton step
+        Ja = wave_sum(pJa);
+        if (!(Ja <= J0)) redo = true;
+        break;
+      }
       T pdec = own ? (isF ? alpha * (-g * pdir) : g * (x - xa)) : T(0);
       block_sum2<T, 64>(pJa, pdec, red);
       Ja = pJa;
@@ -543,6 +588,12 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
       if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
       alpha *= T(0.25);
     }
+    if (redo) {  // (rare) this iteration again from its KKT pass, as a plain projected-Newton step: the free set of that pass is
+      nopredict = true;  // restored by the sweeps (the predicted variables go back in), the gradient is recomputed from hx
+      continue;
+    }
+    nopredict = false;
+    rtot += rounds;
     x = xa;
     hx = hxa;
     J0 = Ja;
@@ -551,7 +602,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   }
   KTRACE(13);
 #ifdef KMPC_TRACE
-  if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + 15] = (unsigned long long)it;
+  if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + 15] = (unsigned long long)(it + rtot);
 #endif
 
   // non-finite problem data (status 2): the point handed back is the feasible start clip(0), never a NaN -- the
@@ -581,10 +632,10 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     if (sv.x_next) {  // ... and the status / iteration counters are accumulated next to it, written once at the end
       int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
       acc[0] = acc[0] > status ? acc[0] : status;
-      acc[1] += it;
+      acc[1] += it + rtot;
     } else {
       if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
-      if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+      if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it + rtot : it + rtot;
     }
   }
   KTRACE(14);
@@ -721,7 +772,8 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   T hx = matvec(Hm, x);
   T J0 = block_sum<T, 256>(own ? x * (hx + fi) : T(0), red);
   unsigned long long Smask = 0ull;
-  int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0;
+  int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0, rtot = 0;
+  bool nopredict = false;
 
   while (true) {
     T g = T(0);
@@ -757,59 +809,102 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     if (it >= N_ + 10) { status = 3; break; }  // crawling: the active-set loop of qp_lds finishes from here
     unsigned long long Fmask = ~Imask & allmask;
 
-    bool broke = false;
-    for (int pass = 0; pass < 2; ++pass) {
-      unsigned long long diff = Smask ^ Fmask;
-      while (diff) {
-        const int k = __ffsll((long long)diff) - 1;
-        diff &= diff - 1ull;
-        const int kt = k & 15, kr = k >> 4;
-        const bool rev = (Smask >> k) & 1ull;
-        T* const col = colb + (nsw & 1) * 64;
-        T* const row = rowb + (nsw & 1) * 64;
-        ++nsw;
-        switch (kr) {
-          case 0: sweep_put256<T, N_, 0>(Tm, kt, ti, tj, col, row); break;
-          case 1: if constexpr (RM > 1) sweep_put256<T, N_, 1>(Tm, kt, ti, tj, col, row); break;
-          case 2: if constexpr (RM > 2) sweep_put256<T, N_, 2>(Tm, kt, ti, tj, col, row); break;
-          default: if constexpr (RM > 3) sweep_put256<T, N_, 3>(Tm, kt, ti, tj, col, row); break;
-        }
-        __syncthreads();
-        const T d = col[k];  // T(k, k)
-        if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
-          broke = true;
-          if (pass == 1) Fmask &= ~(1ull << k);
-          continue;
-        }
-        switch (kr) {
-          case 0: sweep_regs256<T, N_, 0>(Tm, kt, rev, d, ti, tj, col, row); break;
-          case 1: if constexpr (RM > 1) sweep_regs256<T, N_, 1>(Tm, kt, rev, d, ti, tj, col, row); break;
-          case 2: if constexpr (RM > 2) sweep_regs256<T, N_, 2>(Tm, kt, rev, d, ti, tj, col, row); break;
-          default: if constexpr (RM > 3) sweep_regs256<T, N_, 3>(Tm, kt, rev, d, ti, tj, col, row); break;
-        }
-        Smask ^= (1ull << k);
-      }
-      if (!broke || pass == 1) break;
-      ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
-#pragma unroll
-      for (int r = 0; r < RM; ++r)
-#pragma unroll
-        for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hm[r][c];
-      Smask = 0ull;
-    }
-    Fmask = Smask;
-
-    // Newton direction on F, straight to the bound on I
-    const bool isF = own && ((Fmask >> myvar) & 1ull);
-    T pdir = matvec(Tm, isF ? g : T(0));
-    if (!isF) pdir = own ? ((g > T(0) ? lb : (g < T(0) ? ub : x)) - x) : T(0);
-
-    // projected Armijo search on the true cost
-    T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
+    // active-set prediction rounds inside the iteration: see qp_regs (same rule, the block-wide maximum goes through LDS)
+    const bool predict = !nopredict && a.qp_predict != 0;
+    int rounds = 0;
+    bool broke = false, isF = false;
+    T pdir = T(0);
     while (true) {
-      xa = own ? tclip(x + alpha * pdir, lb, ub) : T(0);
+      broke = false;
+      for (int pass = 0; pass < 2; ++pass) {
+        unsigned long long diff = Smask ^ Fmask;
+        while (diff) {
+          const int k = __ffsll((long long)diff) - 1;
+          diff &= diff - 1ull;
+          const int kt = k & 15, kr = k >> 4;
+          const bool rev = (Smask >> k) & 1ull;
+          T* const col = colb + (nsw & 1) * 64;
+          T* const row = rowb + (nsw & 1) * 64;
+          ++nsw;
+          switch (kr) {
+            case 0: sweep_put256<T, N_, 0>(Tm, kt, ti, tj, col, row); break;
+            case 1: if constexpr (RM > 1) sweep_put256<T, N_, 1>(Tm, kt, ti, tj, col, row); break;
+            case 2: if constexpr (RM > 2) sweep_put256<T, N_, 2>(Tm, kt, ti, tj, col, row); break;
+            default: if constexpr (RM > 3) sweep_put256<T, N_, 3>(Tm, kt, ti, tj, col, row); break;
+          }
+          __syncthreads();
+          const T d = col[k];  // T(k, k)
+          if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
+            broke = true;
+            if (pass == 1) Fmask &= ~(1ull << k);
+            continue;
+          }
+          switch (kr) {
+            case 0: sweep_regs256<T, N_, 0>(Tm, kt, rev, d, ti, tj, col, row); break;
+            case 1: if constexpr (RM > 1) sweep_regs256<T, N_, 1>(Tm, kt, rev, d, ti, tj, col, row); break;
+            case 2: if constexpr (RM > 2) sweep_regs256<T, N_, 2>(Tm, kt, rev, d, ti, tj, col, row); break;
+            default: if constexpr (RM > 3) sweep_regs256<T, N_, 3>(Tm, kt, rev, d, ti, tj, col, row); break;
+          }
+          Smask ^= (1ull << k);
+        }
+        if (!broke || pass == 1) break;
+        ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
+#pragma unroll
+        for (int r = 0; r < RM; ++r)
+#pragma unroll
+          for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hm[r][c];
+        Smask = 0ull;
+      }
+      Fmask = Smask;
+
+      // Newton direction on F
+      isF = own && ((Fmask >> myvar) & 1ull);
+      pdir = matvec(Tm, isF ? g : T(0));
+      if (!predict || broke || rounds >= N_) break;
+      // the free variable whose Newton value lies furthest outside the box is fixed at that bound
+      const T cand = x + pdir;
+      const T over = isF ? (cand - ub > lb - cand ? cand - ub : lb - cand) : T(-1);
+      const T wmax = wave_max_x(over);
+      __syncthreads();
+      if ((tid & 63) == 0) red[tid >> 6] = wmax;
+      if (tid == 0) smk[0] = ~0ull;
+      __syncthreads();
+      const T w01 = red[0] > red[1] ? red[0] : red[1], w23 = red[2] > red[3] ? red[2] : red[3];
+      const T worst = w01 > w23 ? w01 : w23;
+      if (!(worst > T(0))) break;
+      if (isF && over == worst) atomicMin(&smk[0], (unsigned long long)myvar);
+      __syncthreads();
+      const int jv = (int)smk[0];
+      if (own && myvar == jv) {
+        const T bj = cand > ub ? ub : lb;
+        qx_out[jv] = bj;
+        red[12] = bj - x;
+      }
+      __syncthreads();
+      const T delta = red[12];
+      if (own) g += T(2) * sH[myvar * N_ + jv] * delta;  // gradient at the new base point
+      Fmask &= ~(1ull << jv);
+      ++rounds;
+    }
+
+    // trial point (see qp_regs): projected Armijo search on the true cost, or the predicted point if it lowers the cost
+    T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
+    bool redo = false;
+    while (true) {
+      T dstep = pdir;
+      if (!isF) {
+        const T g0 = T(2) * hx + fi;
+        dstep = own ? ((g0 > T(0) ? lb : (g0 < T(0) ? ub : x)) - x) : T(0);
+        if (rounds > 0 && own && !inI) dstep = qx_out[myvar] - x;
+      }
+      xa = own ? tclip(x + alpha * dstep, lb, ub) : T(0);
       hxa = matvec(Hm, xa);
       T pJa = own ? xa * (hxa + fi) : T(0);
+      if (rounds > 0) {
+        Ja = block_sum<T, 256>(pJa, red);
+        if (!(Ja <= J0)) redo = true;
+        break;
+      }
       T pdec = own ? (isF ? alpha * (-g * pdir) : g * (x - xa)) : T(0);
       block_sum2<T, 256>(pJa, pdec, red);
       Ja = pJa;
@@ -817,6 +912,12 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
       alpha *= T(0.25);
     }
+    if (redo) {
+      nopredict = true;
+      continue;
+    }
+    nopredict = false;
+    rtot += rounds;
     x = xa;
     hx = hxa;
     J0 = Ja;
@@ -844,7 +945,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       a.X_rw[(size_t)B + b] = x2;
     }
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
-    if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it : it;
+    if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it + rtot : it + rtot;
   }
   return false;
 }

@@ -48,6 +48,10 @@ def pn(H, f, x0, eact_rel=1e-8, predict=False, max_it=200, eps_rule=None, ls="ar
                     with np.errstate(divide="ignore", invalid="ignore"):
                         al = np.where(out, np.where(step > 0, (ub - z0) / step, (lb - z0) / step), np.inf)
                     j = np.argmin(al); out = np.zeros(N, bool); out[j] = True
+                if predict == "lane":  # the offender on the lowest owner lane: variable k sits on lane (k & 7) * 8 + (k >> 3)
+                    ks = np.where(out)[0]; j = ks[np.argmin((ks & 7) * 8 + (ks >> 3))]; out = np.zeros(N, bool); out[j] = True
+                if predict == "first":  # the earliest offender of the horizon
+                    j = np.where(out)[0][0]; out = np.zeros(N, bool); out[j] = True
                 if predict == "one":   # only the worst offender per round
                     viol_amt = np.where(out, np.maximum(xa - ub, lb - xa), -1)
                     j = np.argmax(viol_amt); out = np.zeros(N, bool); out[j] = True
@@ -78,9 +82,9 @@ def run(name, start='warm', **kw):
     for s in range(S):
         for b in range(0, Bk, 2):
             x, it, nback, nf, nsw = pn(H_[s, b], f_[s, b], W_[s, b] if start == 'warm' else (np.zeros(20) if start == 'cold' else np.clip(-np.linalg.solve(2 * H_[s, b], f_[s, b]), lb, ub)), **kw)
-            its.append(it); costs.append(it + 0.35 * nf + 0.3 * nsw + 0.3 * nback); sweeps.append(nsw); errs.append(np.abs(x - U_[s, b]).max()); nb += nback
+            its.append(it); costs.append(it + 0.27 * nf + 0.08 * nsw + 0.3 * nback); sweeps.append(nsw); errs.append(np.abs(x - U_[s, b]).max()); nb += nback
     its = np.array(its); costs = np.array(costs)
-    print('   sweeps/solve %.1f;' % np.mean(sweeps), end=''); print(' cost (it + 0.35 fix + 0.3 sweep + .3 backtrack): mean %.2f  E[max16] %.2f  p99 %.2f max %.2f' % (costs.mean(), costs.reshape(S, -1, 16).max(2).mean(), np.percentile(costs, 99), costs.max()))
+    print('   sweeps/solve %.1f;' % np.mean(sweeps), end=''); print(' cost (it + 0.27 fix + 0.08 sweep + .3 backtrack): mean %.2f  E[max16] %.2f  p99 %.2f max %.2f' % (costs.mean(), costs.reshape(S, -1, 16).max(2).mean(), np.percentile(costs, 99), costs.max()))
     mx = its.reshape(S, -1, 16).max(2).mean()
     print("  (fixes %d)" % nfix[0], end=""); nfix[0] = 0
     print("%-28s mean %.2f  P(>=3) %.3f P(>=5) %.3f P(>=10) %.4f max %d  E[max16] %.2f  backtracks/solve %.2f  max|x - x_gpu| %.1e" % (
@@ -92,7 +96,5 @@ print("GPU                          mean %.2f  P(>=3) %.3f P(>=5) %.3f P(>=10) %
     g.mean(), (g >= 3).mean(), (g >= 5).mean(), (g >= 10).mean(), g.max(), IT[:, ::2].reshape(IT.shape[0], -1, 16).max(2).mean()))
 run("emulation (kernel rules)")
 run("prediction (worst offender)", predict="one")
-run("cold start", start="cold")
-run("start at clipped unconstrained", start="unc")
-run("worst offender + cold", start="cold", predict="one")
-run("worst offender + clipped unc", start="unc", predict="one")
+run("prediction (lowest lane)", predict="lane")
+run("prediction (earliest)", predict="first")
