@@ -168,7 +168,7 @@ struct Impl : kmpc_handle {
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
                       (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
-                      (void*)dMsf, (void*)dMsc, (void*)dMsW})
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -711,7 +711,7 @@ struct Impl : kmpc_handle {
 
   // ---- shared-model mode -----------------------------------------------------------------------------
   double *dGram = nullptr, *dPartial = nullptr;
-  T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr;
+  T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr, *dTs = nullptr;
   T* dWt = nullptr;  // PN - Qw I (terminal block of Q_bar)
   bool have_wterm = false;
   // kmpc_terminal_from_dare: Riccati workspace and the block(s) it produced ([1] or [B][q*q], PN - Qw I)
@@ -754,8 +754,7 @@ struct Impl : kmpc_handle {
     g.psi_prev = psi_prev; g.pp_sl = 1; g.pp_sb = L;
     g.psi_now = psi_now; g.pn_sl = 1; g.pn_sb = L;
     g.u_prev = dUprev; g.x_now = (const T*)X; g.partial = dPartial;
-    HIPCHK(hipMemsetAsync(delta, 0, sizeof(double) * (size_t)gram_elems(), s));
-    HIPCHK(launch_gram<T>(g, 0.0, delta, s));
+    HIPCHK(launch_gram<T>(g, 0.0, delta, s));  // (forget = 0 overwrites delta)
     return 0;
   }
   int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
@@ -765,19 +764,31 @@ struct Impl : kmpc_handle {
       FAIL(-3, "kmpc_shared_solve: per-trajectory terminal blocks do not apply to the shared model (kmpc_terminal_from_dare with per_trajectory = 0)");
     int rc = shared_alloc();
     if (rc) return rc;
-    if (have_prev) {
-      HIPCHK(launch_axpby(dGram, delta, cfg.lambda, (int)gram_elems(), s));
-      HIPCHK(launch_shared_solve<T>(dGram, L, n, 1.0 / cfg.P0, 1.0 / cfg.barQ0,
-                                    cfg.output_kind == KMPC_OUT_CX ? 1 : 0, dKs, dCs, s));
-      shared_has_samples = true;
+    const T* wt = !have_wterm ? nullptr : (wterm_from_dare ? (const T*)dWtB : dWt);
+    const int okind = cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX;
+    const int cy0 = cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0;
+    static const bool two_kernels = getenv("KMPC_SHARED_TWO_KERNELS") != nullptr;  // measurement aid: the round-1 launches
+    const bool one_launch = !two_kernels && cfg.output_kind == KMPC_OUT_CX && shared_model_available(L, n, q, N, cfg.delta_u ? 1 : 0);
+    if (have_prev) HIPCHK(launch_axpby(dGram, delta, cfg.lambda, (int)gram_elems(), s));
+    if (one_launch) {
+      // model solve + condensed QP + the tableau the box QPs start from, one launch (shared_model_kernel)
+      if (!dTs) HIPCHK(hipMalloc(&dTs, sizeof(T) * (size_t)N * N));
+      HIPCHK(launch_shared_model<T>(dGram, (const T*)ref, L, n, q, N, 1.0 / cfg.P0, 1.0 / cfg.barQ0, 1, have_prev ? 1 : 0, cfg.Qw,
+                                    cfg.Rw, dKs, dCs, dHs, dFs, df0s, dTs, wt, cfg.delta_u ? 1 : 0, cy0, s));
+      if (have_prev) shared_has_samples = true;
+    } else {
+      if (have_prev) {
+        HIPCHK(launch_shared_solve<T>(dGram, L, n, 1.0 / cfg.P0, 1.0 / cfg.barQ0,
+                                      cfg.output_kind == KMPC_OUT_CX ? 1 : 0, dKs, dCs, s));
+        shared_has_samples = true;
+      }
+      HIPCHK(launch_shared_condense<T>(dKs, dCs, (const T*)ref, L, n, q, N, okind, cfg.Qw, cfg.Rw, dHs, dFs, df0s, s, wt,
+                                       cfg.delta_u ? 1 : 0, cy0));
     }
-    HIPCHK(launch_shared_condense<T>(dKs, dCs, (const T*)ref, L, n, q, N,
-                                     cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX, cfg.Qw, cfg.Rw, dHs, dFs,
-                                     df0s, s, !have_wterm ? nullptr : (wterm_from_dare ? (const T*)dWtB : dWt), cfg.delta_u ? 1 : 0,
-                                     cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0));
     StepArgs<T> a = base_args(B);
     a.phases = PH_QP;
     a.H_in = dHs; a.h_shared = 1; a.F_in = dFs; a.f0_in = df0s;
+    a.T_in = one_launch ? dTs : nullptr;
     a.psi_now = dPsi[cur]; a.pn_sl = 1; a.pn_sb = L;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
     a.x_warm = cfg.cold_start ? nullptr : dWarm;

@@ -381,10 +381,15 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     if constexpr (HREG) return Hm[r][c];
     else return (hb[r] >= 0 && cok[c]) ? sH[hb[r] + 8 * c] : T(0);
   };
+  // shared-model mode: H is the same for every trajectory, and so is the tableau of the free set "all inputs",
+  // T0 = -(2H)^-1 (built once per step by shared_model_kernel): the solve starts from it and only sweeps OUT the inputs
+  // that sit on a bound, instead of sweeping every free input IN (N sweeps per trajectory and step)
+  const bool t0 = a.T_in != nullptr;
 #pragma unroll
   for (int r = 0; r < RM; ++r)
 #pragma unroll
-    for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
+    for (int c = 0; c < RM; ++c)
+      Tm[r][c] = t0 ? ((hb[r] >= 0 && cok[c]) ? a.T_in[hb[r] + 8 * c] : T(0)) : T(2) * Hel(r, c);
   const T fi = own ? sf[myvar] : T(0);
   // row sums of |H| for the owner's variable: partial over my columns, 8-lane all-reduce,
   // the owner of variable ti + 8*tj picks block row r = tj
@@ -424,7 +429,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   T p0 = own ? x * (hx + fi) : T(0);
   T J0 = wave_sum(p0);
   const unsigned long long ownmask = __ballot(own);
-  unsigned long long Smask = 0ull;  // lane-space mask of the variables swept into T
+  unsigned long long Smask = t0 ? ownmask : 0ull;  // lane-space mask of the variables swept into T
   int it = 0, status = 1, refresh = 0, polish = 0;
   int rtot = 0;            // prediction rounds of the solve: each is a Newton solve on a smaller face (reported with `it`)
   bool nopredict = false;  // the last predicted point was refused: this pass of the loop is a plain projected-Newton step
