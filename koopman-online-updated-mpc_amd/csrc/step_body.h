@@ -432,7 +432,20 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   unsigned long long Smask = t0 ? ownmask : 0ull;  // lane-space mask of the variables swept into T
   int it = 0, status = 1, refresh = 0, polish = 0;
   int rtot = 0;            // prediction rounds of the solve: each is a Newton solve on a smaller face (reported with `it`)
-  bool nopredict = false;  // the last predicted point was refused: this pass of the loop is a plain projected-Newton step
+  // Active-set mode (the safeguard, in registers): when projected Newton crawls -- three predicted points refused, eight
+  // Armijo backtracks, or N + 10 iterations (ill-conditioned, almost fully saturated problems) -- the solve continues on
+  // the same tableau as a PRIMAL ACTIVE-SET method: Newton direction on the free set, ratio test to the first blocking
+  // bound (which joins the working set W), and at a minimiser of the face the worst wrong-signed multiplier leaves W --
+  // monotone and finite for a strictly convex QP.  (Round 1 left the register solver for an LDS / global-memory tableau
+  // here: 30 ms for a step of 8192 Delta-u tank QPs after the plant switch, tools/cfg4_transient.py.)
+  // Compiled in for the long horizons (N > 24: their kernels have 256+ registers per lane, and their LDS has no room for a
+  // tableau, so the round-1 fall-back worked on H in global memory); the short-horizon kernels sit at the 128-register limit
+  // of four waves per SIMD (this code costs the cfg2 roll-out 13 %) and keep the LDS fall-back of qp_lds.
+  constexpr bool AS_CT = N_ > 24;
+  const bool AS_REGS = AS_CT && (a.qp_predict & 2) == 0;  // (bit 1 of qp_predict: measurement aid, the LDS fall-back instead)
+  bool mode_as = false, enter_as = false, at_min = false, nopredict = false;
+  int ncrawl = 0;  // refused predictions (x 3) + Armijo backtracks of this solve
+  unsigned long long Wmask = 0ull;  // active-set mode: variables held at a bound (lane space)
   KTRACE(8);
 
   while (true) {
@@ -458,15 +471,26 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     // to two more Newton solves on its face -- iterative refinement -- so that the result does not depend on
     // the path (cold or warm start) beyond rounding.  A warm start itself is never returned unsolved.
     if (Bmask == 0ull && (it > 0 || !a.x_warm)) {
-      if (!refine || polish >= 2) { status = 0; break; }
+      if (!refine || (AS_REGS && mode_as) || polish >= 2) { status = 0; break; }
       ++polish;
     }
     if (it >= a.max_iter || refresh > 4) { status = 1; break; }
-    // Safeguard: projected Newton can crawl (tiny Armijo steps) on ill-conditioned, almost fully saturated
-    // problems; after N+10 iterations the caller finishes the solve from the current point with the
-    // active-set method of qp_lds (rare: ~4e-5 of the QPs of the cfg3-sized closed loop).
-    if (it >= N_ + 10) { status = 3; break; }
-    unsigned long long Fmask = ~Imask & ownmask;
+    if (!AS_REGS) {
+      if (it >= N_ + 10) { status = 3; break; }  // crawling: the caller finishes the solve with the active-set loop of qp_lds
+    }
+    if (AS_REGS && !mode_as && (enter_as || it >= N_ + 10)) {
+      mode_as = true;
+      at_min = false;
+      Wmask = Imask;
+    }
+    if (AS_REGS && mode_as && at_min) {  // x minimises the cost on the free set: release the worst wrong-signed multiplier
+      const bool inW = (Wmask >> tid) & 1ull;
+      const T vr = (own && inW && !inI) ? tabs(g) / gs : T(0);
+      const T vmax = wave_max_x(vr);
+      if (vmax > tol) Wmask &= ~(1ull << (__ffsll((long long)__ballot(own && vr == vmax)) - 1));
+      at_min = false;
+    }
+    unsigned long long Fmask = ((AS_REGS && mode_as) ? ~Wmask : ~Imask) & ownmask;
     if (it == 0) KTRACE(9);
 
     // Active-set prediction (on top of Bertsekas' iteration): when the Newton point of the free set F carries free
@@ -478,7 +502,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     // predicted point is taken only if it lowers the true cost; otherwise this iteration falls back to the projected Armijo
     // step, so convergence is that of the plain method and termination is still the KKT test at the top.
     // (a predicted variable's bound waits in LDS, qx_out[variable]; nothing is written or kept when no round happens)
-    bool predict = !nopredict && a.qp_predict != 0;
+    const bool predict = !(AS_REGS && mode_as) && !nopredict && (a.qp_predict & 1) != 0;
     int rounds = 0;
     bool broke = false;
     T pdir = T(0);
@@ -558,16 +582,33 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
 
     T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
     bool redo = false;
+    int jb = -1;
+    if (AS_REGS && mode_as) {
+      // ratio test: the largest step along the Newton direction that keeps the free variables inside the box
+      T al = (T)1e300;
+      if (isF && pdir < T(0) && x + pdir < lb) al = (lb - x) / pdir;
+      if (isF && pdir > T(0) && x + pdir > ub) al = (ub - x) / pdir;
+      const T amin = wave_min_x(al);
+      alpha = amin < T(1) ? (amin > T(0) ? amin : T(0)) : T(1);
+      if (amin < T(1)) {
+        jb = __ffsll((long long)__ballot(own && al == amin)) - 1;
+        Wmask |= (1ull << jb);
+      } else {
+        at_min = true;
+      }
+    }
     while (true) {
       // free variables move along the Newton direction of the (predicted) face, the bound set of the KKT pass goes onto its
-      // bounds (sign of the gradient at x, which the rounds have not kept), predicted variables onto theirs
+      // bounds (sign of the gradient at x, which the rounds have not kept), predicted variables onto theirs; active-set
+      // mode: the working set stays where it is, the blocking variable lands exactly on its bound
       T dstep = pdir;
       if (!isF) {
         const T g0 = T(2) * hx + fi;
-        dstep = own ? ((g0 > T(0) ? lb : (g0 < T(0) ? ub : x)) - x) : T(0);
+        dstep = (own && !(AS_REGS && mode_as)) ? ((g0 > T(0) ? lb : (g0 < T(0) ? ub : x)) - x) : T(0);
         if (rounds > 0 && own && !inI) dstep = qx_out[myvar] - x;
       }
       xa = own ? tclip(x + alpha * dstep, lb, ub) : T(0);
+      if (AS_REGS && tid == jb) xa = pdir < T(0) ? lb : ub;
       T xc[RM];
 #pragma unroll
       for (int c = 0; c < RM; ++c) xc[c] = __shfl(xa, tj * 8 + c, 64);
@@ -580,10 +621,11 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
         if (tj == r) hxa = s0;
       }
       T pJa = own ? xa * (hxa + fi) : T(0);
-      if (rounds > 0) {
-        // a predicted point: accepted if it lowers the cost, else the iteration is redone as a plain projected-Newton step
+      if (rounds > 0 || (AS_REGS && mode_as)) {
+        // a predicted point: accepted if it lowers the cost, else the solve goes on in active-set mode from x;
+        // an active-set step (exact line search along a Newton direction of a convex quadratic) is always taken
         Ja = wave_sum(pJa);
-        if (!(Ja <= J0)) redo = true;
+        if (!(AS_REGS && mode_as) && !(Ja <= J0)) redo = true;
         break;
       }
       T pdec = own ? (isF ? alpha * (-g * pdir) : g * (x - xa)) : T(0);
@@ -592,9 +634,13 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
       const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
       if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
       alpha *= T(0.25);
+      ++ncrawl;
     }
-    if (redo) {  // (rare) this iteration again from its KKT pass, as a plain projected-Newton step: the free set of that pass is
-      nopredict = true;  // restored by the sweeps (the predicted variables go back in), the gradient is recomputed from hx
+    if (AS_REGS && ncrawl >= 9) enter_as = true;
+    if (redo) {  // this iteration again from its KKT pass (the sweeps put the predicted variables back)
+      nopredict = true;  // as a plain projected-Newton step; a solve that keeps doing this goes on in active-set mode
+      ncrawl += 3;
+      if (AS_REGS && ncrawl >= 9) enter_as = true;
       continue;
     }
     nopredict = false;
@@ -815,7 +861,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     unsigned long long Fmask = ~Imask & allmask;
 
     // active-set prediction rounds inside the iteration: see qp_regs (same rule, the block-wide maximum goes through LDS)
-    const bool predict = !nopredict && a.qp_predict != 0;
+    const bool predict = !nopredict && (a.qp_predict & 1) != 0;
     int rounds = 0;
     bool broke = false, isF = false;
     T pdir = T(0);

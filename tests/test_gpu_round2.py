@@ -533,3 +533,29 @@ def test_full_size_properties(torch_mod, name, steps):
     for k in range(steps):
         small.advance(1, k)
     assert torch.equal(small.X, loop.X[:, :64])
+
+
+# ------------------------------------------------------------------ run-to-run reproducibility
+@pytest.mark.parametrize("name,B,steps", [("cfg2", 1024, 8), ("cfg3", 4096, 8), ("cfg4", 1024, 8), ("cfg5", 256, 4)])
+def test_runs_are_bitwise_reproducible(torch_mod, name, B, steps):
+    """The same workload twice from scratch: states, controls' iteration counts and QP status bit for bit the same (no float
+    atomics, fixed summation orders, no dependence on stale LDS or on which workgroup ran where)."""
+    torch = torch_mod
+    sys.path.insert(0, ROOT)
+    import bench
+
+    c = bench.CONFIGS[name]
+    w = bench.workload_inputs(name, c["L"], c["N"])
+    dev = torch.device("cuda", 0)
+
+    def run():
+        loop = bench.Loop(name, w, B, torch.float64, dev, 0)
+        out = []
+        for k in range(steps):
+            loop.advance(1, k)
+            out.append((loop.X.clone(), loop.m.iters.clone(), loop.m.status.clone()))
+        return out
+
+    a, b = run(), run()
+    for k in range(steps):
+        assert torch.equal(a[k][0], b[k][0]) and torch.equal(a[k][1], b[k][1]) and torch.equal(a[k][2], b[k][2]), k
