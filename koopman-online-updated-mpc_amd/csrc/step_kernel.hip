@@ -61,10 +61,8 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
 template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
   if (threads == 256) {
-#ifndef KMPC_DEV_CFG2_ONLY
     // BASELINE cfg5 sizes (L = 64, N = 50, y = Cx): four waves per trajectory, dimensions fixed at compile time
     if (a.L == 64 && a.N == 50 && a.q == 2 && a.out_kind == OUT_CX) return launch_impl<T, 256, 64, 50, 2>(a, s);
-#endif
     return launch_impl<T, 256, 0, 0, 0>(a, s);
   }
   // (the static instantiations take the output kind from q: y = C x has q <= n <= 4 < 8 <= L rows, y = psi has q = L)
