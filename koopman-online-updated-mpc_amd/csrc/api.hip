@@ -80,6 +80,13 @@ struct kmpc_handle {
 
 static inline long even_up(long v) { return (v + 1) & ~1L; }
 
+// a device temporary that is freed on every return path (the HIPCHK macro returns from the middle of a function)
+struct DevTmp {
+  void* p = nullptr;
+  ~DevTmp() { if (p) (void)hipFree(p); }
+  template <typename U> U* as() const { return static_cast<U*>(p); }
+};
+
 template <typename T>
 struct Impl : kmpc_handle {
   int n, m, L, p, q, N, B, threads;
@@ -262,8 +269,9 @@ struct Impl : kmpc_handle {
       if (!Qh || maxiter < 1) FAIL(-3, "kmpc_terminal_from_dare: bad arguments");
       const int nb = per_traj ? B : 1;
       if (nb == 0) return 0;
-      double* dQl = nullptr;
-      HIPCHK(hipMalloc(&dQl, sizeof(double) * (size_t)L * L));
+      DevTmp tQl, tEye;
+      HIPCHK(hipMalloc(&tQl.p, sizeof(double) * (size_t)L * L));
+      double* const dQl = tQl.as<double>();
       HIPCHK(hipMemcpyAsync(dQl, Qh, sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice, s));
       if (dare_cap < nb) {
         if (dDareP) (void)hipFree(dDareP);
@@ -281,7 +289,8 @@ struct Impl : kmpc_handle {
       if (lift_out) {
         std::vector<double> eye((size_t)L * L, 0.0);
         for (int i = 0; i < L; ++i) eye[(size_t)i * L + i] = 1.0;
-        HIPCHK(hipMalloc(&dEye, sizeof(double) * (size_t)L * L));
+        HIPCHK(hipMalloc(&tEye.p, sizeof(double) * (size_t)L * L));
+        dEye = tEye.as<double>();
         HIPCHK(hipMemcpyAsync(dEye, eye.data(), sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice, s));
         HIPCHK(hipStreamSynchronize(s));  // (the host vector goes out of scope)
       }
@@ -304,8 +313,6 @@ struct Impl : kmpc_handle {
         if (iters_out) HIPCHK(hipMemcpy(iters_out, dDareIt, sizeof(int32_t) * (size_t)nb, hipMemcpyDeviceToHost));
       }
       HIPCHK(hipStreamSynchronize(s));
-      (void)hipFree(dQl);
-      if (dEye) (void)hipFree(dEye);
       wterm_per_traj = per_traj != 0;
       wterm_from_dare = true;
       have_wterm = true;
@@ -353,9 +360,10 @@ struct Impl : kmpc_handle {
           for (int k = 0; k < L; ++k) acc += barX0[(size_t)r * L + k] * barQ0m[(size_t)k * L + c2];
           hC[(size_t)r * L + c2] = (T)acc;
         }
-    T* tmp = nullptr;
+    DevTmp ttmp;
     const size_t tot = hP.size() + hQ.size() + hK.size() + hC.size();
-    HIPCHK(hipMalloc(&tmp, sizeof(T) * tot));
+    HIPCHK(hipMalloc(&ttmp.p, sizeof(T) * tot));
+    T* const tmp = ttmp.as<T>();
     T* tP = tmp; T* tQ = tP + hP.size(); T* tK = tQ + hQ.size(); T* tC = tK + hK.size();
     HIPCHK(hipMemcpyAsync(tP, hP.data(), sizeof(T) * hP.size(), hipMemcpyHostToDevice, s));
     HIPCHK(hipMemcpyAsync(tQ, hQ.data(), sizeof(T) * hQ.size(), hipMemcpyHostToDevice, s));
@@ -368,7 +376,6 @@ struct Impl : kmpc_handle {
     if (dKs) HIPCHK(hipMemcpyAsync(dKs, tK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice, s));
     if (dCs) HIPCHK(hipMemcpyAsync(dCs, tC, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice, s));
     HIPCHK(hipStreamSynchronize(s));
-    (void)hipFree(tmp);
     rls_fresh = false;  // the first online update continues from these accumulators
     return 0;
   }
@@ -392,6 +399,8 @@ struct Impl : kmpc_handle {
     if (cfg.lift_kind == KMPC_LIFT_MLP) {
       a.W1 = dW1; a.b1 = db1; a.Wh[0] = dWh[0]; a.Wh[1] = dWh[1]; a.bh[0] = dbh[0]; a.bh[1] = dbh[1];
       a.Wo = dWo; a.bo = dbo; a.Hp = Hp; a.Lp = Lp;
+      if ((rc = pack_encoder(s))) return rc;
+      a.Whp[0] = dWhp[0]; a.Whp[1] = dWhp[1] ? dWhp[1] : dWhp[0]; a.Wop = dWop; a.KSp = (cfg.hidden + 3) / 4;
       HIPCHK(launch_lift_mlp<T>(a, s));
     } else {
       a.cx = dcx; a.eps = (T)cfg.rbf_eps; a.rbf_matlab = cfg.lift_kind == KMPC_LIFT_RBF_MATLAB;
@@ -817,12 +826,13 @@ struct Impl : kmpc_handle {
     if (!X || !Y || !U || M < 1) FAIL(-3, "kmpc_offline_fit: bad arguments");
     int rc = shared_alloc();
     if (rc) return rc;
-    T *px = nullptr, *py = nullptr, *pinv = nullptr;
-    double* g = nullptr;
-    if (init_rls) HIPCHK(hipMalloc(&pinv, sizeof(T) * (size_t)(p * p + L * L)));
-    HIPCHK(hipMalloc(&px, sizeof(T) * (size_t)L * M));
-    HIPCHK(hipMalloc(&py, sizeof(T) * (size_t)L * M));
-    HIPCHK(hipMalloc(&g, sizeof(double) * (size_t)gram_elems()));
+    DevTmp tpx, tpy, tpinv, tg;
+    if (init_rls) HIPCHK(hipMalloc(&tpinv.p, sizeof(T) * (size_t)(p * p + L * L)));
+    HIPCHK(hipMalloc(&tpx.p, sizeof(T) * (size_t)L * M));
+    HIPCHK(hipMalloc(&tpy.p, sizeof(T) * (size_t)L * M));
+    HIPCHK(hipMalloc(&tg.p, sizeof(double) * (size_t)gram_elems()));
+    T* const px = tpx.as<T>(); T* const py = tpy.as<T>(); T* const pinv = tpinv.as<T>();
+    double* const g = tg.as<double>();
     rc = lift_to((const T*)X, px, M, 1, M, s);           // panels (L x M)
     if (!rc) rc = lift_to((const T*)Y, py, M, 1, M, s);
     if (!rc) {
@@ -851,8 +861,6 @@ struct Impl : kmpc_handle {
       if (e == hipSuccess) e = hipStreamSynchronize(s);
       if (e != hipSuccess) { err = std::string("kmpc_offline_fit: ") + hipGetErrorString(e); rc = -(int)(1000 + (int)e); }
     }
-    (void)hipFree(px); (void)hipFree(py); (void)hipFree(g);
-    if (pinv) (void)hipFree(pinv);
     if (!rc && init_rls) rls_fresh = false;  // the first online update refines this model instead of restarting from K_A = 0
     return rc;
   }

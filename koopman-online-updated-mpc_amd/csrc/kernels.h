@@ -70,6 +70,9 @@ template <typename T> struct LiftArgs {
   const T* Wh[2]; const T* bh[2];
   const T* Wo; const T* bo;
   int Hp, Lp;
+  // the same hidden / output weights as packed MFMA A-fragments [tile][k-step][lane] (pack_afrag_kernel), KSp = ceil(hidden / 4)
+  // k-steps: a fragment is ONE coalesced 512-byte wave load (the row-major form costs 16 segments of 32 bytes per load)
+  const T* Whp[2]; const T* Wop; int KSp;
   // RBF
   const T* cx; T eps; int rbf_matlab;
 };

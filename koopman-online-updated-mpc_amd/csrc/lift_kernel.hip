@@ -12,6 +12,7 @@
 // v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32: A lane l holds A[l&15][l>>4],
 // B lane l holds B[l>>4][l&15]; bias + ReLU are fused on the accumulator registers.
 #include "kernels.h"
+#include <cstdlib>
 
 namespace kmpc {
 
@@ -70,24 +71,32 @@ __global__ __launch_bounds__(LIFT_TPB, 1) void lift_mlp_kernel(const LiftArgs<T>
     for (int e = tid; e < Hp; e += LIFT_TPB) sbh[k * Hp + e] = a.bh[k][e];
   for (int e = tid; e < a.Lp; e += LIFT_TPB) sbo[e] = a.bo[e];
 
-  // ---- this wave's weight rows as A-fragments, resident for the whole kernel
+  // ---- this wave's weight rows as A-fragments, resident for the whole kernel.  Read from the packed form
+  //      [tile][k-step][lane]: every fragment is one coalesced wave load and all of them are in flight together (the
+  //      row-major form made each load 16 segments of 32 bytes: 27 us for B = 4096, nearly all of it this prologue).
+  const int KSp = a.KSp;
   T wh[NHH][MT][KS];
 #pragma unroll
   for (int k = 0; k < NHH; ++k)
 #pragma unroll
     for (int t = 0; t < MT; ++t) {
       const int tile = wave + LIFT_WAVES * t;
-      const int row = 16 * tile + col;  // A[i = lane&15][k = lane>>4]
+      const int tl = tile < mtiles_h ? tile : 0;
 #pragma unroll
-      for (int ks = 0; ks < KS; ++ks)
-        wh[k][t][ks] = (tile < mtiles_h) ? a.Wh[k][(size_t)row * Hp + 4 * ks + kq] : T(0);
+      for (int ks = 0; ks < KS; ++ks) {
+        const T v = a.Whp[k][((size_t)tl * KSp + (ks < KSp ? ks : 0)) * 64 + lane];  // (unconditional loads, clamped indices)
+        wh[k][t][ks] = (tile < mtiles_h && ks < KSp) ? v : T(0);
+      }
     }
   T wo[KS];
   {
     const int tile = wave;  // Lp <= 64: at most one output tile per wave
-    const int row = 16 * tile + col;
+    const int tl = tile < mtiles_o ? tile : 0;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) wo[ks] = (tile < mtiles_o) ? a.Wo[(size_t)row * Hp + 4 * ks + kq] : T(0);
+    for (int ks = 0; ks < KS; ++ks) {
+      const T v = a.Wop[((size_t)tl * KSp + (ks < KSp ? ks : 0)) * 64 + lane];
+      wo[ks] = (tile < mtiles_o && ks < KSp) ? v : T(0);
+    }
   }
   __syncthreads();
 
@@ -159,6 +168,111 @@ __global__ __launch_bounds__(LIFT_TPB, 1) void lift_mlp_kernel(const LiftArgs<T>
 }
 
 // ---------------------------------------------------------------------------------------
+// lift_coop_kernel (float64): the cooperative encoder of the fused roll-out (rollout_kernel.hip) as a kernel of its own.
+// A workgroup of 16 waves lifts 16 trajectories: wave w owns hidden M tile w for the whole K range (two alternating
+// accumulator chains), bias + ReLU on the accumulator registers, results written straight into the next layer's B-fragment
+// layout (one barrier per layer); the weights are packed A-fragments, a fragment is one 512-byte wave load from L2, fetched
+// in two alternating batches of eight k-steps, the first batch of a layer a layer ahead.  The weights-stationary kernel
+// above keeps 180 KB of fragments in registers per workgroup and walks 140 MFMAs per wave one after the other: 27 us for a
+// tile, whatever the batch (6.8 TFLOP/s at B = 4096); here a tile is ~6 us of the same arithmetic spread over 7 + 2 waves.
+// ---------------------------------------------------------------------------------------
+constexpr int LC_ACT = 32 * 64;  // B-fragments of one activation vector set (Hp <= 128)
+constexpr int LC_KB = 8;
+__device__ __forceinline__ void lc_load_afrags(const double* Wp, int KS, int tile, int ks0, int lane, double (&af)[LC_KB]) {
+#pragma unroll
+  for (int i = 0; i < LC_KB; ++i) {
+    const int ks = ks0 + i;
+    af[i] = ks < KS ? Wp[((size_t)tile * KS + ks) * 64 + lane] : 0.0;
+  }
+}
+template <int KS_>
+__global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  double* const sAct0 = reinterpret_cast<double*>(smem_raw);
+  double* const sAct1 = sAct0 + LC_ACT;
+  double* const sXn = sAct1 + LC_ACT;  // 16 x 4
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int B = a.B, n = a.n, L = a.L;
+  const int KS = KS_ > 0 ? KS_ : a.KSp, Hp = a.Hp, MTH = Hp >> 4, MTO = a.Lp >> 4;
+  const int nhh = a.nlayers - 1;
+  const bool hid = wv < MTH, out = wv < MTO;
+  for (int bt = blockIdx.x; bt * 16 < B; bt += gridDim.x) {
+    const int b0 = bt * 16;
+    __syncthreads();  // (the previous tile's activations have been consumed)
+    if (tid < 64) {
+      const int c = tid >> 2, i = tid & 3, b = b0 + c;
+      sXn[tid] = (b < B && i < n) ? a.X[(size_t)i * B + b] : 0.0;
+    }
+    double af[2][LC_KB];
+    if (nhh > 0) { if (hid) lc_load_afrags(a.Whp[0], KS, wv, 0, lane, af[0]); }
+    else if (out) lc_load_afrags(a.Wop, KS, wv, 0, lane, af[0]);
+    // layer 1 (K = n <= 4: one k-step, W1 zero-padded to 4 columns): one MFMA per hidden tile, bias as the accumulator input
+    double a1 = 0.0;
+    d4 c1 = {0.0, 0.0, 0.0, 0.0};
+    if (hid) {
+      a1 = a.W1[4 * (16 * wv + (lane & 15)) + (lane >> 4)];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) c1[r] = a.b1[16 * wv + (lane >> 4) + 4 * r];
+    }
+    __syncthreads();
+    if (hid) {
+      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sXn[4 * (lane & 15) + (lane >> 4)], c1, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wv + (lane >> 4) + 4 * r;
+        sAct0[(row >> 2) * 64 + ((row & 3) << 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
+      }
+    }
+    __syncthreads();
+    for (int h = 0; h <= nhh; ++h) {
+      const bool last = h == nhh;
+      const bool mine = last ? out : hid;
+      const double* act = (h & 1) ? sAct1 : sAct0;
+      double* actn = (h & 1) ? sAct0 : sAct1;
+      const double* Wp = last ? a.Wop : a.Whp[h & 1];
+      const double* bias = last ? a.bo : a.bh[h & 1];
+      d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      if (mine) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc0[r] = bias[16 * wv + (lane >> 4) + 4 * r];
+#pragma unroll
+        for (int bt2 = 0; bt2 < 32 / LC_KB; ++bt2) {
+          const int kb = bt2 * LC_KB;
+          if (kb + LC_KB < KS) lc_load_afrags(Wp, KS, wv, kb + LC_KB, lane, af[(bt2 + 1) & 1]);
+#pragma unroll
+          for (int i = 0; i < LC_KB; i += 2) {
+            if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt2 & 1][i], act[(kb + i) * 64 + lane], acc0, 0, 0, 0);
+            if (kb + i + 1 < KS) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt2 & 1][i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
+          }
+        }
+        const int col = lane & 15;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * wv + (lane >> 4) + 4 * r;
+          const double v = acc0[r] + acc1[r];
+          if (last) { if (row < L && b0 + col < B) a.Psi[(size_t)row * a.ps_l + (size_t)(b0 + col) * a.ps_b] = v; }
+          else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+        }
+      }
+      if (!last) {  // the next layer's first fragments travel across the barrier
+        if (h + 1 < nhh) { if (hid) lc_load_afrags(a.Whp[(h + 1) & 1], KS, wv, 0, lane, af[0]); }
+        else if (out) lc_load_afrags(a.Wop, KS, wv, 0, lane, af[0]);
+        __syncthreads();
+      }
+    }
+  }
+}
+static hipError_t launch_lift_coop(const LiftArgs<double>& a, hipStream_t s) {
+  const size_t lds = (size_t)(2 * LC_ACT + 64) * sizeof(double);
+  const int ntiles = (a.B + 15) / 16;
+  const int grid = ntiles < 2048 ? ntiles : 2048;
+  if (a.KSp == 25 && a.Hp == 112) hipLaunchKernelGGL((lift_coop_kernel<25>), dim3(grid), dim3(1024), lds, s, a);
+  else hipLaunchKernelGGL((lift_coop_kernel<0>), dim3(grid), dim3(1024), lds, s, a);
+  return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------
 // RBF dictionary: one thread per trajectory, centres in LDS
 // ---------------------------------------------------------------------------------------
 template <typename T> __global__ __launch_bounds__(256) void lift_rbf_kernel(const LiftArgs<T> a) {
@@ -214,6 +328,10 @@ template <typename T, int KS, int MT, int NHH> static hipError_t launch_mlp_impl
 template <typename T> hipError_t launch_lift_mlp(const LiftArgs<T>& a, hipStream_t s) {
   if (a.B <= 0) return hipSuccess;
   if (a.n > 4 || a.Lp > 64 || a.Hp > 128 || (a.nlayers != 2 && a.nlayers != 3)) return hipErrorInvalidValue;
+  if constexpr (sizeof(T) == 8) {
+    static const bool stationary = getenv("KMPC_LIFT_STATIONARY") != nullptr;  // measurement aid: the weights-stationary kernel
+    if (!stationary && a.KSp <= 32 && (a.Hp & 15) == 0) return launch_lift_coop(reinterpret_cast<const LiftArgs<double>&>(a), s);
+  }
   const int nhh = a.nlayers - 1;
   if (a.Hp <= 112) {
     if (a.Hp != 112) return hipErrorInvalidValue;

@@ -6,7 +6,7 @@ root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d "$out/trace" -o bench --output-format csv -- python3 "$root/bench.py" > "$out/bench_trace.json" 2> "$out/trace.log"
+rocprofv3 --kernel-trace --stats -d "$out/trace" -o bench --output-format csv -- python3 "$root/bench.py" --cpu-seconds 0 > "$out/bench_trace.json" 2> "$out/trace.log"
 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o bench --output-format csv -- python3 "$root/bench.py" --cpu-seconds 0 > "$out/bench_fetch.json" 2> "$out/fetch.log"
 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o bench --output-format csv -- python3 "$root/bench.py" --cpu-seconds 0 > "$out/bench_write.json" 2> "$out/write.log"
 find "$out" -name "*.csv" | head -20
