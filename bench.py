@@ -52,16 +52,16 @@ CONFIGS = {
     "cfg2": dict(L=20, N=20, B=4096, plant="duffing", lift="mlp", layers=3, output="Cx", lb=-2.0, ub=2.0, P0=1e4, barQ0=100.0,
                  settle=200, text="BASELINE cfg2: Duffing closed loop, 20-dim MLP lift (2-100-100-100-20, random init seed 2024), "
                                   "horizon N=20, box +-2, per-trajectory RLS, RK4 plant on device, parameter switch at step 102"),
-    "cfg3": dict(L=8, N=30, B=16384, plant="vdp", lift="rbf", output="Cx", lb=-2.0, ub=2.0, P0=1e5, barQ0=1e5, settle=60,
+    "cfg3": dict(L=8, N=30, B=16384, plant="vdp", lift="rbf", output="Cx", lb=-2.0, ub=2.0, P0=1e5, barQ0=1e5, settle=150,
                  text="BASELINE cfg3: Van der Pol closed loop as vanderpol_RBF.py (8 thin-plate RBF observables, y = C x, box +-2, "
                       "model continued from the offline Gram = its 'storage' update :434-438), horizon N=30, RK4 plant on device, "
                       "parameter switch at step 102"),
-    "cfg4": dict(L=32, N=40, B=8192, plant="tank", lift="mlp", layers=2, shared=True, settle=40,
+    "cfg4": dict(L=32, N=40, B=8192, plant="tank", lift="mlp", layers=2, shared=True, settle=160,
                  text="BASELINE cfg4: cascaded tanks (Tank_System.m), 32-dim MLP lift (2-100-100-32, random init seed 9), N=40, "
                       "delta-u form with Cy = [0 1], ONE model for all trajectories of all ranks from the all-reduced EDMD Gram "
                       "block (the only collective), plant switch at step 100; 65536 / 8 trajectories per GPU"),
     "cfg5": dict(L=64, N=50, B=32768, plant="duffing", lift="mlp", layers=3, output="Cx", lb=-2.0, ub=2.0, P0=1e4, barQ0=100.0,
-                 settle=60, text="BASELINE cfg5: Duffing with time-varying parameters (switch at step 102), 64-dim MLP lift "
+                 settle=150, text="BASELINE cfg5: Duffing with time-varying parameters (switch at step 102), 64-dim MLP lift "
                                  "(2-100-100-100-64, random init seed 2024), N=50, input box +-2, per-trajectory RLS, fp64; "
                                  "262144 / 8 trajectories per GPU"),
 }
@@ -363,6 +363,9 @@ def main():
     launch_ms = pr["step_ms"] / launches
     lift_ms = pr["lift_ms"] / launches
     bytes_per_traj = mpc.algorithmic_bytes_per_step()
+    if main_loop.shared:  # the shared-model mode drops the per-trajectory state term 2 (p^2 + L p + L^2 + n L)
+        sz, p_, q_ = (8 if args.dtype == "f64" else 4), L + 1, mpc.q
+        bytes_per_traj = sz * ((L + L * p_ + 2 * L + N + 2) + (2 + 1 + q_ * N))
     bytes_per_launch = bytes_per_traj * B * steps_per_launch
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
 

@@ -319,7 +319,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
       sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
       sv.x_next = RBF ? nullptr : sXn + wv * 4;
-      step_body<double, 64, L_, N_, Q_>(a, sv, bk, wsm);
+      step_body<double, 64, L_, N_, Q_, (ro_max_threads<L_, N_, Q_, NW, KS_>() == 1024 && N_ > 24)>(a, sv, bk, wsm);
       if (R.X_log) {
         __threadfence_block();
         if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];

@@ -339,7 +339,7 @@ template <typename T> __device__ __forceinline__ T wave_min_x(T v) {
   return v;
 }
 
-template <typename T, int N_>
+template <typename T, int N_, bool LOWREG = false>
 __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
                                         T* red, T* qx_out, T up, T xw_pre) {
   constexpr int RM = (N_ + 7) / 8;
@@ -363,7 +363,9 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   // hb[r] + 8c) and is re-read for the few mat-vecs with H -- a second register copy costs 2 RM^2 VGPRs of the 128
   // that four waves per SIMD allow, and the fused roll-out spilled because of it.  Longer horizons evaluate more
   // line-search products per solve and keep the register copy (L = 8, N = 30: 209 vs 254 us per step).
-  constexpr bool HREG = N_ > 24;
+  // (LOWREG: instantiations that run four waves per SIMD with a long horizon -- the RBF roll-out of cfg3 -- also re-read H:
+  //  with both copies in registers that kernel spilled 65 dwords and wrote 15 KB of scratch per trajectory-step)
+  constexpr bool HREG = N_ > 24 && !LOWREG;
   T Tm[RM][RM], Hm[HREG ? RM : 1][HREG ? RM : 1];
   int hb[RM];    // LDS element offset of H(ti+8r, tj), or -1 beyond N
   bool cok[RM];  // column tj+8c exists
@@ -1253,7 +1255,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
 // 0: taken from the arguments at run time (generic fallback, same source).
 // Four waves per SIMD (<= 128 VGPRs) for the small static configurations: BASELINE cfg2 puts exactly 4096
 // trajectories = 4 waves per SIMD on the chip, so one register too many costs a whole second round.
-template <typename T, int TPB, int L_, int N_, int Q_>
+template <typename T, int TPB, int L_, int N_, int Q_, bool LOWREG = false>
 __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>& sv, const int b, T* const sm) {
   const int tid = local_tid<TPB>();
   // y = C x has q = rows of C <= n < L outputs, y = psi has q = L: with static dimensions the output kind is known
@@ -1892,7 +1894,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
       }
       // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
-      if (qp_regs<T, N_>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
+      if (qp_regs<T, N_, LOWREG>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
         block_sync<TPB>();
         if constexpr (step_tableau_in_lds<TPB, N_, L_>()) {
           qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
