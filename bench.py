@@ -269,6 +269,10 @@ def main():
                     help="untimed GPU activity on a scratch copy of the workload before the warm-up, so that the "
                          "clocks have left their idle state when the W warm-up steps start")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold-start and post-reset measurements")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal of the "
+                         "multi-rank code path, e.g. with --same-device on a one-GPU box; not a scaling measurement)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal with --backend gloo)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -292,13 +296,18 @@ def main():
         if cpu is not None:
             print("cpu_baseline (no GPU here, nothing else measured): %s" % json.dumps(cpu), file=sys.stderr)
         sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
+    if args.same_device:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
 
     from koopmpc import max_over_ranks
 
@@ -390,7 +399,7 @@ def main():
         del fresh
 
     if dist is not None:
-        flag = torch.tensor([worst_status, 0 if x_ok else 1], device=dev)
+        flag = torch.tensor([worst_status, 0 if x_ok else 1], device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(flag, op=dist.ReduceOp.MAX)
         worst_status, x_ok = int(flag[0].item()), int(flag[1].item()) == 0
 
@@ -431,6 +440,8 @@ def main():
                             "warm-up; arithmetic in %s%s" % (c["text"], B, world, settle, args.dtype,
                                                             " (the config line names fp32; the reference computes in float64 and the 1e-6 bar on u needs it, DESIGN.md 4.1)" if name == "cfg2" else ""),
                 "global_batch": total,
+                **({"rehearsal": "ranks share cuda:0 / gloo collectives: exercises the multi-rank code path, NOT a scaling measurement"}
+                   if (args.same_device or (world > 1 and args.backend != "nccl")) else {}),
                 "parallelism": ("trajectory-sharded x%d, one RCCL all-reduce of the %d-element Gram block per step" % (world, (2 * L + 3) * (L + 1))) if main_loop.shared
                                else "trajectory-sharded x%d, no collective on the step path" % world,
                 "qp": "exact box-QP (projected Newton), %s; mean Newton solves/step %.2f, worst trajectory total %d"

@@ -406,7 +406,12 @@ class KoopmanMPC:
 
         delta = self.shared_local_gram(x)
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(delta, op=dist.ReduceOp.SUM)
+            if dist.get_backend() == "gloo":  # (rehearsals of the multi-rank path on CPU-side collectives: gloo reduces host tensors)
+                hd = delta.cpu()
+                dist.all_reduce(hd, op=dist.ReduceOp.SUM)
+                delta.copy_(hd)
+            else:
+                dist.all_reduce(delta, op=dist.ReduceOp.SUM)  # RCCL over xGMI: the one collective of the path
         return self.shared_solve(delta, r)
 
     def shared_model(self):

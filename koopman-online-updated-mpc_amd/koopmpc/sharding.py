@@ -22,6 +22,8 @@ def max_over_ranks(value, device=None):
 
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = None  # (gloo reduces host tensors)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
