@@ -87,6 +87,7 @@ if fused:
     if t[:, 25].any():
         print("  lift timeline since the group was formed (mean us): layer 1 done %.2f, synced %.2f | hidden 1 done %.2f, synced %.2f | rest (summed) done %.2f synced %.2f"
               % tuple((t[:, i] / 100.0 / steps).mean() for i in (24, 25, 26, 27, 28, 29)))
+    print("  body us/step by wave index in the workgroup (age order):", " ".join("%.1f" % v for v in sb.reshape(-1, G).mean(0)))
     fin = (t[:, 18] - t[:, 19].min()) / 100.0
     order = np.argsort(fin)
     for lo, hi in ((0, 0.25), (0.25, 0.5), (0.5, 0.75), (0.75, 1.0)):
