@@ -512,6 +512,40 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     while (true) {
       broke = false;
       for (int pass = 0; pass < 2; ++pass) {
+        // The build of a solve's first tableau -- nothing swept in yet, the free set goes in -- is what every step pays
+        // (N sweeps; set changes later in the solve are one sweep each), so it has its own straight-line code: the
+        // direction of the sweep is known (no sign logic, no per-sweep update of the set mask) and the pivots are checked
+        // together afterwards; a non-positive pivot leaves garbage behind, which the rebuild below discards exactly as it
+        // discards the partial tableau of the general pass.  Same sweeps in the same order: bitwise the same tableau.
+        if (!t0 && pass == 0 && Smask == 0ull) {
+          const unsigned flo = (unsigned)Fmask, fhi = (unsigned)(Fmask >> 32);
+          bool pos = true;
+#pragma unroll
+          for (int kt = 0; kt < 8; ++kt) {
+#pragma unroll
+            for (int kr = 0; kr < RM; ++kr) {
+              if (kt + 8 * kr < N_) {
+                const int kl = kt * 8 + kr;
+                if (((kl < 32 ? flo >> kl : fhi >> (kl - 32)) & 1u) != 0u) {
+                  const T d = lane_bcast(Tm[kr][kr], kt * 9);
+                  pos = pos && (d > T(0));
+                  sweep_regs_at<T, N_>(Tm, kr, kt, false, d, ti, tj);
+                }
+              }
+            }
+          }
+          if (pos) {
+            Smask = Fmask;
+            break;
+          }
+          broke = true;
+          ++refresh;
+#pragma unroll
+          for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
+          continue;  // pass 1: the general sweeps, which drop a variable whose pivot fails
+        }
         const unsigned long long diff = Smask ^ Fmask;
         // One straight-line block per variable, in owner-lane order ((k&7)*8 + (k>>3), the order of the bit scan):
         // with k a compile-time constant the block index, the pivot lane and the owner tests fold, and the tableau
