@@ -111,6 +111,15 @@ template <int TPB, int N_, int L_> constexpr bool step_tableau_in_lds() {
   return !(N_ > 0 && L_ > 0 && ((TPB == 64 && N_ <= 40) || (TPB == 256 && N_ <= 64)) && tableau_saves_lds(N_, L_));
 }
 
+// Four-wave trajectories with static dimensions (cfg5 sizes: L = 64, N = 50) keep inv_K_G, [A B], bar_Q and H in ONE LDS
+// region, one after the other (bar_Q / C update first, then inv_K_G, then [A B], whose rows go to registers for the
+// recursion, then H): 74 -> 41 KB per trajectory at L = 64, three workgroups on a CU instead of two (measured: two instead
+// of one is 1.76 x).  Region 2 only holds C.
+template <int TPB, int L_, int N_, int Q_> constexpr bool step_one_region() {
+  return TPB == 256 && L_ > 0 && N_ > 0 && Q_ > 0 && Q_ != L_ && Q_ <= 2 && (L_ & 3) == 0 && L_ <= 64 &&
+         ((L_ + 1) * (L_ + 1) + TPB - 1) / TPB <= 17;
+}
+
 template <typename T> struct Tol;
 template <> struct Tol<double> {
   static __device__ __forceinline__ double kkt() { return 1e-9; }
@@ -1297,10 +1306,11 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   const bool out_cx = (Q_ > 0 && L_ > 0) ? (Q_ != L_) : (a.out_kind == OUT_CX);
   const int n = a.n, L = L_ ? L_ : a.L, p = L + 1, q = Q_ ? Q_ : a.q, N = N_ ? N_ : a.N, B = a.B;
 
+  constexpr bool ONE_REGION = step_one_region<TPB, L_, N_, Q_>();
   T* const sX = sm;            // P / bar_Q / H
   T* const sY = sX + a.r1;     // K, C / elimination matrix
-  T* const sK = sY;
-  T* const sC = sY + L * p;
+  T* const sK = ONE_REGION ? sX : sY;  // (one region: [A B] follows inv_K_G in region 1, region 2 is C alone)
+  T* const sC = ONE_REGION ? sY : sY + L * p;
   T* const sH = sX;
   T* const sM = sY;  // LDS solver; the register solvers' fall-back works in global scratch instead (computed there)
   T* const vec = sY + a.r2;
@@ -1344,6 +1354,124 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   // =====================================================================================
   // phase 1: recursive least squares (gain form; algebraically K_A inv_K_G of the reference)
   // =====================================================================================
+  if constexpr (ONE_REGION) {
+   if (sv.phases & PH_RLS) {
+    // The same arithmetic as the general block below, element for element, in another ORDER: the output-map update
+    // (bar_Q, C: it needs neither inv_K_G nor [A B]) comes first, then inv_K_G, then [A B] -- each takes the region
+    // over from its predecessor.  Every HBM request is issued before the first wait, in the order of use.
+    const T* Pg = a.P + (size_t)b * a.strideP;
+    T* Kg = a.K + (size_t)b * a.strideK;
+    const T* Qg = a.Qb + (size_t)b * a.strideQ;
+    T* Cg = a.C + (size_t)b * a.strideC;
+    constexpr int PP_ = (L_ + 1) * (L_ + 1), LP_ = L_ * (L_ + 1), LL_ = L_ * L_;
+    constexpr int NPR = (PP_ + TPB - 1) / TPB, NKR = (LP_ + TPB - 1) / TPB, NQR = (LL_ + TPB - 1) / TPB;
+    const int il = tid < L ? tid : L - 1, in = tid < n ? tid : n - 1;
+    const T zp = sv.psi_in_regs ? sv.psi_prev_v : sv.psi_prev[il * a.pp_sl + b * a.pp_sb];
+    const T yp = sv.psi_in_regs ? sv.psi_now_v : sv.psi_now[il * a.pn_sl + b * a.pn_sb];
+    const T xp = a.x_now[(size_t)in * B + b];
+    T qr[NQR], cr[2], pr[NPR], kr[NKR];
+#pragma unroll
+    for (int i = 0; i < NQR; ++i) { const int e = tid + i * TPB; qr[i] = Qg[e < LL_ ? e : LL_ - 1]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int e = tid + i * TPB; cr[i] = Cg[e < n * L ? e : 0]; }
+#pragma unroll
+    for (int i = 0; i < NPR; ++i) { const int e = tid + i * TPB; pr[i] = Pg[e < PP_ ? e : PP_ - 1]; }
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) { const int e = tid + i * TPB; kr[i] = Kg[e < LP_ ? e : LP_ - 1]; }
+    if (tid < L) { sz[tid] = zp; sy[tid] = yp; }
+    if (tid == 0) sz[L] = up;
+    if (tid < n) sx[tid] = xp;
+    const bool fu = sv.first_update != 0;
+    // ---- C = bar_X bar_Q, target x_{k+1}, regressor psi(x_k)      duffing.py:943-953
+#pragma unroll
+    for (int i = 0; i < NQR; ++i) { const int e = tid + i * TPB; if (e < LL_) sX[e] = qr[i]; }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { const int e = tid + i * TPB; if (e < n * L) sC[e] = fu ? T(0) : cr[i]; }
+    block_sync<TPB>();
+    KTRACE(1);
+    for (int i = tid; i < L; i += TPB) {
+      T acc = T(0);
+#pragma unroll
+      for (int j = 0; j < L; ++j) acc += sX[j * L + i] * sz[j];
+      sPz[i] = acc;
+    }
+    for (int r = tid; r < n; r += TPB) {
+      T acc = sx[r];
+      for (int j = 0; j < L; ++j) acc -= sC[r * L + j] * sz[j];
+      sE[r] = acc;
+    }
+    block_sync<TPB>();
+    {
+      T part2 = T(0);
+      for (int i = tid; i < L; i += TPB) part2 += sz[i] * sPz[i];
+      const T dc = T(1) + block_sum<T, TPB>(part2, red);
+      const T dcinv = T(1) / dc;
+      T* Qw = a.Qb + (size_t)b * a.strideQ;
+      for_strided<TPB, LL_>(tid, L * L, [&](int e, int) {
+        const int i = e / L, j = e - i * L;
+        Qw[e] = sX[e] - (sPz[i] * sPz[j]) * dcinv;
+      });
+      for (int e = tid; e < n * L; e += TPB) {
+        const int r = e / L, j = e - r * L;
+        const T v = (a.c_skip_first && fu) ? T(0) : sC[e] + sE[r] * (sPz[j] * dcinv);
+        sC[e] = v;
+        Cg[e] = v;
+      }
+    }
+    block_sync<TPB>();  // everyone is done with bar_Q in the region and with sPz / sE
+    KTRACE(2);
+    // ---- inv_K_G                                                     duffing.py:931-932
+#pragma unroll
+    for (int i = 0; i < NPR; ++i) { const int e = tid + i * TPB; if (e < PP_) sX[e] = pr[i]; }
+    block_sync<TPB>();
+    for (int i = tid; i < p; i += TPB) {
+      T acc = T(0);
+#pragma unroll
+      for (int j = 0; j < p; ++j) acc += sX[j * p + i] * sz[j];
+      sPz[i] = acc;
+    }
+    block_sync<TPB>();
+    T part = T(0);
+    for (int i = tid; i < p; i += TPB) part += sz[i] * sPz[i];
+    const T d = a.lam + block_sum<T, TPB>(part, red);
+    const T dinv = T(1) / d;
+    const T linv = T(1) / a.lam;
+    T* Pw = a.P + (size_t)b * a.strideP;
+    for_strided<TPB, PP_>(tid, p * p, [&](int e, int) {
+      const int i = e / p, j = e - i * p;
+      Pw[e] = (sX[e] - (sPz[i] * sPz[j]) * dinv) * linv;
+    });
+    block_sync<TPB>();  // everyone is done with inv_K_G in the region
+    KTRACE(3);
+    // ---- [A B]: innovation y - K z and K <- (K - K z g') / lam + y g'   (Koopman_update.m:270-274; see the general block)
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) { const int e = tid + i * TPB; if (e < LP_) sK[e] = fu ? T(0) : kr[i]; }
+    block_sync<TPB>();
+    for (int r = tid; r < L; r += TPB) {
+      T acc = sy[r];
+#pragma unroll
+      for (int j = 0; j < p; ++j) acc -= sK[r * p + j] * sz[j];
+      sE[r] = acc * linv + sy[r] * (T(1) - linv);
+    }
+    block_sync<TPB>();
+    for_strided<TPB, LP_>(tid, L * p, [&](int e, int) {
+      const int r = e / p, j = e - r * p;
+      const T v = tfma(sE[r], sPz[j] * dinv, sK[e] * linv);
+      sK[e] = v;
+      Kg[e] = v;
+    });
+    block_sync<TPB>();
+    KTRACE(4);
+   } else if (sv.phases & PH_CONDENSE) {
+    const T* Kg = a.K + (size_t)b * a.strideK;
+    for (int e = tid; e < L * p; e += TPB) sK[e] = Kg[e];
+    const T* Cg = a.C + (size_t)b * a.strideC;
+    for (int e = tid; e < n * L; e += TPB) sC[e] = Cg[e];
+    if (sv.psi_in_regs) { if (tid < L) sy[tid] = sv.psi_now_v; }
+    else for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
+    block_sync<TPB>();
+   }
+  } else
   if (sv.phases & PH_RLS) {
     const T* Pg = a.P + (size_t)b * a.strideP;
     T* Kg = a.K + (size_t)b * a.strideK;
@@ -1659,6 +1787,44 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         block_sync<TPB>();
         cur ^= 1;
       }
+    } else if constexpr (ONE_REGION) {
+      // Four-wave trajectories, y = C x (cfg5 sizes, L = 64): threads 0-127 run the v-chain, 128-255 the w-chain; a PAIR of
+      // threads keeps one row of A in registers for the whole recursion, half a row each (32 of the 64 columns: every
+      // thread multiplies, and a row costs 64 registers instead of the 128 of one-row-per-thread, which left two of the
+      // four waves idle); the two output rows of C_o are one multiply per thread and a wave sum: wave w = (chain, row).
+      constexpr int HL = L_ / 2;
+      const int chain = tid >> 7, rr = (tid & 127) >> 1, hh = tid & 1;
+      const int ln = tid & 63, corow = (tid >> 6) & 1;
+      const bool isA = rr < L;
+      T row[HL];
+#pragma unroll
+      for (int l = 0; l < HL; ++l) row[l] = isA ? sK[rr * p + hh * HL + l] : T(0);
+      const T co = (ln < L && corow < q) ? sC[(a.cy0 + corow) * L + ln] : T(0);
+      const T bs = (a.du_mode && isA) ? sK[rr * p + L] * (chain ? up : T(1)) : T(0);
+      typedef T T2 __attribute__((ext_vector_type(2)));
+      int cur = 0;
+      for (int j = 0; j <= N; ++j) {
+        T* const vb = (chain ? sW : sV) + cur * L;
+        const T2* v2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(vb + hh * HL, 2 * sizeof(T)));
+        T ac4[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+        for (int l = 0; l < HL / 2; ++l) {
+          const T2 x2 = v2[l];
+          ac4[(2 * l) & 3] += row[2 * l] * x2.x;
+          ac4[(2 * l + 1) & 3] += row[2 * l + 1] * x2.y;
+        }
+        T acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
+        acc += dpp_q(acc, 0);  // the other half of the row (the neighbouring lane)
+        acc += isA ? bs : T(0);
+        const T gco = wave_sum(co * vb[ln < L ? ln : 0]);
+        if (hh == 0 && isA && j < N) (chain ? sW : sV)[(cur ^ 1) * L + rr] = acc;  // v_{j+1} / w_{j+1}
+        if (ln == 0 && corow < q) {
+          if (chain == 0) { if (j < N) sG[j * q + corow] = gco; }       // g_j = Co v_j
+          else if (j >= 1) sEr[(j - 1) * q + corow] += gco;             // e_j = Co w_j - r_{j-1}
+        }
+        block_sync<TPB>();
+        cur ^= 1;
+      }
     } else if constexpr (L_ > 0 && TPB == 256 && (L_ + Q_ <= 128) && ((L_ & 1) == 0)) {
       // Static path for four-wave trajectories (cfg5 sizes, L = 64): waves 0-1 run the v-chain, waves 2-3 the w-chain;
       // thread t of a half keeps row t of [A; Co] in REGISTERS for the whole recursion (the generic path re-reads the
@@ -1947,7 +2113,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       static_assert(L_ == 0 || 2 * (L_ + 1) + 6 * L_ + 1 + 2 * N_ * Q_ >= 3 * N_ + 324, "qp_regs256 workspace");
       if (qp_regs256<T, N_>(sH, sf, a, sv, b, red, qg + N, qx, up)) {
         block_sync<TPB>();
-        if constexpr (step_tableau_in_lds<TPB, N_, L_>()) {
+        if constexpr (step_tableau_in_lds<TPB, N_, L_>() && !ONE_REGION) {
           qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
         } else {
           // no tableau region in LDS: H moves to this trajectory's global scratch block (read-only from here on,

@@ -25,7 +25,8 @@ size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2,
 
 // one workgroup of TPB threads per trajectory
 template <typename T, int TPB, int L_, int N_, int Q_>
-__global__ __launch_bounds__(TPB, (TPB == 256 ? 2 : 1)) void step_kernel(const StepArgs<T> a) {  // (four-wave trajectories: two workgroups per CU fit the LDS, so at most 256 registers)
+// (four-wave trajectories: two workgroups per CU fit the LDS, so at most 256 registers; three with one LDS region: 168)
+__global__ __launch_bounds__(TPB, (TPB == 256 ? (step_one_region<TPB, L_, N_, Q_>() ? 3 : 2) : 1)) void step_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0)};
   step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
@@ -36,9 +37,14 @@ __global__ __launch_bounds__(TPB, (TPB == 256 ? 2 : 1)) void step_kernel(const S
 // ---------------------------------------------------------------------------------------
 template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_impl(const StepArgs<T>& a, hipStream_t s) {
   StepArgs<T> k = a;
-  constexpr bool TAB = step_tableau_in_lds<TPB, N_, L_>();
+  constexpr bool TAB = step_tableau_in_lds<TPB, N_, L_>() && !step_one_region<TPB, L_, N_, Q_>();  // (one region: the fall-back tableau works in global scratch)
   if (!TAB && !a.qp_scratch && (a.phases & PH_QP)) return hipErrorInvalidValue;
   size_t lds = step_lds_bytes(a.n, a.L, a.q, a.N, sizeof(T), &k.r1, &k.r2, TAB);
+  if constexpr (step_one_region<TPB, L_, N_, Q_>()) {  // region 2 is C alone ([A B] follows inv_K_G in region 1)
+    const int r2 = (a.n * a.L + 1) & ~1;
+    lds -= (size_t)(k.r2 - r2) * sizeof(T);
+    k.r2 = r2;
+  }
   // a solve-only launch of a register solver (kmpc_qp_solve, the shared-model step) touches neither the model block
   // nor a tableau region: without it more trajectories fit on a CU (cfg4 sizes: 25 -> 16 KB each)
   if (!TAB && (a.phases & (PH_RLS | PH_CONDENSE)) == 0) {
