@@ -34,6 +34,9 @@ static constexpr int vec_elems(int n, int L, int q, int N) {
   return imax(setA, setB) + N /*sf*/ + 16 /*reduction scratch*/;
 }
 
+static constexpr int vec_elems_one_region(int n, int L, int q, int N) {  // (step_one_region kernels: see the pointer map in step_body)
+  return 5 * L + n + 2 * N * q + N + 16;
+}
 static constexpr int step_region1(int L, int N) { return (imax(imax((L + 1) * (L + 1), L * L), N * N) + 1) & ~1; }
 // lds_tableau: the region also has to hold the N x N tableau of the LDS solver (run-time dimensions).  The register
 // solvers (static N) only need that tableau in their rare fall-back, which then works in a per-trajectory global
@@ -800,7 +803,9 @@ __device__ __forceinline__ void sweep_regs256(T (&Tm)[(N_ + 15) / 16][(N_ + 15) 
     for (int c = 0; c < RM; ++c) Tm[r][c] -= ct[r] * rt[c];
 }
 
-template <typename T, int N_>
+// HREG: H also in registers (two workgroups per CU, 256 registers); false: re-read from LDS for the mat-vecs with H, where it
+// stays intact for the whole solve (the one-region kernels: more workgroups per CU, fewer registers each)
+template <typename T, int N_, bool HREG = true>
 __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
                                            T* red, T* work, T* qx_out, T up) {
   constexpr int RM = (N_ + 15) / 16;
@@ -822,19 +827,24 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   }
   const T c0 = tclip(T(0), lb, ub);
 
-  T Tm[RM][RM], Hm[RM][RM];
+  T Tm[RM][RM], Hm[HREG ? RM : 1][HREG ? RM : 1];
+  auto Hel = [&](int r, int c) -> T {
+    if constexpr (HREG) return Hm[r][c];
+    else { const int i = ti + 16 * r, j = tj + 16 * c; return (i < N_ && j < N_) ? sH[i * N_ + j] : T(0); }
+  };
 #pragma unroll
   for (int r = 0; r < RM; ++r)
 #pragma unroll
     for (int c = 0; c < RM; ++c) {
       const int i = ti + 16 * r, j = tj + 16 * c;
-      Hm[r][c] = (i < N_ && j < N_) ? sH[i * N_ + j] : T(0);
-      Tm[r][c] = T(2) * Hm[r][c];
+      const T h = (i < N_ && j < N_) ? sH[i * N_ + j] : T(0);
+      if constexpr (HREG) Hm[r][c] = h;
+      Tm[r][c] = T(2) * h;
     }
   const T fi = own ? sf[myvar] : T(0);
   if (tid < 64) qv[tid] = T(0);  // (entries beyond N stay zero)
   // y_i = sum_j M_ij v_j for the owner of variable i (v given by the owners)
-  auto matvec = [&](const T (&M)[RM][RM], T vin) -> T {
+  auto matvec = [&](auto&& Mel, T vin) -> T {
     __syncthreads();  // the previous vector has been read
     if (own) qv[myvar] = vin;
     __syncthreads();
@@ -846,26 +856,27 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     for (int r = 0; r < RM; ++r) {
       T s0 = T(0);
 #pragma unroll
-      for (int c = 0; c < RM; ++c) s0 += M[r][c] * xc[c];
+      for (int c = 0; c < RM; ++c) s0 += Mel(r, c) * xc[c];
       s0 = allreduce16(s0);
       if (tj == r) out = s0;
     }
     return own ? out : T(0);
   };
+  auto Tel = [&](int r, int c) -> T { return Tm[r][c]; };
   T ra = T(0);
   {
 #pragma unroll
     for (int r = 0; r < RM; ++r) {
       T s1 = T(0);
 #pragma unroll
-      for (int c = 0; c < RM; ++c) s1 += tabs(Hm[r][c]);
+      for (int c = 0; c < RM; ++c) s1 += tabs(Hel(r, c));
       s1 = allreduce16(s1);
       if (tj == r) ra = s1;
     }
   }
   const T gs = tabs(fi) + T(2) * ra * xmaxb;
   T x = own ? (a.x_warm ? tclip(a.x_warm[(size_t)myvar * a.B + b], lb, ub) : c0) : T(0);
-  T hx = matvec(Hm, x);
+  T hx = matvec(Hel, x);
   T J0 = block_sum<T, 256>(own ? x * (hx + fi) : T(0), red);
   unsigned long long Smask = 0ull;
   int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0, rtot = 0;
@@ -948,14 +959,14 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
 #pragma unroll
         for (int r = 0; r < RM; ++r)
 #pragma unroll
-          for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hm[r][c];
+          for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
         Smask = 0ull;
       }
       Fmask = Smask;
 
       // Newton direction on F
       isF = own && ((Fmask >> myvar) & 1ull);
-      pdir = matvec(Tm, isF ? g : T(0));
+      pdir = matvec(Tel, isF ? g : T(0));
       if (!predict || broke || rounds >= N_) break;
       // the free variable whose Newton value lies furthest outside the box is fixed at that bound
       const T cand = x + pdir;
@@ -994,7 +1005,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
         if (rounds > 0 && own && !inI) dstep = qx_out[myvar] - x;
       }
       xa = own ? tclip(x + alpha * dstep, lb, ub) : T(0);
-      hxa = matvec(Hm, xa);
+      hxa = matvec(Hel, xa);
       T pJa = own ? xa * (hxa + fi) : T(0);
       if (rounds > 0) {
         Ja = block_sum<T, 256>(pJa, red);
@@ -1310,7 +1321,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   T* const sX = sm;            // P / bar_Q / H
   T* const sY = sX + a.r1;     // K, C / elimination matrix
   T* const sK = ONE_REGION ? sX : sY;  // (one region: [A B] follows inv_K_G in region 1, region 2 is C alone)
-  T* const sC = ONE_REGION ? sY : sY + L * p;
+  T* const sC_y = ONE_REGION ? sY : sY + L * p;
   T* const sH = sX;
   T* const sM = sY;  // LDS solver; the register solvers' fall-back works in global scratch instead (computed there)
   T* const vec = sY + a.r2;
@@ -1318,15 +1329,20 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   T* const sf = red + 16;      // N   (lives condense -> QP)
   T* const va = sf + N;        // aliased vector sets
   // set A (RLS + condense)
-  T* const sz = va;            // p
-  T* const sPz = sz + p;       // p
-  T* const sy = sPz + p;       // L   psi_now
-  T* const sE = sy + L;        // L
-  T* const sV = sE + L;        // 2L
+  // (one region: the vectors of the update -- z, Pz, the innovation -- are dead before the recursion's v and w exist, and
+  //  lie where those will: 194 doubles less at L = 64, the margin the fourth workgroup of a CU needs)
+  T* const sz = ONE_REGION ? va + L : va;   // p
+  T* const sPz = sz + p;                     // p
+  T* const sy = ONE_REGION ? va : sPz + p;   // L   psi_now
+  T* const sE = ONE_REGION ? sPz + p : sy + L;  // L
+  T* const sV = ONE_REGION ? va + L : sE + L;   // 2L
   T* const sW = sV + 2 * L;    // 2L
   T* const sx = sW + 2 * L;    // n
   T* const sG = sx + n;        // N*q
   T* const sEr = sG + N * q;   // N*q
+  // (one region, r2 == 0: C waits in the place of g_0 .. g_{N-1}, which the recursion writes only after it has taken its
+  //  rows of C_o into registers -- 128 doubles that decide between three and four workgroups per CU at L = 64)
+  T* const sC = (ONE_REGION && a.r2 == 0) ? sG : sC_y;
   // set B (QP)
   T* const qx = va;
   T* const qxa = qx + N;
@@ -1801,6 +1817,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       for (int l = 0; l < HL; ++l) row[l] = isA ? sK[rr * p + hh * HL + l] : T(0);
       const T co = (ln < L && corow < q) ? sC[(a.cy0 + corow) * L + ln] : T(0);
       const T bs = (a.du_mode && isA) ? sK[rr * p + L] * (chain ? up : T(1)) : T(0);
+      block_sync<TPB>();  // (C may sit where g is written from now on)
       typedef T T2 __attribute__((ext_vector_type(2)));
       int cur = 0;
       for (int j = 0; j <= N; ++j) {
@@ -2111,7 +2128,8 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     } else if constexpr (N_ > 0 && N_ <= 64 && TPB == 256) {
       // four-wave register tableau; the workspace is the vector area behind qx / qxa / qg (dead set A of the phase)
       static_assert(L_ == 0 || 2 * (L_ + 1) + 6 * L_ + 1 + 2 * N_ * Q_ >= 3 * N_ + 324, "qp_regs256 workspace");
-      if (qp_regs256<T, N_>(sH, sf, a, sv, b, red, qg + N, qx, up)) {
+      static_assert(!ONE_REGION || (5 * L_ + 1 + 2 * N_ * Q_ >= 3 * N_ + 324 && 2 * (L_ + 1) + L_ <= 4 * L_), "qp_regs256 workspace / update vectors (one region)");
+      if (qp_regs256<T, N_, !ONE_REGION>(sH, sf, a, sv, b, red, qg + N, qx, up)) {
         block_sync<TPB>();
         if constexpr (step_tableau_in_lds<TPB, N_, L_>() && !ONE_REGION) {
           qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);

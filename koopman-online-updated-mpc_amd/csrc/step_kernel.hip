@@ -25,8 +25,9 @@ size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2,
 
 // one workgroup of TPB threads per trajectory
 template <typename T, int TPB, int L_, int N_, int Q_>
-// (four-wave trajectories: two workgroups per CU fit the LDS, so at most 256 registers; three with one LDS region: 168)
-__global__ __launch_bounds__(TPB, (TPB == 256 ? (step_one_region<TPB, L_, N_, Q_>() ? 3 : 2) : 1)) void step_kernel(const StepArgs<T> a) {
+// (four-wave trajectories: two workgroups per CU fit the LDS, so at most 256 registers; FOUR with one LDS region and H re-read
+//  from LDS in the solve: 128 registers, 38.5 KB)
+__global__ __launch_bounds__(TPB, (TPB == 256 ? (step_one_region<TPB, L_, N_, Q_>() ? 4 : 2) : 1)) void step_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0)};
   step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
@@ -41,9 +42,9 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
   if (!TAB && !a.qp_scratch && (a.phases & PH_QP)) return hipErrorInvalidValue;
   size_t lds = step_lds_bytes(a.n, a.L, a.q, a.N, sizeof(T), &k.r1, &k.r2, TAB);
   if constexpr (step_one_region<TPB, L_, N_, Q_>()) {  // region 2 is C alone ([A B] follows inv_K_G in region 1)
-    const int r2 = (a.n * a.L + 1) & ~1;
-    lds -= (size_t)(k.r2 - r2) * sizeof(T);
+    const int r2 = a.n * a.L <= a.N * a.q ? 0 : (a.n * a.L + 1) & ~1;  // (C fits where g_0 .. g_{N-1} go: no region 2 at all)
     k.r2 = r2;
+    lds = ((size_t)k.r1 + k.r2 + vec_elems_one_region(a.n, a.L, a.q, a.N)) * sizeof(T);
   }
   // a solve-only launch of a register solver (kmpc_qp_solve, the shared-model step) touches neither the model block
   // nor a tableau region: without it more trajectories fit on a CU (cfg4 sizes: 25 -> 16 KB each)
