@@ -1,0 +1,38 @@
+"""Dev tool: profiles/traffic.json entries from the PMC passes of tools/profile_config.sh.
+    python tools/traffic_from_profiles.py <config> <gpurun_out/prof_dir> <profiles/summary name>
+HBM bytes per trajectory-step of the dominant kernel = (FETCH_SIZE x 1.593 + WRITE_SIZE) KiB per launch / (trajectories x steps
+per launch); 1.593 is round 1's own-pattern calibration of FETCH_SIZE (8-byte-per-lane coalesced reads report 0.628 of the
+bytes, profiles/r1_traffic.json); the counters are the mean over the last third of the kernel's launches (summary.txt)."""
+import json, os, re, sys
+cfg, d, summary_name = sys.argv[1], sys.argv[2], sys.argv[3]
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+def bench_line(name):
+    return json.loads([l for l in open(os.path.join(d, "bench_%s.json" % name)) if l.startswith("{")][-1])
+bf, bw = bench_line("fetch"), bench_line("write")
+fused = "rollout_kernel" in bf["roofline"]["kernel"]
+dom = "rollout_kernel" if fused else "step_kernel"
+vals, cur, sec = {}, None, None
+for l in open(os.path.join(d, "summary.txt")):
+    if l.startswith("== "):
+        sec = l.split()[1]
+    elif l.startswith("  ") and not l.startswith("      "):
+        cur = l.strip()
+    elif l.startswith("      ") and cur and cur.startswith(dom):
+        p = l.split()
+        vals[(sec, p[0])] = float(p[1])
+B = int(re.search(r"(\d+) trajectories per GPU x", bf["config"]["workload"]).group(1))
+L, N = [int(x) for x in re.search(r"N=(\d+), (\d+)-dim", bf["metric"]).groups()][::-1]
+units = B * bf["roofline"]["steps_per_launch"]
+fetch_raw = vals[("fetch", "FETCH_SIZE")] * 1024.0 / units
+write = vals[("write", "WRITE_SIZE")] * 1024.0 / (B * bw["roofline"]["steps_per_launch"])
+entry = {"L": L, "N": N, "B": B, "bytes_per_trajectory_step": fetch_raw * 1.593 + write,
+         "fetch_bytes_per_trajectory_step_raw": fetch_raw, "write_bytes_per_trajectory_step": write, "fetch_calibration": 1.593,
+         "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x 1.593 (own-pattern calibration of "
+                   "round 1: 8-byte-per-lane coalesced reads report 0.628 of the bytes) + WRITE, dominant kernel %s, last third of its "
+                   "launches" % (summary_name, dom)}
+tp = os.path.join(ROOT, "profiles", "traffic.json")
+tj = json.load(open(tp))
+key = "%s:f64:%s" % (cfg, "fused" if fused else "steps")
+print(key, "was", tj.get(key, {}).get("bytes_per_trajectory_step"), "now", entry["bytes_per_trajectory_step"], "algorithmic", bf["roofline"]["algorithmic_bytes_per_trajectory_step"])
+tj[key] = entry
+json.dump(tj, open(tp, "w"), indent=1)
