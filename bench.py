@@ -56,6 +56,10 @@ CONFIGS = {
                  text="BASELINE cfg3: Van der Pol closed loop as vanderpol_RBF.py (8 thin-plate RBF observables, y = C x, box +-2, "
                       "model continued from the offline Gram = its 'storage' update :434-438), horizon N=30, RK4 plant on device, "
                       "parameter switch at step 102"),
+    "cfg3-L20": dict(L=20, N=30, B=16384, plant="vdp", lift="rbf", output="Cx", lb=-2.0, ub=2.0, P0=1e5, barQ0=1e5, settle=150,
+                     text="BASELINE cfg3 with L = 20 centres (SURVEY 8d asks for it beside L = 8): Van der Pol closed loop as "
+                          "vanderpol_RBF.py, 20 thin-plate RBF observables, y = C x, box +-2, storage update, horizon N=30, RK4 plant on "
+                          "device, parameter switch at step 102"),
     "cfg4": dict(L=32, N=40, B=8192, plant="tank", lift="mlp", layers=2, shared=True, settle=160,
                  text="BASELINE cfg4: cascaded tanks (Tank_System.m), 32-dim MLP lift (2-100-100-32, random init seed 9), N=40, "
                       "delta-u form with Cy = [0 1], ONE model for all trajectories of all ranks from the all-reduced EDMD Gram "
@@ -80,7 +84,7 @@ def workload_inputs(name, L, N):
         w["weights"] = random_mlp_weights(2, 100, 2, L, seed=9)
         w["data"] = tank_offline_data()
         w["ref"] = np.ones((1, N))
-    elif name == "cfg3":
+    elif c.get("lift") == "rbf":
         X, Y, U = offline_data(plant=vdp_rk4)
         rng = np.random.RandomState(0)
         w["centres"] = X[:, rng.choice(X.shape[1], L, replace=False)].T.copy()  # (vanderpol_RBF.py:44-46 takes k-means centres of the data)
@@ -161,7 +165,7 @@ def _cpu_worker(args):
         return done, time.perf_counter() - t0
     for t in range(x0s.shape[1]):
         ctl = ko.OracleController(lift, L, 2, N, c["lb"], c["ub"], A0, B0, C0, P0=c["P0"], barQ0=c["barQ0"], solver=solver)
-        if name == "cfg3":  # continue from the offline Gram (vanderpol_RBF.py:434-438 in recursive form)
+        if c.get("lift") == "rbf":  # continue from the offline Gram (vanderpol_RBF.py:434-438 in recursive form)
             ctl.rls.K_A = PY @ Z.T
             ctl.rls.P = np.linalg.pinv(Z @ Z.T)
             ctl.rls.bar_X = X @ PX.T
@@ -228,7 +232,7 @@ class Loop:
                                 Rw=1e-3, P0=1e4, barQ0=1e4, delta_u=True, out_row0=1, out_rows=1, dtype=dtype, device=dev,
                                 cold_start=cold, threads=threads)
             self.m.offline_fit(*w["data"], ridge=1e-9)
-        elif name == "cfg3":
+        elif c.get("lift") == "rbf":
             self.m = KoopmanMPC(n=2, L=L, N=N, batch=B, lift="rbf", centres=w["centres"], output="Cx", lb=c["lb"], ub=c["ub"],
                                 P0=c["P0"], barQ0=c["barQ0"], dtype=dtype, device=dev, cold_start=cold, threads=threads)
             self.m.offline_fit(*w["data"], ridge=1e-9, init_rls=True)
