@@ -33,6 +33,16 @@ __global__ __launch_bounds__(TPB, (TPB == 256 ? (step_one_region<TPB, L_, N_, Q_
   step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
 
+// The solve alone (kmpc_qp_solve, the shared-model step of cfg4: H, T0, F come from shared_model_kernel) as a kernel of its
+// own for the long horizons: the step kernel's register allocation is that of its hungriest phase (256 registers at N = 40:
+// 8 trajectories per CU), the solve with H re-read from LDS needs half -- residency is what these kernels are bound by (4.1b).
+template <typename T, int TPB, int L_, int N_, int Q_>
+__global__ __launch_bounds__(TPB, 3) void step_qp_kernel(const StepArgs<T> a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const StepVar<T> sv{PH_QP, 0, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0)};
+  step_body<T, TPB, L_, N_, Q_, true>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
+}
+
 // ---------------------------------------------------------------------------------------
 // launcher
 // ---------------------------------------------------------------------------------------
@@ -48,9 +58,15 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
   }
   // a solve-only launch of a register solver (kmpc_qp_solve, the shared-model step) touches neither the model block
   // nor a tableau region: without it more trajectories fit on a CU (cfg4 sizes: 25 -> 16 KB each)
-  if (!TAB && (a.phases & (PH_RLS | PH_CONDENSE)) == 0) {
+  constexpr bool QPK = TPB == 64 && N_ > 24 && L_ > 0 && !TAB;  // (has a solve-only kernel)
+  const bool qp_only = (a.phases & (PH_RLS | PH_CONDENSE)) == 0;
+  if (!TAB && qp_only) {
     lds -= (size_t)k.r2 * sizeof(T);
     k.r2 = 0;
+    if (QPK) {  // ... and of the vector area only the solve's part: red | f | max(x, x_a, g ; psi behind z, Pz)
+      const int p = a.L + 1, setq = 3 * a.N > 2 * p + a.L ? 3 * a.N : 2 * p + a.L;
+      lds -= (size_t)(vec_elems(a.n, a.L, a.q, a.N) - (16 + a.N + setq)) * sizeof(T);
+    }
   }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   static size_t configured_dev[16] = {};  // (function attributes are per device)
@@ -60,6 +76,12 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
+  }
+  if constexpr (QPK) {
+    if (qp_only && a.phases == PH_QP) {
+      hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_>), dim3(a.B), dim3(TPB), lds, s, k);
+      return hipGetLastError();
+    }
   }
   hipLaunchKernelGGL((step_kernel<T, TPB, L_, N_, Q_>), dim3(a.B), dim3(TPB), lds, s, k);
   return hipGetLastError();
