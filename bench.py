@@ -421,7 +421,7 @@ def main():
     if rank == 0:
         total = B * world
         if main_loop.shared:
-            kname = "step_kernel (box QPs of the shared model, %d blocks x 64 threads); lift, Gram (MFMA), model solve and condense are separate launches" % B
+            kname = "step_qp_kernel (box QPs of the shared model, %d blocks x 64 threads); lift, Gram (MFMA), model solve and condense are separate launches" % B
         elif fused:
             kname = "rollout_kernel (lift + RLS + condense + QP + plant, all %d steps in one launch), %d workgroups" % (steps_per_launch, (B + 15) // 16)
         else:

@@ -10,7 +10,7 @@ def bench_line(name):
     return json.loads([l for l in open(os.path.join(d, "bench_%s.json" % name)) if l.startswith("{")][-1])
 bf, bw = bench_line("fetch"), bench_line("write")
 fused = "rollout_kernel" in bf["roofline"]["kernel"]
-dom = "rollout_kernel" if fused else "step_kernel"
+dom = "rollout_kernel" if fused else ("step_qp_kernel" if "step_qp_kernel" in bf["roofline"]["kernel"] else "step_kernel")
 vals, cur, sec = {}, None, None
 for l in open(os.path.join(d, "summary.txt")):
     if l.startswith("== "):
