@@ -881,6 +881,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   unsigned long long Smask = 0ull;
   int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0, rtot = 0;
   bool nopredict = false;
+  KTRACE(8);
 
   while (true) {
     T g = T(0);
@@ -915,6 +916,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     if (it >= a.max_iter || refresh > 4) { status = 1; break; }
     if (it >= N_ + 10) { status = 3; break; }  // crawling: the active-set loop of qp_lds finishes from here
     unsigned long long Fmask = ~Imask & allmask;
+    if (it == 0) KTRACE(9);
 
     // active-set prediction rounds inside the iteration: see qp_regs (same rule, the block-wide maximum goes through LDS)
     const bool predict = !nopredict && (a.qp_predict & 1) != 0;
@@ -963,6 +965,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
         Smask = 0ull;
       }
       Fmask = Smask;
+      if (it == 0 && rounds == 0) KTRACE(10);
 
       // Newton direction on F
       isF = own && ((Fmask >> myvar) & 1ull);
@@ -994,6 +997,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       ++rounds;
     }
 
+    if (it == 0) KTRACE(11);
     // trial point (see qp_regs): projected Armijo search on the true cost, or the predicted point if it lowers the cost
     T alpha = T(1), xa = x, hxa = T(0), Ja = J0;
     bool redo = false;
@@ -1028,8 +1032,10 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     x = xa;
     hx = hxa;
     J0 = Ja;
+    if (it == 0) KTRACE(12);
     ++it;
   }
+  KTRACE(13);
   if (status == 2) x = own ? c0 : T(0);  // (see qp_regs: non-finite data never leaves as a NaN input)
   if (status == 3) {
     __syncthreads();
@@ -1053,7 +1059,11 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     }
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
     if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it + rtot : it + rtot;
+#ifdef KMPC_TRACE
+    if (b < 8192) kmpc_trace_buf[b * 32 + 15] = (unsigned long long)(it + rtot);
+#endif
   }
+  KTRACE(14);
   return false;
 }
 
