@@ -23,6 +23,7 @@ template <int MODE> __global__ __launch_bounds__(1024) void k(double* out, int i
 #define FMA2 "v_fma_f64 %0, %0, %10, %9\n v_fma_f64 %1, %1, %10, %9\n v_fma_f64 %2, %2, %10, %9\n v_fma_f64 %3, %3, %10, %9\n v_fma_f64 %4, %4, %10, %9\n v_fma_f64 %5, %5, %10, %9\n v_fma_f64 %6, %6, %10, %9\n v_fma_f64 %7, %7, %10, %9\n"
 #define MUL2 "v_mul_f64 %0, %0, %8\n v_mul_f64 %1, %1, %8\n v_mul_f64 %2, %2, %8\n v_mul_f64 %3, %3, %8\n v_mul_f64 %4, %4, %8\n v_mul_f64 %5, %5, %8\n v_mul_f64 %6, %6, %8\n v_mul_f64 %7, %7, %8\n"
 #define ADD2 "v_add_f64 %0, %0, %9\n v_add_f64 %1, %1, %9\n v_add_f64 %2, %2, %9\n v_add_f64 %3, %3, %9\n v_add_f64 %4, %4, %9\n v_add_f64 %5, %5, %9\n v_add_f64 %6, %6, %9\n v_add_f64 %7, %7, %9\n"
+#define FDPP "v_fmac_f64_dpp %0, %8, %9 row_newbcast:1 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %1, %8, %9 row_newbcast:2 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %2, %8, %9 row_newbcast:3 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %3, %8, %9 row_newbcast:4 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %4, %8, %9 row_newbcast:5 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %5, %8, %9 row_newbcast:6 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %6, %8, %9 row_newbcast:7 row_mask:0xf bank_mask:0xf\n v_fmac_f64_dpp %7, %8, %9 row_newbcast:8 row_mask:0xf bank_mask:0xf\n"
 #define DARGS : "+v"(f0), "+v"(f1), "+v"(f2), "+v"(f3), "+v"(f4), "+v"(f5), "+v"(f6), "+v"(f7) : "v"(m), "v"(c), "s"(sm)
 #define F32 "v_fma_f32 %0, %0, %8, %9\n v_fma_f32 %1, %1, %8, %9\n v_fma_f32 %2, %2, %8, %9\n v_fma_f32 %3, %3, %8, %9\n v_fma_f32 %4, %4, %8, %9\n v_fma_f32 %5, %5, %8, %9\n v_fma_f32 %6, %6, %8, %9\n v_fma_f32 %7, %7, %8, %9\n"
 #define MOV "v_mov_b32 %0, %8\n v_mov_b32 %1, %8\n v_mov_b32 %2, %8\n v_mov_b32 %3, %8\n v_mov_b32 %4, %8\n v_mov_b32 %5, %8\n v_mov_b32 %6, %8\n v_mov_b32 %7, %8\n"
@@ -55,6 +56,7 @@ template <int MODE> __global__ __launch_bounds__(1024) void k(double* out, int i
       asm volatile(FMA2 DARGS); asm volatile(MOV GARGS); asm volatile(FMA2 DARGS); asm volatile(MOV GARGS);
       asm volatile(FMA2 DARGS); asm volatile(MOV GARGS); asm volatile(FMA2 DARGS); asm volatile(MOV GARGS);
     }
+    if constexpr (MODE == 13) asm volatile(R4(FDPP) DARGS);
     if constexpr (MODE == 12) asm volatile(R4("s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n s_nop 0\n"));
   }
   if (clk && blockIdx.x == 0 && threadIdx.x == 0) { clk[0] = __builtin_amdgcn_s_memtime() - c0; clk[1] = __builtin_amdgcn_s_memrealtime() - r0; }
@@ -62,7 +64,7 @@ template <int MODE> __global__ __launch_bounds__(1024) void k(double* out, int i
                                          (double)(g0 + g1 + g2 + g3 + g4 + g5 + g6 + g7);
 }
 static const char* names[] = {"v_fma_f64, 3 VGPR sources", "v_fma_f64, 2 VGPR + 1 SGPR source", "v_mul_f64", "v_add_f64", "v_fma_f32", "v_mov_b32", "v_mov_b32_dpp row_shr",
-                              "s_add_u32", "ds_read_b64", "32 v_fma_f64 + 32 s_add_u32", "32 v_fma_f64 + 32 ds_read_b64", "32 v_fma_f64 + 32 v_mov_b32", "s_nop 0"};
+                              "s_add_u32", "ds_read_b64", "32 v_fma_f64 + 32 s_add_u32", "32 v_fma_f64 + 32 ds_read_b64", "32 v_fma_f64 + 32 v_mov_b32", "s_nop 0", "v_fmac_f64_dpp row_newbcast"};
 template <int MODE> void run(double* out, unsigned long long* clk) {
   const int iters = 4000;
   for (int wps = 1; wps <= 8; wps *= 2) {  // waves per SIMD
@@ -88,6 +90,7 @@ int main() {
   for (int i = 0; i < 40; ++i) hipLaunchKernelGGL(k<0>, dim3(256), dim3(1024), 0, 0, out, 20000, (unsigned long long*)nullptr);  // clock ramp
   (void)hipDeviceSynchronize();
   if (getenv("ALL")) { run<0>(out, clk); run<1>(out, clk); run<2>(out, clk); run<3>(out, clk); run<4>(out, clk); run<5>(out, clk); run<6>(out, clk); }
-  run<7>(out, clk); run<8>(out, clk); run<9>(out, clk); run<10>(out, clk); run<11>(out, clk); run<12>(out, clk);
+  if (getenv("ALL")) { run<7>(out, clk); run<8>(out, clk); run<9>(out, clk); run<10>(out, clk); run<11>(out, clk); run<12>(out, clk); }
+  run<1>(out, clk); run<13>(out, clk);
   return 0;
 }
