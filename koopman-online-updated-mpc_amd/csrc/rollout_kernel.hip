@@ -319,7 +319,12 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
       sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
       sv.x_next = RBF ? nullptr : sXn + wv * 4;
-      step_body<double, 64, L_, N_, Q_, (ro_max_threads<L_, N_, Q_, NW, KS_>() == 1024 && N_ > 24)>(a, sv, bk, wsm);
+      // (16 trajectories per CU with a long horizon -- the RBF roll-out of cfg3 -- : H re-read from LDS, and the active-set
+      //  safeguard stays the fall-back on the global-scratch tableau instead of living in registers: 67 -> 51 spilled
+      //  registers, 109.7 -> 117.8 M steps/s; its crawling solves are 14 of 327 680 on that workload)
+      constexpr bool LOWREG = ro_max_threads<L_, N_, Q_, NW, KS_>() == 1024 && N_ > 24;
+      // (y = psi, Q_ == L_: ill-conditioned H, crawling solves are common -- those instantiations keep the register safeguard)
+      step_body<double, 64, L_, N_, Q_, LOWREG, !LOWREG || Q_ == L_>(a, sv, bk, wsm);
       if (R.X_log) {
         __threadfence_block();
         if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];

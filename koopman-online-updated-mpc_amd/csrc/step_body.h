@@ -351,7 +351,7 @@ template <typename T> __device__ __forceinline__ T wave_min_x(T v) {
   return v;
 }
 
-template <typename T, int N_, bool LOWREG = false>
+template <typename T, int N_, bool LOWREG = false, bool ASREG = true>
 __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
                                         T* red, T* qx_out, T up, T xw_pre) {
   constexpr int RM = (N_ + 7) / 8;
@@ -455,7 +455,7 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
   // Compiled in for the long horizons (N > 24: their kernels have 256+ registers per lane, and their LDS has no room for a
   // tableau, so the round-1 fall-back worked on H in global memory); the short-horizon kernels sit at the 128-register limit
   // of four waves per SIMD (this code costs the cfg2 roll-out 13 %) and keep the LDS fall-back of qp_lds.
-  constexpr bool AS_CT = N_ > 24;
+  constexpr bool AS_CT = N_ > 24 && ASREG;  // (ASREG = false: the fused RBF roll-out of cfg3, see rollout_kernel.hip)
   const bool AS_REGS = AS_CT && (a.qp_predict & 2) == 0;  // (bit 1 of qp_predict: measurement aid, the LDS fall-back instead)
   bool mode_as = false, enter_as = false, at_min = false, nopredict = false;
   int ncrawl = 0;  // refused predictions (x 3) + Armijo backtracks of this solve
@@ -1319,7 +1319,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
 // 0: taken from the arguments at run time (generic fallback, same source).
 // Four waves per SIMD (<= 128 VGPRs) for the small static configurations: BASELINE cfg2 puts exactly 4096
 // trajectories = 4 waves per SIMD on the chip, so one register too many costs a whole second round.
-template <typename T, int TPB, int L_, int N_, int Q_, bool LOWREG = false>
+template <typename T, int TPB, int L_, int N_, int Q_, bool LOWREG = false, bool ASREG = true>
 __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>& sv, const int b, T* const sm) {
   const int tid = local_tid<TPB>();
   // y = C x has q = rows of C <= n < L outputs, y = psi has q = L: with static dimensions the output kind is known
@@ -2121,7 +2121,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
       }
       // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
-      if (qp_regs<T, N_, LOWREG>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
+      if (qp_regs<T, N_, LOWREG, ASREG>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
         block_sync<TPB>();
         if constexpr (step_tableau_in_lds<TPB, N_, L_>()) {
           qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
