@@ -86,6 +86,9 @@ template <typename T> struct StepVar {
   // from memory (the read-back sat behind the round trip of the store that had just written them)
   int psi_in_regs;
   T psi_now_v, psi_prev_v;
+  // solve-only launches of the shared-model step: H is ONE matrix for the whole batch and is read where it lies (global memory,
+  // L1 / L2 hits) instead of being staged into every trajectory's LDS -- the launch then needs LDS for its vectors only
+  bool h_global = false;
 };
 
 // e = tid, tid + TPB, ... < count.  With a compile-time COUNT the loop is fully unrolled, so that the loads of all
@@ -2085,7 +2088,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     }
   } else if (sv.phases & PH_QP) {
     const T* Hg = a.H_in + (a.h_shared ? (size_t)0 : (size_t)b * N * N);
-    for (int e = tid; e < N * N; e += TPB) sH[e] = Hg[e];
+    if (!sv.h_global) for (int e = tid; e < N * N; e += TPB) sH[e] = Hg[e];
     if (a.F_in) {
       // shared-model mode: f_b = F psi_b + f0 (the per-trajectory part of the condensed QP)
       for (int i = tid; i < L; i += TPB) sy[i] = sv.psi_now[i * a.pn_sl + b * a.pn_sb];
@@ -2121,7 +2124,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
       }
       // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
-      if (qp_regs<T, N_, LOWREG, ASREG>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
+      if (qp_regs<T, N_, LOWREG, ASREG>(sv.h_global ? a.H_in : sH, sf, a, sv, b, red, qx, up, xw_pre)) {
         block_sync<TPB>();
         if constexpr (step_tableau_in_lds<TPB, N_, L_>()) {
           qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);

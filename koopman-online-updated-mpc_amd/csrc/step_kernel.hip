@@ -14,6 +14,9 @@
 // LDS map (elements of T):  X[r1] : P -> bar_Q -> H      Y[r2] : K, C -> elimination matrix
 //                           V     : vectors (RLS/condense set aliased with the QP set)
 #include "step_body.h"
+#ifndef KMPC_QP_HG_WAVES
+#define KMPC_QP_HG_WAVES 3
+#endif
 
 namespace kmpc {
 
@@ -36,10 +39,12 @@ __global__ __launch_bounds__(TPB, (TPB == 256 ? (step_one_region<TPB, L_, N_, Q_
 // The solve alone (kmpc_qp_solve, the shared-model step of cfg4: H, T0, F come from shared_model_kernel) as a kernel of its
 // own for the long horizons: the step kernel's register allocation is that of its hungriest phase (256 registers at N = 40:
 // 8 trajectories per CU), the solve with H re-read from LDS needs half -- residency is what these kernels are bound by (4.1b).
-template <typename T, int TPB, int L_, int N_, int Q_>
-__global__ __launch_bounds__(TPB, 3) void step_qp_kernel(const StepArgs<T> a) {
+// HG: the shared-model step -- H is one matrix for the whole batch and is read from global memory (L1 / L2) in the mat-vecs
+// instead of from a per-trajectory LDS copy: 1.4 KB of LDS per trajectory, residency set by the registers alone
+template <typename T, int TPB, int L_, int N_, int Q_, bool HG>
+__global__ __launch_bounds__(TPB, (HG ? KMPC_QP_HG_WAVES : 3)) void step_qp_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  const StepVar<T> sv{PH_QP, 0, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0)};
+  const StepVar<T> sv{PH_QP, 0, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0), HG};
   step_body<T, TPB, L_, N_, Q_, true>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
 
@@ -79,7 +84,15 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
   }
   if constexpr (QPK) {
     if (qp_only && a.phases == PH_QP) {
-      hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_>), dim3(a.B), dim3(TPB), lds, s, k);
+      // (shared H and the register safeguard compiled in and not switched off: the solve never leaves for the LDS tableau)
+      static const bool no_hg = getenv("KMPC_QP_NO_HGLOBAL") != nullptr;
+      if (a.h_shared && a.H_in && a.T_in && (a.qp_predict & 2) == 0 && !no_hg) {
+        const int p = a.L + 1, setq = 3 * a.N > 2 * p + a.L ? 3 * a.N : 2 * p + a.L;
+        k.r1 = 0;
+        hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_, true>), dim3(a.B), dim3(TPB), (size_t)(16 + a.N + setq) * sizeof(T), s, k);
+        return hipGetLastError();
+      }
+      hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_, false>), dim3(a.B), dim3(TPB), lds, s, k);
       return hipGetLastError();
     }
   }
