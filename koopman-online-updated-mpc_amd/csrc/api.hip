@@ -778,11 +778,11 @@ struct Impl : kmpc_handle {
     const int cy0 = cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0;
     static const bool two_kernels = getenv("KMPC_SHARED_TWO_KERNELS") != nullptr;  // measurement aid: the round-1 launches
     const bool one_launch = !two_kernels && cfg.output_kind == KMPC_OUT_CX && shared_model_available(L, n, q, N, cfg.delta_u ? 1 : 0);
-    if (have_prev) HIPCHK(launch_axpby(dGram, delta, cfg.lambda, (int)gram_elems(), s));
+    if (have_prev && !one_launch) HIPCHK(launch_axpby(dGram, delta, cfg.lambda, (int)gram_elems(), s));
     if (one_launch) {
       // model solve + condensed QP + the tableau the box QPs start from, one launch (shared_model_kernel)
       if (!dTs) HIPCHK(hipMalloc(&dTs, sizeof(T) * (size_t)N * N));
-      HIPCHK(launch_shared_model<T>(dGram, (const T*)ref, L, n, q, N, 1.0 / cfg.P0, 1.0 / cfg.barQ0, 1, have_prev ? 1 : 0, cfg.Qw,
+      HIPCHK(launch_shared_model<T>(dGram, have_prev ? delta : nullptr, cfg.lambda, (const T*)ref, L, n, q, N, 1.0 / cfg.P0, 1.0 / cfg.barQ0, 1, have_prev ? 1 : 0, cfg.Qw,
                                     cfg.Rw, dKs, dCs, dHs, dFs, df0s, dTs, wt, cfg.delta_u ? 1 : 0, cy0, s));
       if (have_prev) shared_has_samples = true;
     } else {
