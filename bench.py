@@ -248,9 +248,13 @@ class Loop:
         if not self.shared:
             self.m.rollout(self.c["plant"], self.X, self.r, steps, step0=step0)
             return
-        for k in range(step0, step0 + steps):  # shared model: local Gram sums -> all-reduce -> model, QPs; plant
-            u = self.m.shared_step(self.X, self.r)
-            self.X = self.m.plant_step("tank", self.X, u, switched=(k > 100))
+        sep = os.environ.get("KMPC_BENCH_SEPARATE_PLANT") is not None  # (measurement aid: the plant as a launch of its own)
+        for k in range(step0, step0 + steps):  # shared model: local Gram sums -> all-reduce -> model, QPs with the plant inside
+            if sep:
+                u = self.m.shared_step(self.X, self.r)
+                self.X = self.m.plant_step("tank", self.X, u, switched=(k > 100))
+            else:
+                self.m.shared_step(self.X, self.r, plant="tank", switched=(k > 100))
 
 
 def main():

@@ -195,6 +195,12 @@ int kmpc_gram_accumulate(kmpc_handle* h, const void* X_dev, double* delta_gram_d
  * model (H, F, f0 with f_b = F psi_b + f0); box QP of every trajectory.  ref_dev (q x N) is shared.        */
 int kmpc_shared_solve(kmpc_handle* h, const double* delta_gram_dev, const void* ref_dev, void* U0_dev,
                       void* Useq_dev, int32_t* status_dev, int32_t* iters_dev, void* stream);
+/* ... and the plant inside the solve (the shared-model counterpart of kmpc_rollout's fused plant): after
+ * u_k every trajectory's state advances in place, X_dev (n x B) <- f(X_dev, u_k); plant / switched / hstep as kmpc_plant_step
+ * (Tank_System.m:193-196, 211 for the tanks).  One launch less per step of the shared-model loop.                           */
+int kmpc_shared_solve_plant(kmpc_handle* h, const double* delta_gram_dev, const void* ref_dev, void* U0_dev, void* Useq_dev,
+                            int32_t* status_dev, int32_t* iters_dev, int plant, void* X_dev, int switched, double hstep,
+                            void* stream);
 /* the shared model: A_dev (L x L), B_dev (L), C_dev (n x L) in the handle dtype                           */
 int kmpc_shared_get_model(kmpc_handle* h, void* A_dev, void* B_dev, void* C_dev, void* stream);
 

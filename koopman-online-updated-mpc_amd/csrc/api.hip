@@ -52,6 +52,8 @@ struct kmpc_handle {
                           void* B, void* C, hipStream_t s) = 0;
   virtual int64_t gram_elems() const = 0;
   virtual int shared_local_gram(const void* X, double* delta, hipStream_t s) = 0;
+  virtual int shared_solve_plant(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, int plant, void* X,
+                                 int switched, double hstep, hipStream_t s) = 0;
   virtual int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
                            hipStream_t s) = 0;
   virtual int shared_get_model(void* A, void* B, void* C, hipStream_t s) = 0;
@@ -691,6 +693,7 @@ struct Impl : kmpc_handle {
   bool accumulate = false;
   int fuse_plant = -1, fuse_switched = 0;  // rollouts: the step kernel advances the plant itself
   double fuse_h = 0.05;
+  void* fuse_X = nullptr;  // (shared-model solve with the plant inside)
   int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
               void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) override {
     if (!X || !ref || steps < 0) FAIL(-3, "kmpc_rollout: bad arguments");
@@ -766,6 +769,16 @@ struct Impl : kmpc_handle {
     HIPCHK(launch_gram<T>(g, 0.0, delta, s));  // (forget = 0 overwrites delta)
     return 0;
   }
+  int shared_solve_plant(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, int plant, void* X,
+                         int switched, double hstep, hipStream_t s) override {
+    if (!X) FAIL(-3, "kmpc_shared_solve_plant: null pointer");
+    if (n != 2) FAIL(-3, "plants are two-state systems");
+    if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
+    fuse_plant = plant; fuse_switched = switched ? 1 : 0; fuse_h = hstep; fuse_X = X;
+    const int rc = shared_solve(delta, ref, U0, Useq, st, it, s);
+    fuse_plant = -1; fuse_X = nullptr;
+    return rc;
+  }
   int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
                    hipStream_t s) override {
     if (!delta || !ref || !U0) FAIL(-3, "kmpc_shared_solve: null pointer");
@@ -801,6 +814,8 @@ struct Impl : kmpc_handle {
     a.psi_now = dPsi[cur]; a.pn_sl = 1; a.pn_sb = L;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
     a.x_warm = cfg.cold_start ? nullptr : dWarm;
+    // (kmpc_shared_solve_plant: the solve also advances every trajectory's plant with its u_k, as the roll-outs do)
+    if (fuse_plant >= 0) { a.plant = fuse_plant; a.plant_switched = fuse_switched; a.plant_h = (T)fuse_h; a.X_rw = (T*)fuse_X; }
     const bool rec = prof && ev_used + 3 <= EV_CAP;  // (profiling: the QP launch of the shared-model step)
     if (rec) {
       while (ev.size() < ev_used + 3) {
@@ -1127,6 +1142,11 @@ int kmpc_allreduce_gram(kmpc_handle* h, double* delta, void* nccl_comm, void* s)
 int kmpc_shared_local_gram(kmpc_handle* h, const void* X, double* delta, void* s) { NN(h); return h->shared_local_gram(X, delta, (hipStream_t)s); }
 int kmpc_gram_accumulate(kmpc_handle* h, const void* X, double* delta, void* s) { return kmpc_shared_local_gram(h, X, delta, s); }
 int kmpc_shared_solve(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->shared_solve(delta, ref, U0, Useq, st, it, (hipStream_t)s); }
+int kmpc_shared_solve_plant(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
+                            int plant, void* X, int switched, double hstep, void* s) {
+  NN(h);
+  return h->shared_solve_plant(delta, ref, U0, Useq, st, it, plant, X, switched, hstep, (hipStream_t)s);
+}
 int kmpc_shared_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->shared_get_model(A, B, C, (hipStream_t)s); }
 int64_t kmpc_state_bytes(const kmpc_handle* h) { return h ? h->state_bytes() : -1; }
 int kmpc_state_export(kmpc_handle* h, void* blob, int64_t bytes) { NN(h); return h->state_export(blob, bytes); }

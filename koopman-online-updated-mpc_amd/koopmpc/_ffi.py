@@ -68,6 +68,7 @@ SIGNATURES = {
     "kmpc_shared_local_gram": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_gram_accumulate": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_shared_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "kmpc_shared_solve_plant": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _D, _VP]),
     "kmpc_shared_get_model": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "kmpc_set_applied_input": (_I, [_VP, _VP, _I, _VP]),
     "kmpc_plant_step": (_I, [_VP, _I, _VP, _VP, _D, _I, _I, _VP]),

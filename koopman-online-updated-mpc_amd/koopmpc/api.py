@@ -387,21 +387,32 @@ class KoopmanMPC:
                   "kmpc_shared_local_gram")
         return self._delta
 
-    def shared_solve(self, delta_gram, r):
+    def shared_solve(self, delta_gram, r, plant=None, X=None, switched=False, h=0.05):
         """Stage 2: G <- lambda G + delta_gram (summed over ranks by the caller), shared [A B], C from G,
-        condensed QP of the shared model, box QP of every trajectory.  Returns u_k (B,)."""
+        condensed QP of the shared model, box QP of every trajectory.  Returns u_k (B,).
+        plant = "duffing" | "vdp" | "tank" with X (n, B): the solve also advances the plant, X <- f(X, u_k) in place
+        (kmpc_shared_solve_plant; one launch less per step of a closed loop)."""
         rr, per = self._ref(r)
         if per:
             raise ValueError("shared-model mode takes one reference (q, N) for the whole batch")
         d = delta_gram.to(device=self.device, dtype=torch.float64).contiguous()
-        self._chk(self.lib.kmpc_shared_solve(self.h, self._p(d), self._p(rr), self._p(self.U0), self._p(self.Useq),
-                                             self._p(self.status), self._p(self.iters), self._stream()),
-                  "kmpc_shared_solve")
+        if plant is None:
+            self._chk(self.lib.kmpc_shared_solve(self.h, self._p(d), self._p(rr), self._p(self.U0), self._p(self.Useq),
+                                                 self._p(self.status), self._p(self.iters), self._stream()),
+                      "kmpc_shared_solve")
+        else:
+            pl = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP, "tank": _ffi.KMPC_PLANT_TANK}[plant]
+            assert X is not None and X.is_cuda and X.dtype == self.dtype and X.is_contiguous() and tuple(X.shape) == (self.n, self.B)
+            self._chk(self.lib.kmpc_shared_solve_plant(self.h, self._p(d), self._p(rr), self._p(self.U0), self._p(self.Useq),
+                                                       self._p(self.status), self._p(self.iters), pl, self._p(X),
+                                                       int(bool(switched)), float(h), self._stream()),
+                      "kmpc_shared_solve_plant")
         return self.U0
 
-    def shared_step(self, x, r):
+    def shared_step(self, x, r, plant=None, switched=False, h=0.05):
         """One control step with ONE model for all trajectories of all ranks: local Gram sums (MFMA) ->
-        all-reduce over the process group (RCCL on GPUs; the only collective of the path) -> model, QP."""
+        all-reduce over the process group (RCCL on GPUs; the only collective of the path) -> model, QP.
+        With `plant`, x (a contiguous (n, B) device tensor) is advanced in place by the solve kernel."""
         import torch.distributed as dist
 
         delta = self.shared_local_gram(x)
@@ -412,7 +423,7 @@ class KoopmanMPC:
                 delta.copy_(hd)
             else:
                 dist.all_reduce(delta, op=dist.ReduceOp.SUM)  # RCCL over xGMI: the one collective of the path
-        return self.shared_solve(delta, r)
+        return self.shared_solve(delta, r, plant=plant, X=x if plant is not None else None, switched=switched, h=h)
 
     def shared_model(self):
         A = torch.empty(self.L, self.L, dtype=self.dtype, device=self.device)

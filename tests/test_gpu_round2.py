@@ -559,3 +559,31 @@ def test_runs_are_bitwise_reproducible(torch_mod, name, B, steps):
     a, b = run(), run()
     for k in range(steps):
         assert torch.equal(a[k][0], b[k][0]) and torch.equal(a[k][1], b[k][1]) and torch.equal(a[k][2], b[k][2]), k
+
+
+@pytest.mark.gpu
+def test_shared_step_with_the_plant_inside_equals_the_two_calls(torch_mod, KM):
+    """kmpc_shared_solve_plant: the shared-model solve that also advances the plant (Tank_System.m:193-196, 211) gives the
+    inputs and states of shared_step followed by plant_step, bit for bit, across the plant switch."""
+    torch = torch_mod
+    from koopmpc.synth import random_mlp_weights, tank_offline_data
+    L, N, B = 32, 40, 96
+    w = random_mlp_weights(2, 100, 2, L, seed=9)
+    kw = dict(n=2, L=L, N=N, batch=B, weights=w, layers=2, lb=-0.5, ub=0.5, umin=-8.0, umax=8.0, Qw=10.0, Rw=1e-3, P0=1e4,
+              barQ0=1e4, delta_u=True, out_row0=1, out_rows=1)
+    a, b = KM(**kw), KM(**kw)
+    data = tank_offline_data()
+    a.offline_fit(*data, ridge=1e-9)
+    b.offline_fit(*data, ridge=1e-9)
+    rng = np.random.RandomState(3)
+    X0 = torch.tensor(1.0 + 9.0 * rng.rand(2, B), dtype=torch.float64, device="cuda:0")
+    Xa, Xb = X0.clone(), X0.clone()
+    r = np.ones((1, N))
+    for k in range(8):
+        sw = k > 4
+        ua = a.shared_step(Xa, r).clone()
+        Xa = a.plant_step("tank", Xa, ua, switched=sw)
+        ub = b.shared_step(Xb, r, plant="tank", switched=sw).clone()
+        assert torch.equal(ua, ub), k
+        assert torch.equal(Xa, Xb), k
+    assert int(b.status.max()) == 0
