@@ -207,6 +207,26 @@ template <typename T> __device__ __forceinline__ T wave_sum(T v) {
   return (lane_bcast(v, 15) + lane_bcast(v, 31)) + (lane_bcast(v, 47) + lane_bcast(v, 63));
 }
 
+// FOUR wave sums at once: lane l ends with the sum of value (l & 3) over the 64 lanes.  Two butterfly steps fold the four values
+// into one per lane (a lane keeps the value of its own class and sends the other), two row rotations and two row swaps add up
+// the sixteen lanes of a class: ~40 instructions instead of 4 x 23 for four wave_sum.
+__device__ __forceinline__ int dpp_ror(int v, int n) {
+  return n == 4 ? __builtin_amdgcn_update_dpp(0, v, 0x124, 0xf, 0xf, true) : __builtin_amdgcn_update_dpp(0, v, 0x128, 0xf, 0xf, true);
+}
+__device__ __forceinline__ double dpp_ror(double v, int n) {
+  return __hiloint2double(dpp_ror(__double2hiint(v), n), dpp_ror(__double2loint(v), n));
+}
+__device__ __forceinline__ double rows_sum(double v) {  // sum over the four 16-lane rows, lane by lane; every row gets it
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const auto a = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
+  const auto b = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+  const double s = __hiloint2double(b[0], a[0]) + __hiloint2double(b[1], a[1]);
+  const int slo = __double2loint(s), shi = __double2hiint(s);
+  const auto c = __builtin_amdgcn_permlane32_swap(slo, slo, false, false);
+  const auto d = __builtin_amdgcn_permlane32_swap(shi, shi, false, false);
+  return __hiloint2double(d[0], c[0]) + __hiloint2double(d[1], c[1]);
+}
+
 // sum over the whole block; every thread gets the result.  `red` holds >= 8 elements.
 template <typename T, int TPB> __device__ __forceinline__ T block_sum(T v, T* red) {
   v = wave_sum(v);
@@ -273,6 +293,15 @@ template <typename T> __device__ __forceinline__ T allreduce8(T v) {
   v += dpp_q(v, 1);
   v += dpp_q(v, 2);
   return v;
+}
+__device__ __forceinline__ double wave_sum4(double a, double b, double c, double d, int lane) {
+  const bool b0 = (lane & 1) != 0, b1 = (lane & 2) != 0;
+  const double r1 = (b0 ? b : a) + dpp_q(b0 ? a : b, 0);  // lane ^ 1: even lanes collect a, odd lanes b
+  const double r2 = (b0 ? d : c) + dpp_q(b0 ? c : d, 0);  //           even lanes collect c, odd lanes d
+  double r = (b1 ? r2 : r1) + dpp_q(b1 ? r1 : r2, 1);     // lane ^ 2: lane & 3 = 0, 1, 2, 3 collect a, b, c, d
+  r += dpp_ror(r, 4);                                     // the four lanes of a class inside a 16-lane row
+  r += dpp_ror(r, 8);
+  return rows_sum(r);
 }
 
 // fast reciprocal: hardware estimate + two Newton steps (full double / float accuracy for the
@@ -1833,28 +1862,38 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       block_sync<TPB>();  // (C may sit where g is written from now on)
       typedef T T2 __attribute__((ext_vector_type(2)));
       int cur = 0;
-      for (int j = 0; j <= N; ++j) {
-        T* const vb = (chain ? sW : sV) + cur * L;
-        const T2* v2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(vb + hh * HL, 2 * sizeof(T)));
-        T ac4[4] = {T(0), T(0), T(0), T(0)};
+      for (int j0 = 0; j0 <= N; j0 += 4) {  // (the outputs of four steps are reduced together: wave_sum4)
+        T pc[4] = {T(0), T(0), T(0), T(0)};
 #pragma unroll
-        for (int l = 0; l < HL / 2; ++l) {
-          const T2 x2 = v2[l];
-          ac4[(2 * l) & 3] += row[2 * l] * x2.x;
-          ac4[(2 * l + 1) & 3] += row[2 * l + 1] * x2.y;
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u;
+          if (j <= N) {
+            T* const vb = (chain ? sW : sV) + cur * L;
+            const T2* v2 = reinterpret_cast<const T2*>(__builtin_assume_aligned(vb + hh * HL, 2 * sizeof(T)));
+            T ac4[4] = {T(0), T(0), T(0), T(0)};
+#pragma unroll
+            for (int l = 0; l < HL / 2; ++l) {
+              const T2 x2 = v2[l];
+              ac4[(2 * l) & 3] += row[2 * l] * x2.x;
+              ac4[(2 * l + 1) & 3] += row[2 * l + 1] * x2.y;
+            }
+            T acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
+            acc += dpp_q(acc, 0);  // the other half of the row (the neighbouring lane)
+            acc += isA ? bs : T(0);
+            pc[u] = co * vb[ln < L ? ln : 0];
+            if (hh == 0 && isA && j < N) (chain ? sW : sV)[(cur ^ 1) * L + rr] = acc;  // v_{j+1} / w_{j+1}
+            block_sync<TPB>();
+            cur ^= 1;
+          }
         }
-        T acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
-        acc += dpp_q(acc, 0);  // the other half of the row (the neighbouring lane)
-        acc += isA ? bs : T(0);
-        const T gco = wave_sum(co * vb[ln < L ? ln : 0]);
-        if (hh == 0 && isA && j < N) (chain ? sW : sV)[(cur ^ 1) * L + rr] = acc;  // v_{j+1} / w_{j+1}
-        if (ln == 0 && corow < q) {
-          if (chain == 0) { if (j < N) sG[j * q + corow] = gco; }       // g_j = Co v_j
-          else if (j >= 1) sEr[(j - 1) * q + corow] += gco;             // e_j = Co w_j - r_{j-1}
+        const T g4 = (T)wave_sum4((double)pc[0], (double)pc[1], (double)pc[2], (double)pc[3], ln);
+        const int j = j0 + ln;  // lane u < 4 of the wave holds the output of step j0 + u
+        if (ln < 4 && corow < q && j <= N) {
+          if (chain == 0) { if (j < N) sG[j * q + corow] = g4; }       // g_j = Co v_j
+          else if (j >= 1) sEr[(j - 1) * q + corow] += g4;             // e_j = Co w_j - r_{j-1}
         }
-        block_sync<TPB>();
-        cur ^= 1;
       }
+      block_sync<TPB>();  // (the last outputs)
     } else if constexpr (L_ > 0 && TPB == 256 && (L_ + Q_ <= 128) && ((L_ & 1) == 0)) {
       // Static path for four-wave trajectories (cfg5 sizes, L = 64): waves 0-1 run the v-chain, waves 2-3 the w-chain;
       // thread t of a half keeps row t of [A; Co] in REGISTERS for the whole recursion (the generic path re-reads the
