@@ -194,3 +194,42 @@ def test_mat_io_roundtrip(tmp_path):
     d = sio.loadmat(f2)
     assert d["logXloc"].shape == (2, 7) and d["logUloc"].shape == (1, 7) and d["logR"].shape == (2, 7)
     assert np.array_equal(d["logXloc"][:, 3], logX[3, :, 1]) and np.allclose(d["tspan"].ravel(), 0.05 * np.arange(7))
+
+
+# --------------------------------------------------------------------------------------
+# bench.py host logic (no GPU): every configuration's workload builds, and the CPU baseline leg -- the oracle run the
+# reference's way, the only place outside tests/ and smoke() that may use it -- produces trajectory-steps for each of them
+# --------------------------------------------------------------------------------------
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+
+    return bench
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg3-L20", "cfg4", "cfg5"])
+def test_bench_workloads_build(name):
+    bench = _bench()
+    c = bench.CONFIGS[name]
+    w = bench.workload_inputs(name, c["L"], c["N"])
+    assert w["L"] == c["L"] and w["N"] == c["N"]
+    X, Y, U = w["data"]
+    assert X.shape == Y.shape and X.shape[0] == 2 and U.shape == (X.shape[1],)
+    if c.get("lift") == "rbf":
+        assert w["weights"] is None and w["centres"].shape == (c["L"], 2)
+    else:
+        assert w["centres"] is None and w["weights"][-1][0].shape[0] == c["L"]  # output layer rows = lift dimension
+    q = 1 if name == "cfg4" else 2
+    assert w["ref"].shape == (q, c["N"])
+    x0 = bench.initial_states_for(name, 8, 101)
+    assert x0.shape == (2, 8) and np.isfinite(x0).all()
+    assert np.array_equal(x0, bench.initial_states_for(name, 8, 101))  # seeded
+
+
+@pytest.mark.parametrize("name,solver", [("cfg2", "lbfgsb"), ("cfg3", "exact"), ("cfg4", "exact")])
+def test_bench_cpu_baseline_worker_makes_steps(name, solver):
+    bench = _bench()
+    c = bench.CONFIGS[name]
+    x0 = bench.initial_states_for(name, 4, 101)
+    done, secs = bench._cpu_worker((name, c["L"], c["N"], x0, 1.5, solver, 2))
+    assert done >= 2 and secs > 0.0
