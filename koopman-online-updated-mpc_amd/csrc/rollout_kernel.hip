@@ -44,8 +44,15 @@ __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int til
 // uniform branch and waited for its own LDS read); 0: run-time width.
 // Register budget: the LDS decides how many trajectories (= waves) a CU holds; up to four waves per SIMD get 128
 // VGPRs each (cfg2: 16 trajectories per CU), dimension sets with large per-trajectory regions leave room for more.
+// RBF roll-outs with a long horizon and y = C x keep inv_K_G, [A B], bar_Q and H in ONE LDS region (step_body's ONE64, as the
+// four-wave kernels do): their residency is set by the LDS alone
+template <int L_, int N_, int Q_, int KS_> constexpr bool ro_one_region() { return KS_ < 0 && N_ > 24 && Q_ != L_ && Q_ > 0; }
+static bool ro_one_region_rt(int L, int N, int q, bool rbf) { return rbf && N > 24 && q != L && q > 0; }
 template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads() {
-  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
+  constexpr size_t pw = ro_one_region<L_, N_, Q_, KS_>()
+                            ? (((size_t)step_region1(L_, N_) + (2 * L_ <= N_ * Q_ ? 0 : ((2 * L_ + 1) & ~1)) + vec_elems_one_region(2, L_, Q_, N_) + 1) & ~(size_t)1)
+                            : ((step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1);
+  constexpr size_t cap = 160 * 1024 / sizeof(double);
   constexpr size_t wgs = cap / (pw * NW);
   constexpr size_t fit = wgs * NW > 16 ? 16 : (wgs * NW < (size_t)NW ? (size_t)NW : wgs * NW);
   // long horizons with the MLP lift: at most 8 trajectories per CU, 256 registers each (the N = 30 solver keeps H and
@@ -324,7 +331,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       //  registers, 109.7 -> 117.8 M steps/s; its crawling solves are 14 of 327 680 on that workload)
       constexpr bool LOWREG = ro_max_threads<L_, N_, Q_, NW, KS_>() == 1024 && N_ > 24;
       // (y = psi, Q_ == L_: ill-conditioned H, crawling solves are common -- those instantiations keep the register safeguard)
-      step_body<double, 64, L_, N_, Q_, LOWREG, !LOWREG || Q_ == L_>(a, sv, bk, wsm);
+      step_body<double, 64, L_, N_, Q_, LOWREG, !LOWREG || Q_ == L_, ro_one_region<L_, N_, Q_, KS_>()>(a, sv, bk, wsm);
       if (R.X_log) {
         __threadfence_block();
         if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
@@ -359,8 +366,11 @@ namespace kmpc {
 // waves (= trajectories) per workgroup of the fused roll-out.  MLP lift: 16 (one workgroup per CU) or 8 (two per
 // CU); the RBF lift needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.
 // 0: does not fit.
+static int ro_one_region_r2(int n, int L, int q, int N) { return n * L <= N * q ? 0 : ((n * L + 1) & ~1); }  // (C where g goes, else its own region)
 static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves, int Lp, int* wstride) {
-  const size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr, !tableau_saves_lds(N, L)) / sizeof(double) + 1) & ~(size_t)1;
+  size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr, !tableau_saves_lds(N, L)) / sizeof(double) + 1) & ~(size_t)1;
+  if (ro_one_region_rt(L, N, q, rbf))
+    per_wave = ((size_t)step_region1(L, N) + ro_one_region_r2(n, L, q, N) + vec_elems_one_region(n, L, q, N) + 1) & ~(size_t)1;
   if (wstride) *wstride = (int)per_wave;
   size_t elems = per_wave * waves;
   if (rbf) return elems;
@@ -473,6 +483,7 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   if (waves == 0) return hipErrorInvalidValue;
   step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));
   if (!a.s.qp_scratch) return hipErrorInvalidValue;
+  if (ro_one_region_rt(a.s.L, a.s.N, a.s.q, rbf)) k.s.r2 = ro_one_region_r2(a.s.n, a.s.L, a.s.q, a.s.N);
   const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
   k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp, waves));
   const size_t lds = elems * sizeof(double);

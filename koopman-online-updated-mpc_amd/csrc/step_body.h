@@ -1351,7 +1351,7 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
 // 0: taken from the arguments at run time (generic fallback, same source).
 // Four waves per SIMD (<= 128 VGPRs) for the small static configurations: BASELINE cfg2 puts exactly 4096
 // trajectories = 4 waves per SIMD on the chip, so one register too many costs a whole second round.
-template <typename T, int TPB, int L_, int N_, int Q_, bool LOWREG = false, bool ASREG = true>
+template <typename T, int TPB, int L_, int N_, int Q_, bool LOWREG = false, bool ASREG = true, bool ONE64 = false>
 __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>& sv, const int b, T* const sm) {
   const int tid = local_tid<TPB>();
   // y = C x has q = rows of C <= n < L outputs, y = psi has q = L: with static dimensions the output kind is known
@@ -1359,7 +1359,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   const bool out_cx = (Q_ > 0 && L_ > 0) ? (Q_ != L_) : (a.out_kind == OUT_CX);
   const int n = a.n, L = L_ ? L_ : a.L, p = L + 1, q = Q_ ? Q_ : a.q, N = N_ ? N_ : a.N, B = a.B;
 
-  constexpr bool ONE_REGION = step_one_region<TPB, L_, N_, Q_>();
+  // (ONE64: the fused RBF roll-outs -- one wave per trajectory with the regions merged the same way: L = 20, N = 30 puts 16 instead
+  //  of 11 trajectories on a CU)
+  constexpr bool ONE_REGION = step_one_region<TPB, L_, N_, Q_>() || (ONE64 && TPB == 64 && L_ > 0 && N_ > 0 && Q_ > 0 && Q_ != L_);
   T* const sX = sm;            // P / bar_Q / H
   T* const sY = sX + a.r1;     // K, C / elimination matrix
   T* const sK = ONE_REGION ? sX : sY;  // (one region: [A B] follows inv_K_G in region 1, region 2 is C alone)
@@ -2165,7 +2167,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       // register tableau; its rare "crawling" cases are finished by the active-set loop of the LDS solver
       if (qp_regs<T, N_, LOWREG, ASREG>(sv.h_global ? a.H_in : sH, sf, a, sv, b, red, qx, up, xw_pre)) {
         block_sync<TPB>();
-        if constexpr (step_tableau_in_lds<TPB, N_, L_>()) {
+        if constexpr (step_tableau_in_lds<TPB, N_, L_>() && !ONE_REGION) {
           qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
         } else {
           // no tableau region in LDS: H moves to this trajectory's global scratch block (read-only from here on,
