@@ -46,8 +46,8 @@ __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int til
 // VGPRs each (cfg2: 16 trajectories per CU), dimension sets with large per-trajectory regions leave room for more.
 // RBF roll-outs with a long horizon and y = C x keep inv_K_G, [A B], bar_Q and H in ONE LDS region (step_body's ONE64, as the
 // four-wave kernels do): their residency is set by the LDS alone
-template <int L_, int N_, int Q_, int KS_> constexpr bool ro_one_region() { return KS_ < 0 && N_ > 24 && Q_ != L_ && Q_ > 0; }
-static bool ro_one_region_rt(int L, int N, int q, bool rbf) { return rbf && N > 24 && q != L && q > 0; }
+template <int L_, int N_, int Q_, int KS_> constexpr bool ro_one_region() { return N_ > 24 && Q_ != L_ && Q_ > 0; }
+static bool ro_one_region_rt(int L, int N, int q, bool) { return N > 24 && q != L && q > 0; }
 template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads() {
   constexpr size_t pw = ro_one_region<L_, N_, Q_, KS_>()
                             ? (((size_t)step_region1(L_, N_) + (2 * L_ <= N_ * Q_ ? 0 : ((2 * L_ + 1) & ~1)) + vec_elems_one_region(2, L_, Q_, N_) + 1) & ~(size_t)1)
@@ -58,7 +58,7 @@ template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads(
   // long horizons with the MLP lift: at most 8 trajectories per CU, 256 registers each (the N = 30 solver keeps H and
   // the tableau in registers; L = 8, N = 30: 24.6 M steps/s like this, 18.7 M with 16 trajectories at 128 registers and
   // 173 of them spilled.  With the RBF lift the same step measures the other way round -- 90 against 60 M steps/s)
-  constexpr size_t waves = (KS_ >= 0 && N_ > 24 && fit > 8) ? 8 : fit;
+  constexpr size_t waves = (KS_ >= 0 && N_ > 24 && fit > 8 && !ro_one_region<L_, N_, Q_, KS_>()) ? 8 : fit;
   return waves > 8 ? 1024 : (waves > 4 ? 512 : 256);  // 4 / 2 / 1 waves per SIMD
 }
 template <int L_, int N_, int Q_, int NW, int KS_>
@@ -401,7 +401,7 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     auto wgs = [&](int w) -> int {
       const size_t e = (rollout_lds_elems(n, L, q, N, false, w, Lp, nullptr) + 63) & ~(size_t)63;
       const int k = (int)(cap / e);
-      const int maxw = N > 24 ? 8 : 16;  // (long horizons: see ro_max_threads)
+      const int maxw = (N > 24 && !ro_one_region_rt(L, N, q, false)) ? 8 : 16;  // (long horizons: see ro_max_threads)
       return k * w > maxw ? maxw / w : k;
     };
     if (g_rollout_workgroup) return wgs(g_rollout_workgroup) > 0 ? g_rollout_workgroup : 0;
@@ -492,7 +492,10 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
   if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1>(k, waves, lds, s);
   // (workgroup sizes whose per-wave regions alone exceed the LDS are not instantiated)
-  constexpr size_t pw = (step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1, cap = 160 * 1024 / sizeof(double);
+  constexpr size_t pw = ro_one_region<L_, N_, Q_, 0>()
+                            ? (((size_t)step_region1(L_, N_) + (2 * L_ <= N_ * Q_ ? 0 : ((2 * L_ + 1) & ~1)) + vec_elems_one_region(2, L_, Q_, N_) + 1) & ~(size_t)1)
+                            : ((step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1);
+  constexpr size_t cap = 160 * 1024 / sizeof(double);
   if constexpr (4 * pw <= cap)
     if (waves == 4) return ks25 ? launch_rollout_nw<L_, N_, Q_, 4, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 4, 0>(k, waves, lds, s);
   if constexpr (8 * pw <= cap)
