@@ -504,7 +504,7 @@ def test_two_ranks_shared_step_equals_one_batch(torch_mod, KM, tmp_path):
 
 
 # ------------------------------------------------------------------ full-size properties of the other BASELINE configurations
-@pytest.mark.parametrize("name,steps", [("cfg3", 12), ("cfg4", 6), ("cfg5", 4)])
+@pytest.mark.parametrize("name,steps", [("cfg3", 12), ("cfg3-L20", 8), ("cfg4", 6), ("cfg5", 4)])
 def test_full_size_properties(torch_mod, name, steps):
     """BASELINE cfg3 / cfg4 / cfg5 at their per-GPU batch (16384 / 8192 / 32768), built exactly as bench.py builds them:
     every QP solved (status 0), inputs inside the box, states finite, and batch independence -- trajectory b of the full
