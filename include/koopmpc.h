@@ -289,13 +289,6 @@ int kmpc_rollout_is_fused(const kmpc_handle* h);
  * trajectory's arithmetic is the same for every choice, only the scheduling differs.
  * Returns -1 for any other value.                                                            */
 int kmpc_set_rollout_workgroup(int trajectories);
-/* Scheduling of the fused roll-out with the MLP lift (the loop duffing.py:823-1012).  group = 0: one cooperative
- * lift per step behind a workgroup barrier (16 trajectories wait for the slowest of them at every step);
- * group = 1..4: no barrier -- the trajectories that are ready form lift groups of up to `group` at run time
- * (timeout_ticks x 10 ns = how long the first one waits for a full group); -1: library default.  Process-wide
- * tuning / test knob: a trajectory's arithmetic does not depend on it (the encoder's summation order does, as
- * between workgroup sizes).  Returns -1 for values outside these ranges.                        */
-int kmpc_set_rollout_schedule(int group, int timeout_ticks);
 /* algorithmic bytes of one trajectory-step (SURVEY.md 8d formula) for this configuration   */
 int64_t kmpc_algorithmic_bytes_per_step(const kmpc_handle* h);
 

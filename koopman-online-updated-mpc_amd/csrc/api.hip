@@ -100,6 +100,12 @@ struct Impl : kmpc_handle {
   T* dUprev = nullptr;
   T* dQpScr = nullptr;  // [B][N*N] fall-back tableau of the register QP solvers (global scratch, rarely touched)
   int qp_scr_cap = 0;
+  // Register-state step (step_v2.h): the fused roll-out of the small y = C x dimension sets streams the state as a "wave image"
+  // ([B][sImg] doubles).  The dense blocks above stay the form every other entry point works on; whichever of the two was
+  // written last is the valid one and the other is rebuilt on demand (state_to_image / image_to_state, one pass over the state).
+  double* dImg = nullptr;
+  long sImg = 0;
+  bool use_img = false, img_valid = false, dense_valid = true;
   T* dWarm = nullptr;  // [N][B] last minimiser = start of the next solve (the reference restarts at zeros, duffing.py:634-635)
   int cur = 0;
   bool have_prev = false;  // a previous (psi, u) exists -> next step runs the RLS update
@@ -151,6 +157,14 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMemset(dPsi[1], 0, sizeof(T) * (size_t)L * B));
     HIPCHK(hipMemset(dUprev, 0, sizeof(T) * (size_t)B));
     HIPCHK(hipMemset(dWarm, 0, sizeof(T) * (size_t)N * B));
+    if constexpr (sizeof(T) == 8) {
+      use_img = threads == 64 && c.output_kind != KMPC_OUT_LIFT && rollout_uses_image(n, L, N, q) &&
+                rollout_fused_available<T>(n, L, N, q, threads, c.lift_kind != KMPC_LIFT_MLP);
+      if (use_img) {
+        sImg = state_image_elems(L, n);
+        HIPCHK(hipMalloc(&dImg, sizeof(double) * (size_t)sImg * B));
+      }
+    }
     if (c.lift_kind == KMPC_LIFT_MLP) {
       if (c.layers != 2 && c.layers != 3) FAIL(-2, "layers (hidden layers) must be 2 or 3");
       if (c.hidden < 1 || c.hidden > 128) FAIL(-2, "hidden must be in 1..128");
@@ -177,7 +191,7 @@ struct Impl : kmpc_handle {
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
                       (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
-                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs})
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dImg})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -188,6 +202,28 @@ struct Impl : kmpc_handle {
     for (int r = 0; r < rows; ++r)
       for (int c2 = 0; c2 < cols; ++c2) tmp[(size_t)r * pcol + c2] = (T)src[(size_t)r * cols + c2];
     HIPCHK(hipMemcpy(dst, tmp.data(), tmp.size() * sizeof(T), hipMemcpyHostToDevice));
+    return 0;
+  }
+
+  // the dense blocks are about to be read or modified / the wave image is about to be used by the roll-out
+  int ensure_dense(hipStream_t s, bool will_modify) {
+    if constexpr (sizeof(T) == 8) {
+      if (use_img && !dense_valid) {
+        HIPCHK(launch_image_to_state(dImg, sImg, n, L, B, (double*)dP, sP, (double*)dK, sK, (double*)dQ, sQ, (double*)dC, sC, s));
+        dense_valid = true;
+      }
+    }
+    if (will_modify) img_valid = false;
+    return 0;
+  }
+  int ensure_image(hipStream_t s) {
+    if constexpr (sizeof(T) == 8) {
+      if (!img_valid) {
+        HIPCHK(launch_state_to_image((const double*)dP, sP, (const double*)dK, sK, (const double*)dQ, sQ, (const double*)dC, sC, n, L, B, dImg, sImg, s));
+        img_valid = true;
+      }
+      dense_valid = false;  // (the roll-out writes the image)
+    }
     return 0;
   }
 
@@ -229,6 +265,7 @@ struct Impl : kmpc_handle {
       for (int c2 = 0; c2 < L; ++c2) k[(size_t)r * p + c2] = (T)A[(size_t)r * L + c2];
       k[(size_t)r * p + L] = (T)Bm[r];
     }
+    { int rc = ensure_dense(nullptr, true); if (rc) return rc; }
     HIPCHK(hipMemcpy(dTmp, k.data(), k.size() * sizeof(T), hipMemcpyHostToDevice));
     HIPCHK(launch_broadcast<T>(dK, sK, dTmp, L * p, B, nullptr));
     if (cfg.output_kind == KMPC_OUT_CX) {
@@ -271,6 +308,7 @@ struct Impl : kmpc_handle {
       if (!Qh || maxiter < 1) FAIL(-3, "kmpc_terminal_from_dare: bad arguments");
       const int nb = per_traj ? B : 1;
       if (nb == 0) return 0;
+      { int rc = ensure_dense(s, false); if (rc) return rc; }
       DevTmp tQl, tEye;
       HIPCHK(hipMalloc(&tQl.p, sizeof(double) * (size_t)L * L));
       double* const dQl = tQl.as<double>();
@@ -325,6 +363,7 @@ struct Impl : kmpc_handle {
   int reset(hipStream_t s) override {
     if (dGram) HIPCHK(hipMemsetAsync(dGram, 0, sizeof(double) * (size_t)gram_elems(), s));
     shared_has_samples = false;
+    { int rc = ensure_dense(s, true); if (rc) return rc; }
     HIPCHK(launch_fill_state<T>(dP, sP, p, (T)cfg.P0, dQ, sQ, L, (T)cfg.barQ0, nullptr, sK, nullptr, sC, n, B, s));
     HIPCHK(hipMemsetAsync(dWarm, 0, sizeof(T) * (size_t)N * B, s));  // first solve starts at clip(0) like the reference's (duffing.py:634-635)
     have_prev = false;
@@ -441,6 +480,7 @@ struct Impl : kmpc_handle {
   int rls_update(const void* psi, const void* u, const void* psin, const void* xn, int Bc, hipStream_t s) override {
     if (Bc != B) FAIL(-3, "kmpc_rls_update: B must equal the handle's batch (the state is per trajectory)");
     if (!psi || !u || !psin || !xn) FAIL(-3, "kmpc_rls_update: null pointer");
+    { int rc = ensure_dense(s, true); if (rc) return rc; }
     StepArgs<T> a = base_args(Bc);
     a.phases = PH_RLS;
     a.first_update = rls_fresh ? 1 : 0;
@@ -453,6 +493,7 @@ struct Impl : kmpc_handle {
   }
 
   int get_model(void* A, void* Bm, void* C, hipStream_t s) override {
+    { int rc = ensure_dense(s, false); if (rc) return rc; }
     HIPCHK(launch_export_model<T>(dK, sK, cfg.output_kind == KMPC_OUT_CX ? dC : nullptr, sC, n, L, B, (T*)A, (T*)Bm,
                                   (T*)C, s));
     return 0;
@@ -461,6 +502,7 @@ struct Impl : kmpc_handle {
   int condense(const void* psi, const void* ref, int rpt, void* H, void* f, void* c, int Bc, hipStream_t s) override {
     if (Bc != B) FAIL(-3, "kmpc_condense: B must equal the handle's batch");
     if (!psi || !ref || !H || !f) FAIL(-3, "kmpc_condense: null pointer");
+    { int rc = ensure_dense(s, false); if (rc) return rc; }
     StepArgs<T> a = base_args(Bc);
     a.phases = PH_CONDENSE;
     a.psi_now = (const T*)psi; a.pn_sl = Bc; a.pn_sb = 1;
@@ -575,6 +617,7 @@ struct Impl : kmpc_handle {
     T* psi_prev = dPsi[cur ^ 1];
     int rc = lift_to((const T*)X, psi_now, 1, L, B, s);
     if (rc) return rc;
+    if ((rc = ensure_dense(s, true))) return rc;
     if (rec) HIPCHK(hipEventRecord(e1, s));
     StepArgs<T> a = base_args(B);
     a.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
@@ -665,7 +708,12 @@ struct Impl : kmpc_handle {
     r.steps = steps; r.step0 = step0; r.switch_step = switch_step;
     r.have_prev = have_prev ? 1 : 0; r.rls_fresh = rls_fresh ? 1 : 0;
     r.U_log = (T*)Ulog; r.X_log = (T*)Xlog;
-    rollout_schedule(&r.dyn_group, &r.dyn_timeout);
+    if constexpr (sizeof(T) == 8) {
+      if (use_img) {
+        if ((rc = ensure_image(s))) return rc;
+        r.img = dImg; r.img_stride = sImg;
+      } else if ((rc = ensure_dense(s, true))) return rc;
+    }
     const bool rec = prof && ev_used + 3 <= EV_CAP;
     if (rec) {
       while (ev.size() < ev_used + 3) {
@@ -745,6 +793,7 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMalloc(&dFs, sizeof(T) * (size_t)N * (L + 1)));  // (one more column in the delta-u form)
     HIPCHK(hipMalloc(&df0s, sizeof(T) * (size_t)N));
     // until samples exist the shared model is the offline one (trajectory 0's copy, duffing.py:811-813)
+    { int rc = ensure_dense(nullptr, false); if (rc) return rc; HIPCHK(hipDeviceSynchronize()); }
     HIPCHK(hipMemcpy(dKs, dK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(dCs, dC, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice));
     return 0;
@@ -841,6 +890,7 @@ struct Impl : kmpc_handle {
     if (!X || !Y || !U || M < 1) FAIL(-3, "kmpc_offline_fit: bad arguments");
     int rc = shared_alloc();
     if (rc) return rc;
+    if ((rc = ensure_dense(s, true))) return rc;
     DevTmp tpx, tpy, tpinv, tg;
     if (init_rls) HIPCHK(hipMalloc(&tpinv.p, sizeof(T) * (size_t)(p * p + L * L)));
     HIPCHK(hipMalloc(&tpx.p, sizeof(T) * (size_t)L * M));
@@ -905,6 +955,7 @@ struct Impl : kmpc_handle {
   }
   int state_export(void* blob, int64_t bytes) override {
     if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_export: buffer too small");
+    { int rc = ensure_dense(nullptr, false); if (rc) return rc; }
     HIPCHK(hipDeviceSynchronize());
     BlobHeader hd{};
     hd.magic = 0x4b4d5043; hd.version = 2; hd.dtype = cfg.dtype; hd.n = n; hd.L = L; hd.N = N; hd.B = B;
@@ -940,6 +991,7 @@ struct Impl : kmpc_handle {
     const int64_t sb = hd.has_shared ? (int64_t)sizeof(double) * gram_elems() + (int64_t)sizeof(T) * ((int64_t)L * p + (int64_t)n * L) : 0;
     if (bytes < (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * base_elems() + sb + wb) FAIL(-3, "kmpc_state_import: buffer too small");
     HIPCHK(hipDeviceSynchronize());
+    dense_valid = true; img_valid = false;  // (the blob overwrites every dense block)
     if (hd.has_shared) { int rc = shared_alloc(); if (rc) return rc; }
     if (hd.have_wterm) {
       if (hd.wterm_from_dare) {
@@ -1082,11 +1134,6 @@ int kmpc_rollout_is_fused(const kmpc_handle* h) { NN(h); return h->rollout_is_fu
 int kmpc_set_rollout_workgroup(int trajectories) {
   if (trajectories != 0 && trajectories != 4 && trajectories != 8 && trajectories != 16) return -1;
   kmpc::set_rollout_workgroup(trajectories);
-  return 0;
-}
-int kmpc_set_rollout_schedule(int group, int timeout_ticks) {
-  if (group < -1 || group > 4 || (group > 0 && timeout_ticks < 1)) return -1;
-  kmpc::set_rollout_schedule(group, timeout_ticks);
   return 0;
 }
 int kmpc_reset(kmpc_handle* h, void* s) { NN(h); return h->reset((hipStream_t)s); }

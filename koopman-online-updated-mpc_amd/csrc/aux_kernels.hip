@@ -180,6 +180,49 @@ hipError_t launch_axpby(double* g, const double* d, double a, int count, hipStre
 INST(float)
 INST(double)
 
+// ---------------------------------------------------------------------------------------
+// dense state blocks <-> wave image of the register-state step (step_v2.h: V2Dims).  One workgroup per trajectory;
+// the image is walked element by element (coalesced on the image side), padding elements are written as zero.
+// ---------------------------------------------------------------------------------------
+template <bool TO_IMAGE>
+__global__ __launch_bounds__(256) void state_image_kernel(double* P, long sP, double* K, long sK, double* Q, long sQ, double* C, long sC,
+                                                          int n, int L, double* img, long stride) {
+  const V2Dims d(L, n);
+  const int b = blockIdx.x, p = L + 1;
+  double* const im = img + (size_t)b * stride;
+  const long l2 = (long)d.cp * d.s2 * 2, tot = d.elems();
+  for (long e = threadIdx.x; e < tot; e += blockDim.x) {
+    const bool lay2 = e < l2;
+    const long r = lay2 ? e : e - l2;
+    const int S = lay2 ? d.s2 : d.s1;
+    const int col = (int)(r / (2 * S)) * 2 + (int)(r & 1), slot = (int)((r >> 1) % S);
+    double* src = nullptr;
+    if (lay2) {
+      if (slot < p) { if (col < p) src = P + (size_t)b * sP + (size_t)slot * p + col; }
+      else if (col < L) src = Q + (size_t)b * sQ + (size_t)(slot - p) * L + col;
+    } else {
+      if (slot < L) { if (col < p) src = K + (size_t)b * sK + (size_t)slot * p + col; }
+      else if (col < L && C) src = C + (size_t)b * sC + (size_t)(slot - L) * L + col;
+    }
+    if (TO_IMAGE) im[e] = src ? *src : 0.0;
+    else if (src) *src = im[e];
+  }
+}
+long state_image_elems(int L, int n) { return V2Dims(L, n).elems(); }
+hipError_t launch_state_to_image(const double* P, long sP, const double* K, long sK, const double* Q, long sQ, const double* C, long sC,
+                                 int n, int L, int B, double* img, long stride, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((state_image_kernel<true>), dim3(B), dim3(256), 0, s, const_cast<double*>(P), sP, const_cast<double*>(K), sK,
+                     const_cast<double*>(Q), sQ, const_cast<double*>(C), sC, n, L, img, stride);
+  return hipGetLastError();
+}
+hipError_t launch_image_to_state(const double* img, long stride, int n, int L, int B, double* P, long sP, double* K, long sK,
+                                 double* Q, long sQ, double* C, long sC, hipStream_t s) {
+  if (B <= 0) return hipSuccess;
+  hipLaunchKernelGGL((state_image_kernel<false>), dim3(B), dim3(256), 0, s, P, sP, K, sK, Q, sQ, C, sC, n, L, const_cast<double*>(img), stride);
+  return hipGetLastError();
+}
+
 // Row-major zero-padded weights (Mp x Hp) -> MFMA A-fragments [tile][k-step][lane]: lane l of tile t, k-step ks
 // holds W[16 t + (l & 15)][4 ks + (l >> 4)], so a wave reads one fragment as 64 consecutive elements.
 template <typename T> __global__ void pack_afrag_kernel(const T* src, int Mp, int Hp, int KS, T* dst) {

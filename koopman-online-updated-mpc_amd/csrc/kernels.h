@@ -95,9 +95,8 @@ template <typename T> struct RolloutArgs {
   int wstride;              // per-wave LDS region in elements
   int keep_off;             // LDS offset (elements) of the part the lift scratch does not overlay
   T* U_log; T* X_log;       // optional (steps x B), (steps x n x B)
-  // > 0: the kernel without a per-step workgroup barrier (rollout_dyn.h): lift groups of up to dyn_group (<= 4) waves
-  // are formed at run time; dyn_timeout = how long the queue head waits for a full group, in 10 ns ticks
-  int dyn_group, dyn_timeout;
+  // register-state step (step_v2.h): the wave images of the trajectories' state, [B][img_stride]
+  T* img; long img_stride;
 };
 
 // K7: Gram sums of one step's transitions (rows [psi_prev; u_prev; psi_now; x_now] against [psi_prev; u_prev])
@@ -137,10 +136,23 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf);
 template <typename T> hipError_t launch_rollout_fused(const RolloutArgs<T>& a, hipStream_t s);
 void set_rollout_workgroup(int trajectories);  // 0 = automatic, else 4 / 8 / 16 (process-wide)
-// scheduling of the fused roll-out with the MLP lift: group = 0: one cooperative lift per step behind a workgroup barrier;
-// 1..4: lift groups formed at run time, no barrier (rollout_dyn.h); timeout in 10 ns ticks (process-wide)
-void set_rollout_schedule(int group, int timeout_ticks);
-void rollout_schedule(int* group, int* timeout_ticks);
+// wave image of one trajectory's state (step_v2.h): [column pair][slot][2] doubles, layer 2 then layer 1
+struct V2Dims {
+  int L, n, p, cp, s2, s1;
+  __host__ __device__ V2Dims(int L_, int n_) : L(L_), n(n_), p(L_ + 1), cp((L_ + 2) / 2), s2(2 * L_ + 1), s1(L_ + n_) {}
+  __host__ __device__ long elems() const { return (long)cp * (s2 + s1) * 2; }
+  // layer 2: slot i < p = row i of inv_K_G, slot p + i = row i of bar_Q;  layer 1: slot r < L = row r of [A B], L + r = row r of C
+  __host__ __device__ long off2(int slot, int col) const { return ((long)(col >> 1) * s2 + slot) * 2 + (col & 1); }
+  __host__ __device__ long off1(int slot, int col) const { return (long)cp * s2 * 2 + ((long)(col >> 1) * s1 + slot) * 2 + (col & 1); }
+};
+// true: the fused roll-out of this dimension set keeps the state in registers and streams its wave image (step_v2.h)
+bool rollout_uses_image(int n, int L, int N, int q);
+long state_image_elems(int L, int n);
+// dense row-major state blocks <-> wave image, whole batch (aux_kernels.hip)
+hipError_t launch_state_to_image(const double* P, long sP, const double* K, long sK, const double* Q, long sQ, const double* C, long sC,
+                                 int n, int L, int B, double* img, long stride, hipStream_t s);
+hipError_t launch_image_to_state(const double* img, long stride, int n, int L, int B, double* P, long sP, double* K, long sK,
+                                 double* Q, long sQ, double* C, long sC, hipStream_t s);
 template <typename T> hipError_t launch_pack_afrag(const T* src, int Mp, int Hp, int KS, T* dst, hipStream_t s);
 template <typename T> hipError_t launch_lift_mlp(const LiftArgs<T>& a, hipStream_t s);
 template <typename T> hipError_t launch_lift_rbf(const LiftArgs<T>& a, hipStream_t s);

@@ -2,6 +2,7 @@
 // launch, step_body (step_body.h) inside, encoder on MFMA.  Compiled as its own translation unit (in parallel with
 // step_kernel.hip); the trace build includes it into step_kernel.hip instead.
 #include "step_body.h"
+#include "step_v2.h"
 
 namespace kmpc {
 
@@ -48,7 +49,14 @@ __device__ __forceinline__ void ro_load_afrags(const double* Wp, int KS, int til
 // four-wave kernels do): their residency is set by the LDS alone
 template <int L_, int N_, int Q_, int KS_> constexpr bool ro_one_region() { return N_ > 24 && Q_ != L_ && Q_ > 0; }
 static bool ro_one_region_rt(int L, int N, int q, bool) { return N > 24 && q != L && q > 0; }
+// dimension sets whose step keeps the state in registers (step_v2.h): their roll-out reads and writes the handle's wave image
+template <int L_, int N_, int Q_> constexpr bool ro_v2() { return step_v2_dims(L_, N_, Q_); }
 template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads() {
+  if constexpr (ro_v2<L_, N_, Q_>()) {  // (LDS per trajectory <= 10 KB: sixteen trajectories per CU, 128 registers)
+    constexpr size_t pw2 = v2_lds_elems(L_, Q_, N_), cap2 = 160 * 1024 / sizeof(double), wgs2 = cap2 / (pw2 * NW);
+    constexpr size_t fit2 = wgs2 * NW > 16 ? 16 : (wgs2 * NW < (size_t)NW ? (size_t)NW : wgs2 * NW);
+    return fit2 > 8 ? 1024 : (fit2 > 4 ? 512 : 256);
+  }
   constexpr size_t pw = ro_one_region<L_, N_, Q_, KS_>()
                             ? (((size_t)step_region1(L_, N_) + (2 * L_ <= N_ * Q_ ? 0 : ((2 * L_ + 1) & ~1)) + vec_elems_one_region(2, L_, Q_, N_) + 1) & ~(size_t)1)
                             : ((step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1);
@@ -86,8 +94,11 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
   int cur = ra.cur;
   // lane i < L: psi_i(x_{k-1}) of this wave's trajectory, carried from step to step (a launch that continues an earlier
   // one starts from the handle's copy)
+  // (register-state step: lanes i and 32 + i both carry psi_i -- the two halves of the wave run the v and the w chain)
+  constexpr bool V2 = ro_v2<L_, N_, Q_>();
+  constexpr int PSI_MASK = V2 ? 31 : 63;
   double psi_prev_reg = 0.0;
-  if (live && ra.have_prev && (int)(tid0 & 63) < L) psi_prev_reg = ra.psi[ra.cur ^ 1][(size_t)b * L + (tid0 & 63)];
+  if (live && ra.have_prev && (int)(tid0 & PSI_MASK) < L) psi_prev_reg = ra.psi[ra.cur ^ 1][(size_t)b * L + (tid0 & PSI_MASK)];
   typedef const RolloutArgs<double> __attribute__((address_space(4))) * kernarg_ptr_t;
   for (int k = 0; k < ra.steps; ++k) {
     // The step arguments stay in the kernel-argument segment and are re-read where they are used: hoisted out
@@ -107,11 +118,11 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
 #endif
     double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
     if constexpr (RBF) {
-      if (live && lane < L) {
+      if (live && (lane & PSI_MASK) < L) {
         double x[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) x[i] = (i < n) ? a.X_rw[(size_t)i * B + b] : 0.0;
-        const double* c = R.cx + (size_t)lane * n;
+        const double* c = R.cx + (size_t)(lane & PSI_MASK) * n;
         if (R.rbf_matlab) {
           double r2 = 0.0;
           for (int i = 0; i < n; ++i) { const double d = x[i] - c[i]; r2 += d * d; }
@@ -226,7 +237,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
         }
         __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
       }
-      if (lane < L) psi_i = sPsi[lane * NC + wv];
+      if ((lane & PSI_MASK) < L) psi_i = sPsi[(lane & PSI_MASK) * NC + wv];
     } else {
       // Cooperative encoder.  Wave w < Hp/16 owns hidden M tile w for the whole K range (two alternating
       // accumulator chains), so bias + ReLU are applied on the accumulator registers and the result is written
@@ -302,7 +313,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
         }
         __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
       }
-      if (lane < L) psi_i = sPsi[lane * 16 + wv];
+      if ((lane & PSI_MASK) < L) psi_i = sPsi[(lane & PSI_MASK) * 16 + wv];
     }
 
 #ifdef KMPC_TRACE
@@ -331,7 +342,12 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       //  registers, 109.7 -> 117.8 M steps/s; its crawling solves are 14 of 327 680 on that workload)
       constexpr bool LOWREG = ro_max_threads<L_, N_, Q_, NW, KS_>() == 1024 && N_ > 24;
       // (y = psi, Q_ == L_: ill-conditioned H, crawling solves are common -- those instantiations keep the register safeguard)
-      step_body<double, 64, L_, N_, Q_, LOWREG, !LOWREG || Q_ == L_, ro_one_region<L_, N_, Q_, KS_>()>(a, sv, bk, wsm);
+      if constexpr (V2) {
+        double* imgb = R.img + (size_t)bk * R.img_stride;
+        step_v2<L_, N_, Q_, LOWREG, !LOWREG>(a, sv, bk, wsm, imgb);
+      } else {
+        step_body<double, 64, L_, N_, Q_, LOWREG, !LOWREG || Q_ == L_, ro_one_region<L_, N_, Q_, KS_>()>(a, sv, bk, wsm);
+      }
       if (R.X_log) {
         __threadfence_block();
         if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
@@ -359,9 +375,6 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
   }
 }
 
-}  // namespace kmpc
-#include "rollout_dyn.h"
-namespace kmpc {
 
 // waves (= trajectories) per workgroup of the fused roll-out.  MLP lift: 16 (one workgroup per CU) or 8 (two per
 // CU); the RBF lift needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.
@@ -371,6 +384,7 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
   size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr, !tableau_saves_lds(N, L)) / sizeof(double) + 1) & ~(size_t)1;
   if (ro_one_region_rt(L, N, q, rbf))
     per_wave = ((size_t)step_region1(L, N) + ro_one_region_r2(n, L, q, N) + vec_elems_one_region(n, L, q, N) + 1) & ~(size_t)1;
+  if (step_v2_dims(L, N, q)) per_wave = v2_lds_elems(L, q, N);  // register-state step: H, the fall-back tableau and vectors only
   if (wstride) *wstride = (int)per_wave;
   size_t elems = per_wave * waves;
   if (rbf) return elems;
@@ -380,19 +394,6 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
 }
 static int g_rollout_workgroup = 0;  // kmpc_set_rollout_workgroup
 void set_rollout_workgroup(int trajectories) { g_rollout_workgroup = trajectories; }
-static int g_dyn_group = -1, g_dyn_timeout = 300;  // kmpc_set_rollout_schedule (-1: not set, take the default / environment)
-void set_rollout_schedule(int group, int timeout_ticks) { g_dyn_group = group; g_dyn_timeout = timeout_ticks; }
-void rollout_schedule(int* group, int* timeout_ticks) {
-  if (g_dyn_group < 0) {  // measurement aids: KMPC_ROLLOUT_DYN = 0..4, KMPC_ROLLOUT_DYN_TIMEOUT in 10 ns ticks
-    const char* e = getenv("KMPC_ROLLOUT_DYN");
-    const char* t = getenv("KMPC_ROLLOUT_DYN_TIMEOUT");
-    g_dyn_group = e ? atoi(e) : 0;
-    if (g_dyn_group < 0 || g_dyn_group > 4) g_dyn_group = 0;
-    if (t && atoi(t) > 0) g_dyn_timeout = atoi(t);
-  }
-  *group = g_dyn_group;
-  *timeout_ticks = g_dyn_timeout;
-}
 static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
   const size_t cap = 160 * 1024 / sizeof(double);
   if (!rbf) {
@@ -401,7 +402,7 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     auto wgs = [&](int w) -> int {
       const size_t e = (rollout_lds_elems(n, L, q, N, false, w, Lp, nullptr) + 63) & ~(size_t)63;
       const int k = (int)(cap / e);
-      const int maxw = (N > 24 && !ro_one_region_rt(L, N, q, false)) ? 8 : 16;  // (long horizons: see ro_max_threads)
+      const int maxw = (N > 24 && !ro_one_region_rt(L, N, q, false) && !step_v2_dims(L, N, q)) ? 8 : 16;  // (long horizons: see ro_max_threads)
       return k * w > maxw ? maxw / w : k;
     };
     if (g_rollout_workgroup) return wgs(g_rollout_workgroup) > 0 ? g_rollout_workgroup : 0;
@@ -444,46 +445,21 @@ static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, siz
   hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_>), dim3(grid), dim3(64 * waves), lds, s, k);
   return hipGetLastError();
 }
-// the kernel without a per-step workgroup barrier (rollout_dyn.h); 16 trajectories per workgroup
-template <int L_, int N_, int Q_, int KS_> static hipError_t launch_rollout_dyn(const RolloutArgs<double>& a, hipStream_t s) {
-  RolloutArgs<double> k = a;
-  step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));
-  const size_t elems = rollout_dyn_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, a.Lp, &k.wstride);
-  k.keep_off = k.wstride * 16;
-  const size_t lds = elems * sizeof(double);
-  if (lds > 160 * 1024 || (size_t)k.wstride < (size_t)2 * a.Hp * 4) return hipErrorInvalidValue;
-  static size_t configured_dev[16] = {};  // (function attributes are per device)
-  size_t& configured = configured_dev[device_slot()];
-  if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_dyn_kernel<L_, N_, Q_, KS_>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
-  hipLaunchKernelGGL((rollout_dyn_kernel<L_, N_, Q_, KS_>), dim3((a.s.B + 15) / 16), dim3(1024), lds, s, k);
-  return hipGetLastError();
-}
-// dimension sets with a barrier-free instantiation (MLP lift only; the RBF lift never had a barrier)
-static bool rollout_dyn_available(int n, int L, int N, int q, int Hp, int Lp) {
-  if (!(L == 20 && N == 20 && q == 2)) return false;
-  int ws = 0;
-  return rollout_dyn_lds_elems(n, L, q, N, Lp, &ws) * sizeof(double) <= 160 * 1024 && ws >= 2 * Hp * 4;
-}
 
 template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
   RolloutArgs<double> k = a;
   const bool rbf = a.lift_rbf != 0;
-  if constexpr (L_ == 20 && N_ == 20 && Q_ == 2) {
-    if (!rbf && a.dyn_group > 0 && rollout_dyn_available(a.s.n, a.s.L, a.s.N, a.s.q, a.Hp, a.Lp)) {
-      if (!a.s.qp_scratch) return hipErrorInvalidValue;
-      return (a.KS == 25 && a.Hp == 112) ? launch_rollout_dyn<L_, N_, Q_, 25>(a, s) : launch_rollout_dyn<L_, N_, Q_, 0>(a, s);
-    }
-  }
+  constexpr bool V2 = ro_v2<L_, N_, Q_>();
   const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
   if (waves == 0) return hipErrorInvalidValue;
   step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));
   if (!a.s.qp_scratch) return hipErrorInvalidValue;
   if (ro_one_region_rt(a.s.L, a.s.N, a.s.q, rbf)) k.s.r2 = ro_one_region_r2(a.s.n, a.s.L, a.s.q, a.s.N);
+  if constexpr (V2) {
+    if (!a.img || a.s.n != 2) return hipErrorInvalidValue;
+    k.s.r1 = v2_region1(N_);
+    k.s.r2 = v2_region2(N_, L_);
+  }
   const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
   k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp, waves));
   const size_t lds = elems * sizeof(double);
@@ -492,7 +468,8 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
   if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1>(k, waves, lds, s);
   // (workgroup sizes whose per-wave regions alone exceed the LDS are not instantiated)
-  constexpr size_t pw = ro_one_region<L_, N_, Q_, 0>()
+  constexpr size_t pw = V2 ? v2_lds_elems(L_, Q_, N_)
+                        : ro_one_region<L_, N_, Q_, 0>()
                             ? (((size_t)step_region1(L_, N_) + (2 * L_ <= N_ * Q_ ? 0 : ((2 * L_ + 1) & ~1)) + vec_elems_one_region(2, L_, Q_, N_) + 1) & ~(size_t)1)
                             : ((step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1);
   constexpr size_t cap = 160 * 1024 / sizeof(double);
@@ -512,6 +489,8 @@ template <typename T> bool rollout_fused_available(int n, int L, int N, int q, i
                     (L == 20 && N == 30 && q == 2) || (L == 32 && N == 40 && q == 2) || (L == 32 && N == 40 && q == 1);
   return inst && rollout_waves(n, L, q, N, rbf, 64) > 0;  // (Lp <= 64)
 }
+// true: the fused roll-out of this dimension set works on the wave image of the state (step_v2.h) instead of the dense blocks
+bool rollout_uses_image(int n, int L, int N, int q) { return n == 2 && step_v2_dims(L, N, q); }
 template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
   if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
   if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))

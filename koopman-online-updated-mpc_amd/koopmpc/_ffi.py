@@ -49,7 +49,6 @@ SIGNATURES = {
     "kmpc_terminal_from_dare": (_I, [_VP, _DP, _D, _I, _D, _I, _DP, C.POINTER(C.c_int32), _VP]),
     "kmpc_rollout_is_fused": (_I, [_VP]),
     "kmpc_set_rollout_workgroup": (_I, [_I]),
-    "kmpc_set_rollout_schedule": (_I, [_I, _I]),
     "kmpc_reset": (_I, [_VP, _VP]),
     "kmpc_state_init": (_I, [_VP, _D, _D, _VP]),
     "kmpc_state_init_from": (_I, [_VP, _DP, _DP, _DP, _DP, _VP]),

@@ -279,39 +279,6 @@ def test_fp32_rls_condense_qp(torch_mod, KM):
         assert np.abs(U[:, b] - Uo).max() < 2e-3, b
 
 
-# ------------------------------------------------------------------ the barrier-free schedule of the roll-out
-@pytest.mark.parametrize("group", [4, 3, 1])
-def test_rollout_schedule_does_not_change_the_arithmetic(torch_mod, KM, group):
-    """kmpc_set_rollout_schedule: lift groups formed at run time (no workgroup barrier per step) against the lock-step
-    kernel, cfg2 dimensions, a batch that is not a multiple of the workgroup: same controls, states and models, bit for
-    bit (the group's encoder sums its k-steps in the lock-step kernel's order), status 0 (a bounded spin that ran out would
-    report 9)."""
-    torch = torch_mod
-    from koopmpc import _ffi
-    from koopmpc.synth import initial_states, offline_data, random_mlp_weights
-
-    lib = _ffi.load()
-    L = N = 20
-    B, steps = 150, 25
-    w = random_mlp_weights(2, 100, 3, L, seed=2024)
-    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
-    outs = []
-    try:
-        for grp in (0, group):
-            assert lib.kmpc_set_rollout_schedule(grp, 300) == 0
-            m = KM(n=2, L=L, N=N, batch=B, weights=w)
-            m.offline_fit(*offline_data())
-            X = _t(torch, initial_states(B, seed=7))
-            Ul, Xl = m.rollout("duffing", X, r, steps, step0=95, log=True)
-            outs.append((Ul.cpu().numpy(), Xl.cpu().numpy(), m.get_model()[0].cpu().numpy(), m.status.cpu().numpy(), m.iters.cpu().numpy()))
-    finally:
-        lib.kmpc_set_rollout_schedule(0, 300)
-    assert lib.kmpc_set_rollout_schedule(5, 300) == -1
-    (U0, X0, A0, s0, i0), (U1, X1, A1, s1, i1) = outs
-    assert s0.max() == 0 and s1.max() == 0
-    assert np.array_equal(U0, U1) and np.array_equal(X0, X1) and np.array_equal(A0, A1) and np.array_equal(i0, i1)
-
-
 # ------------------------------------------------------------------ boundary: stateless solve wrapper, result.fun
 def test_mpc_solve_with_the_model_as_an_argument(torch_mod, KM):
     """mpc_solve(A, B, C, xlift, r, lb, ub, Q, R[, P_N]): the reference's own logged models and lifted states
