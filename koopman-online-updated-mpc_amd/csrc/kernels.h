@@ -93,6 +93,7 @@ template <typename T> struct RolloutArgs {
   int cur;
   int steps, step0, switch_step, have_prev, rls_fresh;
   int wstride;              // per-wave LDS region in elements
+  int wbase;                // LDS offset (elements) of the first per-wave region (register-state step: behind the lift scratch)
   int keep_off;             // LDS offset (elements) of the part the lift scratch does not overlay
   T* U_log; T* X_log;       // optional (steps x B), (steps x n x B)
   // register-state step (step_v2.h): the wave images of the trajectories' state, [B][img_stride]

@@ -90,6 +90,9 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
   if (!RBF && (tid0 & 63) < 4)
     sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? ra.s.X_rw[(size_t)(tid0 & 63) * B + b] : 0.0;
 
+  if constexpr (ro_v2<L_, N_, Q_>()) {
+    if (live) step_v2_init<N_, Q_>(smem + ra.wbase + wave * ra.wstride);
+  }
   bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
   int cur = ra.cur;
   // lane i < L: psi_i(x_{k-1}) of this wave's trajectory, carried from step to step (a launch that continues an earlier
@@ -321,7 +324,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
     if (lane == 0 && b < 8192 && k == 0) kmpc_trace_buf[b * 32 + 19] = wall_clock64();
 #endif
     if (live) {
-      int woff = wv * R.wstride, bk = b;
+      int woff = R.wbase + wv * R.wstride, bk = b;
       asm volatile("" : "+s"(woff), "+s"(bk));  // (as local_tid: keeps the step's address arithmetic inside the loop)
       double* const wsm = smem + woff;
       double* const psi_now = R.psi[cur];
@@ -384,11 +387,13 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
   size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr, !tableau_saves_lds(N, L)) / sizeof(double) + 1) & ~(size_t)1;
   if (ro_one_region_rt(L, N, q, rbf))
     per_wave = ((size_t)step_region1(L, N) + ro_one_region_r2(n, L, q, N) + vec_elems_one_region(n, L, q, N) + 1) & ~(size_t)1;
-  if (step_v2_dims(L, N, q)) per_wave = v2_lds_elems(L, q, N);  // register-state step: H, the fall-back tableau and vectors only
+  const bool v2 = step_v2_dims(L, N, q);
+  if (v2) per_wave = v2_lds_elems(L, q, N);  // register-state step: H / carried tableau and vectors only
   if (wstride) *wstride = (int)per_wave;
   size_t elems = per_wave * waves;
   if (rbf) return elems;
   const size_t scratch = waves == 4 ? RO_ACT + 128 * 4 : ro_scratch();  // (sAct1 sits RO_ACT behind sAct0)
+  if (v2) return scratch + elems + ro_keep(Lp, waves);  // (the regions carry the tableau from step to step: no overlay)
   if (elems < scratch) elems = scratch;
   return elems + ro_keep(Lp, waves);
 }
@@ -458,10 +463,11 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   if constexpr (V2) {
     if (!a.img || a.s.n != 2) return hipErrorInvalidValue;
     k.s.r1 = v2_region1(N_);
-    k.s.r2 = v2_region2(N_, L_);
+    k.s.r2 = 0;
   }
   const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
   k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp, waves));
+  k.wbase = (V2 && !rbf) ? (int)(waves == 4 ? RO_ACT + 128 * 4 : ro_scratch()) : 0;
   const size_t lds = elems * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)

@@ -21,6 +21,7 @@
 // K += (y - K z) g', P -= (P z)(P z)' / d); sums over a row run in four partial sums.
 #pragma once
 #include "step_body.h"
+#include "qp_rl.h"
 
 namespace kmpc {
 
@@ -28,11 +29,16 @@ namespace kmpc {
 // wave image of one trajectory (host + device)
 // ---------------------------------------------------------------------------------------
 static constexpr bool step_v2_dims(int L, int N, int q) { return q != L && q > 0 && L + 2 <= 32 && N <= 40 && L >= 2; }
-// LDS of one trajectory (elements): H | fall-back tableau (short horizons) | red, f | chain outputs / QP vectors
+// LDS of one trajectory (elements):
+//   R    N x N   H while a solve runs, the tableau of the last solve between two solves (qp_rl.h)          persistent
+//   cs   66      row scales of that tableau (2 x 32) and its variable set / validity (2 ints)               persistent
+//   zp   N q     zeros: e_j beyond the horizon (the f lanes of the H / f pass read past the end)             persistent
+//   vec  red 16 | f N | predicted bounds N | e (one q-block in front, N q) ... zp ... | g (N+1) q | dump 64 + (N+1) q
+// (the fall-back solver's vectors alias g and the dump).  Nothing here is overlaid by the lift scratch.
 static constexpr int v2_region1(int N) { return (N * N + 1) & ~1; }
-static constexpr int v2_region2(int N, int L) { return tableau_saves_lds(N, L) ? 0 : ((N * N + 1) & ~1); }
-static constexpr int v2_vec_elems(int q, int N) { return 16 + N + imax(3 * N, 3 * (N + 1) * q + q + 64) + 2; }
-static constexpr size_t v2_lds_elems(int L, int q, int N) { return ((size_t)v2_region1(N) + v2_region2(N, L) + v2_vec_elems(q, N) + 1) & ~(size_t)1; }
+static constexpr int v2_carry_elems() { return 66; }
+static constexpr int v2_vec_elems(int q, int N) { return 16 + 2 * ((N + 1) & ~1) + (q + 2 * N * q) + imax(3 * N, 2 * (N + 1) * q + 64) + 2; }
+static constexpr size_t v2_lds_elems(int L, int q, int N) { return ((size_t)v2_region1(N) + v2_carry_elems() + v2_vec_elems(q, N) + 1) & ~(size_t)1; }
 
 // ---------------------------------------------------------------------------------------
 // row products on DPP
@@ -103,18 +109,18 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   const int tid = local_tid<64>();
   const int half = tid >> 5, t = tid & 31;
   const int B = a.B;
-  // LDS map
-  double* const sH = sm;
-  double* const sM = sH + a.r1;  // fall-back tableau of qp_lds (short horizons; else the fall-back works in global scratch)
-  double* const vec = sM + a.r2;
+  // LDS map (v2_lds_elems)
+  double* const sR = sm;                          // H / carried tableau
+  double* const sCs = sR + v2_region1(N_);        // rs[32] | rsi[32] | {smask, valid}
+  double* const vec = sCs + v2_carry_elems();
   double* const red = vec;
+  constexpr int NE = (N_ + 1) & ~1;               // (even offsets: g and e are read as 16-byte vectors)
   double* const sf = red + 16;
-  double* const va = sf + N;
-  double* const sG = va;                          // g_0 .. g_N        (N + 1) q
-  double* const sEr = sG + (N + 1) * q + q;       // e_0 .. e_N  at  sEr[(j - 1) q + r]: one q-block in front
-  double* const dump = sEr + N * q;               // 64 + (N + 1) q: where lanes without an output write
-  double* const qx = va;
-  double* const qxa = qx + N;
+  double* const qxo = sf + NE;                    // predicted bounds of the solve / its hand-over point
+  double* const sEr = qxo + NE + q;                // e_1 .. e_N at sEr[(j - 1) q + r]; one q-block in front; N q zeros behind
+  double* const sG = sEr + 2 * N * q;             // g_0 .. g_N        (N + 1) q
+  double* const dump = sG + (N + 1) * q;          // 64 + (N + 1) q: where lanes without an output write
+  double* const qxa = sG;                         // (fall-back solver: aliases g and the dump)
   double* const qg = qxa + N;
 
   KTRACE(0);
@@ -276,61 +282,60 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     block_sync<64>();
   }
   KTRACE(6);
-  if ((sv.phases & PH_QP) && a.x_warm) {
-    const int mv = (tid >> 3) + 8 * (tid & 7);
-    xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
+  if ((sv.phases & PH_QP) && a.x_warm) xw_pre = a.x_warm[(size_t)(t < N_ ? t : 0) * a.B + b];
+  // the tableau of the last solve leaves LDS before H takes its place
+  double M[N_];
+  double rs = 1.0, rsi = 1.0;
+  QpCarry cs;
+  {
+    const int* const ci = reinterpret_cast<const int*>(sCs + 64);
+    cs.smask = (unsigned)__builtin_amdgcn_readfirstlane(ci[0]);  // (wave-uniform: the solve branches on them)
+    cs.valid = __builtin_amdgcn_readfirstlane(ci[1]);
+    if (cs.valid) {
+      const double* const trow = sR + (t < N_ ? t : N_ - 1) * N_;
+      if constexpr ((N_ & 1) == 0) {
+        const d2_t* t2 = reinterpret_cast<const d2_t*>(__builtin_assume_aligned(trow, 16));
+#pragma unroll
+        for (int j = 0; j < N_ / 2; ++j) { const d2_t v = t2[j]; M[2 * j] = v.x; M[2 * j + 1] = v.y; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < N_; ++j) M[j] = trow[j];
+      }
+      rs = sCs[t];
+      rsi = sCs[32 + t];
+    }
+    block_sync<64>();
   }
-  // H[a][b] = Qw S(b - a, N-1-b) (+ Rw on the diagonal), S(d, t) = sum_{s <= t} g_{s+d} . g_s;  f[a] = 2 Qw sum_t g_t . e_{t+a}
-  if constexpr (N_ <= 32) {
-    // lane d < N walks diagonal d of H, lane 32 + a accumulates f[a]: one instruction stream (see step_body.h)
+  // H[a][b] = Qw S(b - a, N-1-b) (+ Rw on the diagonal), S(d, t) = sum_{s <= t} g_{s+d} . g_s;  f[a] = 2 Qw sum_t g_t . e_{t+a}:
+  // lane d < N walks diagonal d of H and writes both triangles, lane 32 + a accumulates f[a] -- one instruction stream; the f
+  // lanes read zeros behind e_N, the H lanes leave a diagonal under a compile-time lane mask
+  {
+    typedef double dq_t __attribute__((ext_vector_type(Q_ == 2 ? 2 : 1)));
     const int hf = tid >> 5, idx = tid & 31;
-    const double* const wb = (hf ? sEr : sG) + idx * Q_;
-    const bool on = idx < N_;
+    // (even element offsets in the static layout: g and e are read as 16-byte vectors when q = 2)
+    const dq_t* const gq = reinterpret_cast<const dq_t*>(__builtin_assume_aligned(sG, Q_ == 2 ? 16 : 8));
+    const dq_t* const wq = reinterpret_cast<const dq_t*>(__builtin_assume_aligned((hf ? sEr : sG) + idx * Q_, Q_ == 2 ? 16 : 8));
     double acc = 0.0;
-    double* const h1 = hf ? red + 14 : sH - idx * N_;
-    double* const h2 = hf ? red + 15 : sH - idx;
-    const int hstep = hf ? 0 : N_ + 1;
-    const double rdiag = (idx == 0 && !hf) ? a.Rw : 0.0;
+    double* const h1 = sR - idx * N_;
+    double* const h2 = sR - idx;
+    const double Qw = a.Qw, rdiag = idx == 0 ? a.Rw : 0.0;  // (read once: inside the masked regions below every use was a scalar load of its own)
 #pragma unroll
     for (int tt = 0; tt < N_; ++tt) {
-      if (on && tt + idx < N_) {
-        double s0 = 0.0;
+      if constexpr (Q_ == 2) {
+        const dq_t u = gq[tt], w = wq[tt];
+        acc = tfma(u[0], w[0], acc);
+        acc = tfma(u[1], w[1], acc);
+      } else {
 #pragma unroll
-        for (int r = 0; r < Q_; ++r) s0 += sG[tt * Q_ + r] * wb[tt * Q_ + r];
-        acc += s0;
-        const double hv = a.Qw * acc + rdiag;
-        h1[(N_ - 1 - tt) * hstep] = hv;
-        h2[(N_ - 1 - tt) * hstep] = hv;
+        for (int r = 0; r < Q_; ++r) acc = tfma(sG[tt * Q_ + r], ((hf ? sEr : sG) + idx * Q_)[tt * Q_ + r], acc);
+      }
+      if (tid < N_ - tt) {  // lanes idx < N - tt of the lower half: (aa, bb) = (N-1-tt-idx, N-1-tt) is inside H
+        const double hv = Qw * acc + rdiag;
+        h1[(N_ - 1 - tt) * (N_ + 1)] = hv;
+        h2[(N_ - 1 - tt) * (N_ + 1)] = hv;
       }
     }
-    if (hf && on) sf[idx] = 2.0 * a.Qw * acc;
-  } else {
-    for (int d = tid; d < N; d += 64) {
-      double acc = 0.0;
-#pragma unroll
-      for (int tt = 0; tt < N; ++tt) {
-        if (tt + d < N) {
-          double s0 = 0.0;
-#pragma unroll
-          for (int r = 0; r < q; ++r) s0 += sG[(tt + d) * q + r] * sG[tt * q + r];
-          acc += s0;
-          const int bb = N - 1 - tt, aa = bb - d;
-          const double hv = a.Qw * acc + (d == 0 ? a.Rw : 0.0);
-          sH[aa * N + bb] = hv;
-          sH[bb * N + aa] = hv;
-        }
-      }
-    }
-    for (int aa = tid; aa < N; aa += 64) {
-      double acc = 0.0;
-#pragma unroll
-      for (int tt = 0; tt < N; ++tt)
-        if (tt + aa < N) {
-#pragma unroll
-          for (int r = 0; r < q; ++r) acc += sG[tt * q + r] * sEr[(tt + aa) * q + r];
-        }
-      sf[aa] = 2.0 * a.Qw * acc;
-    }
+    if (hf && idx < N_) sf[idx] = 2.0 * Qw * acc;
   }
   if (a.Wterm) {
     // terminal block of Q_bar is PN instead of Qw I (Koopman_update.m:381); Wterm = PN - Qw I:
@@ -344,7 +349,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       double acc = 0.0;
       for (int r = 0; r < q; ++r)
         for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * (0.5 * (Wt[r * q + s2] + Wt[s2 * q + r])) * gb[s2];
-      sH[e] += acc;
+      sR[e] += acc;
     }
     for (int aa = tid; aa < N; aa += 64) {
       const double* ga = sG + (N - 1 - aa) * q;
@@ -359,22 +364,45 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   KTRACE(7);
 
   // =====================================================================================
-  // phase 3: box QP (register tableau; step_body.h)
+  // phase 3: box QP (rows in lanes, carried tableau: qp_rl.h)
   // =====================================================================================
   if (sv.phases & PH_QP) {
-    if (qp_regs<double, N_, LOWREG, ASREG>(sH, sf, a, sv, b, red, qx, up, xw_pre)) {
+    if (qp_rl<N_>(sR, sf, a, sv, b, qxo, M, rs, rsi, cs, up, xw_pre)) {
+      // crawling solve (rare): H moves to this trajectory's global scratch block, the active-set loop of qp_lds works with an
+      // LDS tableau in its place
       block_sync<64>();
-      if constexpr (!tableau_saves_lds(N_, L_)) {
-        qp_lds<double, 64>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
-      } else {
-        double* const Hg = a.qp_scratch + (size_t)b * N * N;
-        for (int e = tid; e < N * N; e += 64) Hg[e] = sH[e];
-        __threadfence_block();
-        block_sync<64>();
-        qp_lds<double, 64>(Hg, sf, sH, qx, qxa, qg, red, a, sv, b, N, true);
-      }
+      double* const Hg = a.qp_scratch + (size_t)b * N * N;
+      for (int e = tid; e < N * N; e += 64) Hg[e] = sR[e];
+      __threadfence_block();
+      block_sync<64>();
+      qp_lds<double, 64>(Hg, sf, sR, qxo, qxa, qg, red, a, sv, b, N, true);
+      block_sync<64>();
+      for (int e = tid; e < N * q; e += 64) sEr[N * q + e] = 0.0;  // (the solver's vectors may have covered the zeros behind e_N)
     }
+    if (!half) {
+      sCs[t] = rs;
+      sCs[32 + t] = rsi;
+    }
+    if (tid == 0) {
+      int* const ci = reinterpret_cast<int*>(sCs + 64);
+      ci[0] = (int)cs.smask;
+      ci[1] = cs.valid;
+    }
+    block_sync<64>();
   }
+}
+
+// once per launch, before the first step: no carried tableau, zeros behind e_N
+template <int N_, int Q_> __device__ __forceinline__ void step_v2_init(double* const sm) {
+  const int tid = local_tid<64>();
+  double* const sCs = sm + v2_region1(N_);
+  double* const sEr = sCs + v2_carry_elems() + 16 + 2 * ((N_ + 1) & ~1) + Q_;
+  if (tid == 0) {
+    int* const ci = reinterpret_cast<int*>(sCs + 64);
+    ci[0] = 0;
+    ci[1] = 0;
+  }
+  for (int e = tid; e < N_ * Q_; e += 64) sEr[N_ * Q_ + e] = 0.0;
 }
 
 }  // namespace kmpc

@@ -1078,7 +1078,10 @@ def test_rollout_equals_step_plus_plant_loop(torch_mod, KM, lift, L, N, output, 
     assert float((X1 - X2).abs().max()) < 1e-9
     assert torch.equal(st1, st2)  # (the random model of the lifted-output case has a few degenerate QPs: status 1 on both sides)
     if lift == "mlp" and B < 4096:
-        assert int(st1.max().item()) == 0
+        # status 0 everywhere, except that ONE trajectory of the random model may meet a numerically singular QP right after the
+        # RLS reset (cond(H) = 9e13 at (L, N) = (20, 20), step 5, tools/dbg/status_debug.py: the stateless solve of the same H, f
+        # reports it too) -- it is flagged (status 1) on both sides, never silently wrong
+        assert int(st1.max().item()) <= 1 and int((st1 != 0).sum().item()) <= 1
     assert int((its1 - its)[st2 == 0].abs().max()) <= 2  # refinement solves may differ by rounding
     # the handles are in the same state: one more step agrees
     u1, u2 = m1.step(X1, r).clone(), m2.step(X2, r).clone()
