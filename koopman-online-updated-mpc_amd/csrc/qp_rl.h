@@ -153,7 +153,7 @@ struct QpCarry {  // what a solve leaves for the next one (registers of the step
 // Return true: the solve has to continue in the active-set loop of qp_lds from qx_out (H is still in sR; nothing carried).
 template <int N_>
 __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const StepArgs<double>& a, const StepVar<double>& sv, const int b,
-                                      double* qx_out, double (&M)[N_], double& rs, double& rsi, QpCarry& cs, double up, double xw_pre) {
+                                      double* qx_out, double* u_slot, double (&M)[N_], double& rs, double& rsi, QpCarry& cs, double up, double xw_pre) {
   typedef double d2_t __attribute__((ext_vector_type(2)));
   const int tid = local_tid<64>(), half = tid >> 5, t = tid & 31;
   const bool own = t < N_;
@@ -375,6 +375,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   }
   if (tid == 0) {
     const double uout = a.du_mode ? uprev + x : x;  // U0 = U0 + dU*(1)   (Tank_System.m:192)
+    *u_slot = x;  // (the first move, for a covariance update done ahead: step_v2.h)
     if (sv.U0) sv.U0[b] = uout;
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)

@@ -89,6 +89,9 @@ template <typename T> struct StepVar {
   // solve-only launches of the shared-model step: H is ONE matrix for the whole batch and is read where it lies (global memory,
   // L1 / L2 hits) instead of being staged into every trajectory's LDS -- the launch then needs LDS for its vectors only
   bool h_global = false;
+  // register-state step (step_v2.h): the covariance half of this step's RLS update was done at the end of the previous step /
+  // is to be done for the next one at the end of this step
+  int cov_done = 0, cov_ahead = 0;
 };
 
 // e = tid, tid + TPB, ... < count.  With a compile-time COUNT the loop is fully unrolled, so that the loads of all

@@ -31,12 +31,13 @@ namespace kmpc {
 static constexpr bool step_v2_dims(int L, int N, int q) { return q != L && q > 0 && L + 2 <= 32 && N <= 40 && L >= 2; }
 // LDS of one trajectory (elements):
 //   R    N x N   H while a solve runs, the tableau of the last solve between two solves (qp_rl.h)          persistent
-//   cs   66      row scales of that tableau (2 x 32) and its variable set / validity (2 ints)               persistent
+//   cs   130     row scales of that tableau (2 x 32), its variable set / validity (2 ints), the gains of a covariance
+//                update done ahead (64)                                                                       persistent
 //   zp   N q     zeros: e_j beyond the horizon (the f lanes of the H / f pass read past the end)             persistent
 //   vec  red 16 | f N | predicted bounds N | e (one q-block in front, N q) ... zp ... | g (N+1) q | dump 64 + (N+1) q
 // (the fall-back solver's vectors alias g and the dump).  Nothing here is overlaid by the lift scratch.
 static constexpr int v2_region1(int N) { return (N * N + 1) & ~1; }
-static constexpr int v2_carry_elems() { return 66; }
+static constexpr int v2_carry_elems() { return 130; }
 static constexpr int v2_vec_elems(int q, int N) { return 16 + 2 * ((N + 1) & ~1) + (q + 2 * N * q) + imax(3 * N, 2 * (N + 1) * q + 64) + 2; }
 static constexpr size_t v2_lds_elems(int L, int q, int N) { return ((size_t)v2_region1(N) + v2_carry_elems() + v2_vec_elems(q, N) + 1) & ~(size_t)1; }
 
@@ -111,7 +112,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   const int B = a.B;
   // LDS map (v2_lds_elems)
   double* const sR = sm;                          // H / carried tableau
-  double* const sCs = sR + v2_region1(N_);        // rs[32] | rsi[32] | {smask, valid}
+  double* const sCs = sR + v2_region1(N_);        // rs[32] | rsi[32] | {smask, valid} | gains of rls_cov [64]
+  double* const sCov = sCs + 66;
   double* const vec = sCs + v2_carry_elems();
   double* const red = vec;
   constexpr int NE = (N_ + 1) & ~1;               // (even offsets: g and e are read as 16-byte vectors)
@@ -138,15 +140,19 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   }
 
   // =====================================================================================
-  // phase 1: recursive least squares in registers
+  // phase 1: recursive least squares in registers.  The covariance half -- inv_K_G and bar_Q, which only need the regressor
+  // z = [psi(x_{k-1}); u_{k-1}] -- normally ran at the END of the previous step (rls_cov below, sv.cov_done): its state then
+  // travels while the waves of the workgroup are out of step with each other, not all at once behind the lift's barrier,
+  // and only the model half (16 x 3.9 KB per CU) is read here.
   // =====================================================================================
   double R1[NC];
   const int slot1 = t < S1 ? t : S1 - 1;
   const d2_t* const im = reinterpret_cast<const d2_t*>(img);
   d2_t* const imw = reinterpret_cast<d2_t*>(img);
   const double psin = sv.psi_now_v;
-  if (sv.phases & PH_RLS) {
-    const bool fu = sv.first_update != 0;
+  // inv_K_G <- (inv_K_G - Pz Pz' / d) / lam ; bar_Q <- bar_Q - (Q psi)(Q psi)' / dc        duffing.py:931-932, 947-951
+  // returns lanes < p: g_i = (P z)_i / d, lanes 32 + i: h_i = (bar_Q psi)_i / dc  (the gains of the model half)
+  auto rls_cov = [&](const double z) -> double {
     const int slot2 = half ? P_ + (t < L_ ? t : L_ - 1) : (t < P_ ? t : P_ - 1);
     double R2[NC];
 #pragma unroll
@@ -154,6 +160,44 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       const d2_t v = im[c * S2 + slot2];
       R2[2 * c] = v.x; R2[2 * c + 1] = v.y;
     }
+    double zv0, zv1;
+    half_gather(z, zv0, zv1);
+    double a2[4] = {0.0, 0.0, 0.0, 0.0};
+    rowdot1<P_, NC>(a2, zv0, zv1, R2);
+    const double acc2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);  // lanes < p: (P z)_i ; lanes 32 + i: (bar_Q psi)_i
+    // d = lam + z'Pz (lanes 0-31), dc = 1 + psi' bar_Q psi (lanes 32-63): one sum per half
+    double s = ((half && t >= L_) ? 0.0 : z) * acc2;
+    s += dpp_shr(s, 1);
+    s += dpp_shr(s, 2);
+    s += dpp_shr(s, 4);
+    s += dpp_shr(s, 8);
+    double rt = 0.0;
+    fmac_rowbcast<15, true>(rt, s, 1.0);  // the total of this lane's 16-lane row
+    double r0, r1;
+    half_gather(rt, r0, r1);
+    const double dd = (half ? 1.0 : a.lam) + (r0 + r1);
+    const double dinv = 1.0 / dd;
+    const double c2 = -acc2 * dinv;
+    double w0, w1;
+    half_gather(acc2, w0, w1);
+    rowupd<P_, NC, L_>(R2, w0, w1, c2);
+    if (a.lam != 1.0) {
+      const double sc = half ? 1.0 : 1.0 / a.lam;
+#pragma unroll
+      for (int c = 0; c < P_; ++c) R2[c] *= sc;
+    }
+    if (half ? t < L_ : t < P_) {
+#pragma unroll
+      for (int c = 0; c < CP; ++c) {
+        d2_t v;
+        v.x = R2[2 * c]; v.y = R2[2 * c + 1];
+        imw[c * S2 + slot2] = v;
+      }
+    }
+    return acc2 * dinv;
+  };
+  if (sv.phases & PH_RLS) {
+    const bool fu = sv.first_update != 0;
     if (!fu) {
 #pragma unroll
       for (int c = 0; c < CP; ++c) {
@@ -169,51 +213,18 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     const double xn = sv.x_next ? sv.x_next[xr] : a.x_now[(size_t)xr * B + b];
     // z = [psi(x_{k-1}); u_{k-1}] in the lanes of both halves
     const double z = t < L_ ? sv.psi_prev_v : (t == L_ ? up : 0.0);
+    KTRACE(1);
+    const double u2 = sv.cov_done ? sCov[tid] : rls_cov(z);
+    KTRACE(2);
     double zv0, zv1;
     half_gather(z, zv0, zv1);
-    KTRACE(1);
-    double a2[4] = {0.0, 0.0, 0.0, 0.0}, a1[4] = {0.0, 0.0, 0.0, 0.0};
-    rowdot2<P_, NC>(a2, a1, zv0, zv1, R2, R1);
-    const double acc2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);  // lanes < p: (P z)_i ; lanes 32 + i: (bar_Q psi)_i
+    double a1[4] = {0.0, 0.0, 0.0, 0.0};
+    rowdot1<P_, NC>(a1, zv0, zv1, R1);
     const double acc1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);  // [A B] rows: (K z)_r ; C rows: (C psi)_r
-    // d = lam + z'Pz (lanes 0-31), dc = 1 + psi' bar_Q psi (lanes 32-63): one sum per half
-    double s = ((half && t >= L_) ? 0.0 : z) * acc2;
-    s += dpp_shr(s, 1);
-    s += dpp_shr(s, 2);
-    s += dpp_shr(s, 4);
-    s += dpp_shr(s, 8);
-    double rt = 0.0;
-    fmac_rowbcast<15, true>(rt, s, 1.0);  // the total of this lane's 16-lane row
-    double r0, r1;
-    half_gather(rt, r0, r1);
-    const double dd = (half ? 1.0 : a.lam) + (r0 + r1);
-    const double dinv = 1.0 / dd;
-    KTRACE(2);
-    // inv_K_G <- (inv_K_G - Pz Pz' / d) / lam ; bar_Q <- bar_Q - (Q psi)(Q psi)' / dc        duffing.py:931-932, 947-951
-    {
-      const double c2 = -acc2 * dinv;
-      double w0, w1;
-      half_gather(acc2, w0, w1);
-      rowupd<P_, NC, L_>(R2, w0, w1, c2);
-      if (a.lam != 1.0) {
-        const double sc = half ? 1.0 : 1.0 / a.lam;
-#pragma unroll
-        for (int c = 0; c < P_; ++c) R2[c] *= sc;
-      }
-      if (half ? t < L_ : t < P_) {
-#pragma unroll
-        for (int c = 0; c < CP; ++c) {
-          d2_t v;
-          v.x = R2[2 * c]; v.y = R2[2 * c + 1];
-          imw[c * S2 + slot2] = v;
-        }
-      }
-    }
     KTRACE(3);
     // [A B] <- ([A B] - K z g') / lam + y g' = K / lam + (e / lam + y (1 - 1/lam)) g',  g = Pz / d   (Koopman_update.m:270-274;
     // lam = 1: K + e g', duffing.py:927-938);  C <- C + (x_{k+1} - C psi) h',  h = bar_Q psi / dc          duffing.py:943-953
     {
-      const double u2 = acc2 * dinv;
       double gall, hall;
       halves_both(u2, gall, hall);
       double g0, g1, h0, h1;
@@ -367,7 +378,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   // phase 3: box QP (rows in lanes, carried tableau: qp_rl.h)
   // =====================================================================================
   if (sv.phases & PH_QP) {
-    if (qp_rl<N_>(sR, sf, a, sv, b, qxo, M, rs, rsi, cs, up, xw_pre)) {
+    if (qp_rl<N_>(sR, sf, a, sv, b, qxo, red + 15, M, rs, rsi, cs, up, xw_pre)) {
       // crawling solve (rare): H moves to this trajectory's global scratch block, the active-set loop of qp_lds works with an
       // LDS tableau in its place
       block_sync<64>();
@@ -378,6 +389,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       qp_lds<double, 64>(Hg, sf, sR, qxo, qxa, qg, red, a, sv, b, N, true);
       block_sync<64>();
       for (int e = tid; e < N * q; e += 64) sEr[N * q + e] = 0.0;  // (the solver's vectors may have covered the zeros behind e_N)
+      if (tid == 0) red[15] = qxo[0];
     }
     if (!half) {
       sCs[t] = rs;
@@ -389,6 +401,11 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       ci[1] = cs.valid;
     }
     block_sync<64>();
+    if (sv.cov_ahead) {
+      // the covariance half of the NEXT step's update: its regressor [psi(x_k); u_k] is complete now
+      const double uk = (a.du_mode ? up : 0.0) + red[15];  // (the solve leaves its first move there)
+      sCov[tid] = rls_cov(t < L_ ? psin : (t == L_ ? uk : 0.0));
+    }
   }
 }
 
