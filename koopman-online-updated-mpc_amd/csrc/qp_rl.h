@@ -263,7 +263,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
           carried = false;
           rebuild = false;
         }
-        rl_sweep_set<N_>(M, rs, rsi, Smask ^ Fmask, Smask, Fmask, broke, pass == 1, t, half);
+        if (Smask != Fmask) rl_sweep_set<N_>(M, rs, rsi, Smask ^ Fmask, Smask, Fmask, broke, pass == 1, t, half);  // (one test instead of N when nothing changes sides)
         if (!broke || pass == 1) break;
         if (!carried) ++refresh;  // (a carried tableau that breaks down is simply replaced; only fresh ones count towards giving up)
         rebuild = true;  // pass 1: from 2H, dropping a variable whose pivot fails
