@@ -42,6 +42,13 @@ enum {
   KMPC_OUT_LIFT = 1  /* y = lifted state (vanderpol.py:456-459); q = L, C not used        */
 };
 enum { KMPC_PLANT_DUFFING = 0, KMPC_PLANT_VDP = 1, KMPC_PLANT_TANK = 2 /* Tank_System.m:9-10, 194-195, 211 */ };
+/* OR-ed to KMPC_PLANT_DUFFING / KMPC_PLANT_VDP: the Runge-Kutta step as the MATLAB scripts write it, k4 = f(x + h k1) instead
+ * of f(x + h k3) (Koopman_update.m:24, Koopman_update_Tracking_Lift.m)                          */
+enum { KMPC_PLANT_RK4_MATLAB = 16 };
+/* kmpc_config.lift_offset: the lifts of the MATLAB scripts on top of the encoder (KMPC_LIFT_MLP only)
+ *   KMPC_LIFT_OFFSET_PSI0    psi(x) - psi(0)               Koopman_update_Tracking_Lift.m:65   (L = encoder outputs)
+ *   KMPC_LIFT_OFFSET_X_PSI0  [x; psi(x)] - [0; psi(0)]     Koopman_update.m:67, 70             (L = n + encoder outputs) */
+enum { KMPC_LIFT_OFFSET_NONE = 0, KMPC_LIFT_OFFSET_PSI0 = 1, KMPC_LIFT_OFFSET_X_PSI0 = 2 };
 
 /* kmpc_step / kmpc_run phases (bit mask) */
 enum { KMPC_PH_RLS = 1, KMPC_PH_CONDENSE = 2, KMPC_PH_QP = 4 };
@@ -68,7 +75,7 @@ typedef struct kmpc_config {
   int32_t cold_start;  /* 0: kmpc_step / kmpc_rollout start each solve at the previous minimiser; 1: always at
                           clip(0), the reference's start (its pastRes_loc stays zeros, duffing.py:634-635, 859).
                           The minimiser is unique, so this only changes the work, not the answer        */
-  int32_t reserved0;   /* keeps the doubles 8-byte aligned; must be 0                              */
+  int32_t lift_offset; /* KMPC_LIFT_OFFSET_* (0: the raw encoder, as the Python scripts use it)                 */
   double lambda;       /* RLS forgetting factor (1.0; Koopman_update.m:258)                */
   double P0;           /* inv_K_G init scale (1e4 duffing.py:929-930; 1e5 vanderpol.py:874)*/
   double barQ0;        /* bar_Q init scale (100 duffing.py:946)                            */
@@ -148,7 +155,8 @@ int kmpc_condense_cost(kmpc_handle* h, const void* psi_dev, const void* ref_dev,
  * mpc_solve(A, B, C, xlift, r, lb, ub, Q, R[, P_N])): condensed QP of the GIVEN models and exact box-QP, nothing of
  * the handle's estimator state is read or written.  A_dev [B][L][L], B_dev [B][L], C_dev [B][n][L] (NULL for
  * KMPC_OUT_LIFT), or ONE model for the batch when model_shared = 1; psi_dev (L x B); ref as in kmpc_condense;
- * lb, ub, Qw, Rw override the handle's for this call; PN_host (q x q, may be NULL) the terminal block.
+ * lb, ub, Qw, Rw override the handle's for this call; PN_host (q x q) the terminal block of this call, NULL: the handle's
+ * (kmpc_set_terminal_weight / kmpc_terminal_from_dare; none if the handle has none) -- the cost kmpc_condense and kmpc_step use.
  * Outputs: U_dev (N x B), U0_dev [B] (may be NULL), fun_dev [B] = J at the minimiser (may be NULL), status / iters.
  * Every solve starts at clip(0) like the reference.  B must equal the handle's batch.                          */
 int kmpc_mpc_solve(kmpc_handle* h, const void* A_dev, const void* B_dev, const void* C_dev, int model_shared,
@@ -291,6 +299,10 @@ int kmpc_rollout_is_fused(const kmpc_handle* h);
 int kmpc_set_rollout_workgroup(int trajectories);
 /* algorithmic bytes of one trajectory-step (SURVEY.md 8d formula) for this configuration   */
 int64_t kmpc_algorithmic_bytes_per_step(const kmpc_handle* h);
+/* on = 0: kmpc_step / kmpc_rollout run the loop WITHOUT the online update (the reference's comparison loop,
+ * duffing.py:738-805, vanderpol.py:645-722): no RLS phase, the model stays as kmpc_set_model / kmpc_offline_fit or the
+ * updates so far left it; on = 1 (default) resumes the update with the next transition                               */
+int kmpc_set_online_update(kmpc_handle* h, int on);
 
 #ifdef __cplusplus
 }

@@ -46,6 +46,7 @@ struct kmpc_handle {
                    hipStream_t s) = 0;
   virtual int plant_step(int plant, void* X, const void* U, double h, int sw, int B, hipStream_t s) = 0;
   virtual int set_applied_input(const void* U, int B, hipStream_t s) = 0;
+  virtual int set_online_update(int on) = 0;
   virtual int rollout(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
                       void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) = 0;
   virtual int offline_fit(const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A,
@@ -81,6 +82,11 @@ struct kmpc_handle {
   } while (0)
 
 static inline long even_up(long v) { return (v + 1) & ~1L; }
+// KMPC_PLANT_* with the optional KMPC_PLANT_RK4_MATLAB bit (not for the tank map, which has no Runge-Kutta step)
+static inline bool plant_id_ok(int plant) {
+  const int base = plant & ~KMPC_PLANT_RK4_MATLAB;
+  return base >= KMPC_PLANT_DUFFING && base <= KMPC_PLANT_TANK && !(base == KMPC_PLANT_TANK && (plant & KMPC_PLANT_RK4_MATLAB));
+}
 
 // a device temporary that is freed on every return path (the HIPCHK macro returns from the middle of a function)
 struct DevTmp {
@@ -93,6 +99,8 @@ template <typename T>
 struct Impl : kmpc_handle {
   int n, m, L, p, q, N, B, threads;
   int Hp = 0, Lp = 0;
+  int hid = 0, Lenc = 0;  // effective hidden width / the encoder's own output dimension (lift_offset)
+  std::vector<std::vector<double>> hostW, hostb;  // the layers as given (row-major), kept for finalize_encoder
   long sP, sK, sQ, sC;
   // persistent state
   T *dP = nullptr, *dK = nullptr, *dQ = nullptr, *dC = nullptr;
@@ -168,7 +176,16 @@ struct Impl : kmpc_handle {
     if (c.lift_kind == KMPC_LIFT_MLP) {
       if (c.layers != 2 && c.layers != 3) FAIL(-2, "layers (hidden layers) must be 2 or 3");
       if (c.hidden < 1 || c.hidden > 128) FAIL(-2, "hidden must be in 1..128");
-      Hp = c.hidden <= 112 ? 112 : 128;
+      // lift_offset (the MATLAB scripts' lifts): 1: psi(x) - psi(0) (Koopman_update_Tracking_Lift.m:65) -- an output bias;
+      // 2: [x; psi(x)] - [0; psi(0)] (Koopman_update.m:67, L = n + the encoder's outputs) -- 2n more hidden units carry
+      // relu(x), relu(-x) through the layers with identity weights and the first n output rows read x = relu(x) - relu(-x)
+      // back (exact: one of the two is zero).  Either way the kernels see an ordinary encoder (finalize_encoder).
+      if (c.lift_offset < 0 || c.lift_offset > 2) FAIL(-2, "lift_offset must be 0, 1 or 2");
+      hid = c.hidden + (c.lift_offset == 2 ? 2 * n : 0);
+      Lenc = L - (c.lift_offset == 2 ? n : 0);
+      if (Lenc < 1) FAIL(-2, "lift_offset = 2 needs L > n (L = n + the encoder's output dimension)");
+      if (hid > 128) FAIL(-2, "hidden + 2 n must not exceed 128 with lift_offset = 2");
+      Hp = hid <= 112 ? 112 : 128;
       Lp = ((L + 15) / 16) * 16;
       HIPCHK(hipMalloc(&dW1, sizeof(T) * Hp * 4));
       HIPCHK(hipMalloc(&db1, sizeof(T) * Hp));
@@ -179,7 +196,10 @@ struct Impl : kmpc_handle {
       HIPCHK(hipMalloc(&dWo, sizeof(T) * Lp * Hp));
       HIPCHK(hipMalloc(&dbo, sizeof(T) * Lp));
       layer_set.assign(c.layers + 1, false);
+      hostW.assign(c.layers + 1, std::vector<double>());
+      hostb.assign(c.layers + 1, std::vector<double>());
     } else {
+      if (c.lift_offset != 0) FAIL(-2, "lift_offset applies to the MLP encoder only");
       HIPCHK(hipMalloc(&dcx, sizeof(T) * L * n));
     }
     return reset(nullptr);
@@ -232,20 +252,66 @@ struct Impl : kmpc_handle {
     const int nl = cfg.layers + 1;  // linear layers
     if (layer < 0 || layer >= nl) FAIL(-3, "layer index out of range");
     const int in_dim = layer == 0 ? n : cfg.hidden;
-    const int out_dim = layer == nl - 1 ? L : cfg.hidden;
+    const int out_dim = layer == nl - 1 ? Lenc : cfg.hidden;
     if (rows != out_dim || cols != in_dim) FAIL(-3, "encoder layer shape does not match the configuration");
-    int rc;
-    if (layer == 0) {
-      if ((rc = upload_padded(dW1, W, rows, cols, Hp, 4))) return rc;
-      if ((rc = upload_padded(db1, b, 1, rows, 1, Hp))) return rc;
-    } else if (layer == nl - 1) {
-      if ((rc = upload_padded(dWo, W, rows, cols, Lp, Hp))) return rc;
-      if ((rc = upload_padded(dbo, b, 1, rows, 1, Lp))) return rc;
-    } else {
-      if ((rc = upload_padded(dWh[layer - 1], W, rows, cols, Hp, Hp))) return rc;
-      if ((rc = upload_padded(dbh[layer - 1], b, 1, rows, 1, Hp))) return rc;
-    }
+    hostW[layer].assign(W, W + (size_t)rows * cols);
+    hostb[layer].assign(b, b + rows);
     layer_set[layer] = true;
+    packed_ok = false;
+    for (int k = 0; k < nl; ++k)
+      if (!layer_set[k]) return 0;
+    return finalize_encoder();
+  }
+  // every layer is known: upload the network the kernels evaluate (the given one, or the one that realises lift_offset)
+  int finalize_encoder() {
+    const int nl = cfg.layers + 1, H = cfg.hidden, off = cfg.lift_offset, ex = off == 2 ? 2 * n : 0;
+    std::vector<double> psi0((size_t)Lenc, 0.0);
+    if (off) {  // psi(0) = W_o relu(... relu(b_1)) + b_o, float64 on the host
+      std::vector<double> h(hostb[0]), hn;
+      for (double& v : h) v = v > 0.0 ? v : 0.0;
+      for (int k = 1; k < nl; ++k) {
+        const int rows = k == nl - 1 ? Lenc : H;
+        hn.assign((size_t)rows, 0.0);
+        for (int r = 0; r < rows; ++r) {
+          double acc = hostb[k][r];
+          for (int c2 = 0; c2 < H; ++c2) acc += hostW[k][(size_t)r * H + c2] * h[c2];
+          hn[r] = (k == nl - 1) ? acc : (acc > 0.0 ? acc : 0.0);
+        }
+        h.swap(hn);
+      }
+      psi0 = h;
+    }
+    int rc;
+    for (int k = 0; k < nl; ++k) {
+      const bool first = k == 0, last = k == nl - 1;
+      const int rin = first ? n : H, rout = last ? Lenc : H;          // the given layer
+      const int ein = first ? n : hid, eout = last ? L : hid;         // the effective one
+      std::vector<double> We((size_t)eout * ein, 0.0), be((size_t)eout, 0.0);
+      const int r0 = (last && off == 2) ? n : 0;                       // (the first n output rows are x)
+      for (int r = 0; r < rout; ++r) {
+        for (int c2 = 0; c2 < rin; ++c2) We[(size_t)(r0 + r) * ein + c2] = hostW[k][(size_t)r * rin + c2];
+        be[r0 + r] = hostb[k][r] - (last ? psi0[r] : 0.0);
+      }
+      if (ex) {
+        if (first) {
+          for (int i = 0; i < n; ++i) { We[(size_t)(H + i) * ein + i] = 1.0; We[(size_t)(H + n + i) * ein + i] = -1.0; }
+        } else if (!last) {
+          for (int i = 0; i < ex; ++i) We[(size_t)(H + i) * ein + (H + i)] = 1.0;
+        } else {
+          for (int i = 0; i < n; ++i) { We[(size_t)i * ein + (H + i)] = 1.0; We[(size_t)i * ein + (H + n + i)] = -1.0; }
+        }
+      }
+      if (first) {
+        if ((rc = upload_padded(dW1, We.data(), eout, ein, Hp, 4))) return rc;
+        if ((rc = upload_padded(db1, be.data(), 1, eout, 1, Hp))) return rc;
+      } else if (last) {
+        if ((rc = upload_padded(dWo, We.data(), eout, ein, Lp, Hp))) return rc;
+        if ((rc = upload_padded(dbo, be.data(), 1, eout, 1, Lp))) return rc;
+      } else {
+        if ((rc = upload_padded(dWh[k - 1], We.data(), eout, ein, Hp, Hp))) return rc;
+        if ((rc = upload_padded(dbh[k - 1], be.data(), 1, eout, 1, Hp))) return rc;
+      }
+    }
     packed_ok = false;
     return 0;
   }
@@ -285,12 +351,13 @@ struct Impl : kmpc_handle {
 
   int set_terminal_weight(const double* PN) override {
     wterm_from_dare = false;
-    if (!PN) { have_wterm = false; return 0; }
+    if (!PN) { have_wterm = false; hostPN.clear(); return 0; }
     std::vector<T> w((size_t)q * q);
     for (int r = 0; r < q; ++r)
       for (int c2 = 0; c2 < q; ++c2) w[(size_t)r * q + c2] = (T)(PN[(size_t)r * q + c2] - (r == c2 ? cfg.Qw : 0.0));
     if (!dWt) HIPCHK(hipMalloc(&dWt, sizeof(T) * (size_t)q * q));
     HIPCHK(hipMemcpy(dWt, w.data(), w.size() * sizeof(T), hipMemcpyHostToDevice));
+    hostPN.assign(PN, PN + (size_t)q * q);
     have_wterm = true;
     return 0;
   }
@@ -435,13 +502,13 @@ struct Impl : kmpc_handle {
     int rc = check_lift_ready();
     if (rc) return rc;
     LiftArgs<T> a{};
-    a.B = Bc; a.n = n; a.L = L; a.hidden = cfg.hidden; a.nlayers = cfg.layers;
+    a.B = Bc; a.n = n; a.L = L; a.hidden = hid; a.nlayers = cfg.layers;
     a.X = X; a.Psi = Psi; a.ps_l = ps_l; a.ps_b = ps_b;
     if (cfg.lift_kind == KMPC_LIFT_MLP) {
       a.W1 = dW1; a.b1 = db1; a.Wh[0] = dWh[0]; a.Wh[1] = dWh[1]; a.bh[0] = dbh[0]; a.bh[1] = dbh[1];
       a.Wo = dWo; a.bo = dbo; a.Hp = Hp; a.Lp = Lp;
       if ((rc = pack_encoder(s))) return rc;
-      a.Whp[0] = dWhp[0]; a.Whp[1] = dWhp[1] ? dWhp[1] : dWhp[0]; a.Wop = dWop; a.KSp = (cfg.hidden + 3) / 4;
+      a.Whp[0] = dWhp[0]; a.Whp[1] = dWhp[1] ? dWhp[1] : dWhp[0]; a.Wop = dWop; a.KSp = (hid + 3) / 4;
       HIPCHK(launch_lift_mlp<T>(a, s));
     } else {
       a.cx = dcx; a.eps = (T)cfg.rbf_eps; a.rbf_matlab = cfg.lift_kind == KMPC_LIFT_RBF_MATLAB;
@@ -542,7 +609,18 @@ struct Impl : kmpc_handle {
     StepArgs<T> a = base_args(B);
     a.K = dMsK; a.C = dMsC;
     a.lb = (T)lb_; a.ub = (T)ub_; a.Qw = (T)Qw_; a.Rw = (T)Rw_;
-    a.Wterm = PN ? dMsW : nullptr; a.wterm_per_traj = 0;
+    // the terminal block: P_N of this call, else the handle's (kmpc_set_terminal_weight / kmpc_terminal_from_dare), as
+    // kmpc_condense and kmpc_step use it -- the same cost on every route through the handle
+    if (PN) { a.Wterm = dMsW; a.wterm_per_traj = 0; }
+    else if (have_wterm && Qw_ != cfg.Qw) {
+      if (wterm_from_dare || hostPN.empty()) FAIL(-3, "kmpc_mpc_solve: the handle's terminal block was formed with the handle's Q; pass P_N with another Q");
+      std::vector<T> w((size_t)q * q);
+      for (int r = 0; r < q; ++r)
+        for (int c2 = 0; c2 < q; ++c2) w[(size_t)r * q + c2] = (T)(hostPN[(size_t)r * q + c2] - (r == c2 ? Qw_ : 0.0));
+      HIPCHK(hipMemcpyAsync(dMsW, w.data(), w.size() * sizeof(T), hipMemcpyHostToDevice, s));
+      HIPCHK(hipStreamSynchronize(s));
+      a.Wterm = dMsW; a.wterm_per_traj = 0;
+    }
     a.phases = PH_CONDENSE | PH_QP;
     a.psi_now = (const T*)psi; a.pn_sl = B; a.pn_sb = 1;
     a.ref = (const T*)ref; a.ref_per_traj = rpt;
@@ -557,7 +635,7 @@ struct Impl : kmpc_handle {
                        int init_rls, void* A, void* Bm, void* C, void* Xo, void* Yo, hipStream_t s) override {
     if (!X0 || !U || n_traj < 1 || n_steps < 1) FAIL(-3, "kmpc_generate_and_fit: bad arguments");
     if (n != 2) FAIL(-3, "plants are two-state systems");
-    if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
+    if (!plant_id_ok(plant)) FAIL(-3, "unknown plant");
     const size_t M = (size_t)n_traj * n_steps;
     T *gx = nullptr, *gy = nullptr;
     if (!Xo) HIPCHK(hipMalloc(&gx, sizeof(T) * 2 * M));
@@ -620,7 +698,7 @@ struct Impl : kmpc_handle {
     if ((rc = ensure_dense(s, true))) return rc;
     if (rec) HIPCHK(hipEventRecord(e1, s));
     StepArgs<T> a = base_args(B);
-    a.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
+    a.phases = PH_CONDENSE | PH_QP | ((have_prev && update_on) ? PH_RLS : 0);
     a.first_update = rls_fresh ? 1 : 0;
     a.psi_prev = psi_prev; a.pp_sl = 1; a.pp_sb = L;
     a.psi_now = psi_now; a.pn_sl = 1; a.pn_sb = L;
@@ -636,7 +714,7 @@ struct Impl : kmpc_handle {
       ev_used += 3;
       prof_steps += 1;
     }
-    if (have_prev) rls_fresh = false;
+    if (have_prev && update_on) rls_fresh = false;
     have_prev = true;
     cur ^= 1;
     return 0;
@@ -644,6 +722,10 @@ struct Impl : kmpc_handle {
 
   // the input that was actually applied at the last step, when it is not the one kmpc_step returned (actuator limits, a
   // logged trajectory that is being followed): the next RLS update regresses on it (z = [psi; u], duffing.py:900)
+  // the loop WITHOUT the online update (duffing.py:738-805, vanderpol.py:645-722): kmpc_step / kmpc_rollout skip the RLS phase and
+  // solve with the model as it is; the lift / input history keeps running, so that switching the update back on continues
+  bool update_on = true;
+  int set_online_update(int on) override { update_on = on != 0; return 0; }
   int set_applied_input(const void* U, int Bc, hipStream_t s) override {
     if (!U || Bc != B) FAIL(-3, "kmpc_set_applied_input: U must hold one input per trajectory of the handle");
     HIPCHK(hipMemcpyAsync(dUprev, U, sizeof(T) * (size_t)B, hipMemcpyDeviceToDevice, s));
@@ -652,7 +734,7 @@ struct Impl : kmpc_handle {
 
   int plant_step(int plant, void* X, const void* U, double h, int sw, int Bc, hipStream_t s) override {
     if (n != 2) FAIL(-3, "plants are two-state systems");
-    if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
+    if (!plant_id_ok(plant)) FAIL(-3, "unknown plant");
     PlantArgs<T> a{};
     a.B = Bc; a.plant = plant; a.switched = sw; a.h = (T)h; a.X = (T*)X; a.U = (const T*)U;
     HIPCHK(launch_plant<T>(a, s));
@@ -665,7 +747,7 @@ struct Impl : kmpc_handle {
   int64_t prof_steps = 0;   // profiling: control steps covered by the recorded events
   int pack_encoder(hipStream_t s) {
     if (packed_ok) return 0;
-    const int KS = (cfg.hidden + 3) / 4;
+    const int KS = (hid + 3) / 4;
     const int nhh = cfg.layers - 1;
     for (int k = 0; k < nhh; ++k) {
       if (!dWhp[k]) HIPCHK(hipMalloc(&dWhp[k], sizeof(T) * (size_t)(Hp / 16) * KS * 64));
@@ -699,7 +781,7 @@ struct Impl : kmpc_handle {
       if ((rc = pack_encoder(s))) return rc;
       r.lift_rbf = 0;
       r.W1 = dW1; r.b1 = db1; r.Whp[0] = dWhp[0]; r.Whp[1] = dWhp[1]; r.bh[0] = dbh[0]; r.bh[1] = dbh[1];
-      r.Wop = dWop; r.bo = dbo; r.Hp = Hp; r.Lp = Lp; r.KS = (cfg.hidden + 3) / 4; r.nhh = cfg.layers - 1;
+      r.Wop = dWop; r.bo = dbo; r.Hp = Hp; r.Lp = Lp; r.KS = (hid + 3) / 4; r.nhh = cfg.layers - 1;
     } else {
       r.lift_rbf = 1;
       r.cx = dcx; r.eps = (T)cfg.rbf_eps; r.rbf_matlab = cfg.lift_kind == KMPC_LIFT_RBF_MATLAB ? 1 : 0;
@@ -707,6 +789,7 @@ struct Impl : kmpc_handle {
     r.psi[0] = dPsi[0]; r.psi[1] = dPsi[1]; r.cur = cur;
     r.steps = steps; r.step0 = step0; r.switch_step = switch_step;
     r.have_prev = have_prev ? 1 : 0; r.rls_fresh = rls_fresh ? 1 : 0;
+    r.no_update = update_on ? 0 : 1;
     r.U_log = (T*)Ulog; r.X_log = (T*)Xlog;
     if constexpr (sizeof(T) == 8) {
       if (use_img) {
@@ -731,7 +814,7 @@ struct Impl : kmpc_handle {
       prof_steps += steps;
     }
     // the host-side flags follow the kernel's own bookkeeping
-    if (steps >= 2 || (steps == 1 && have_prev)) rls_fresh = false;
+    if (update_on && (steps >= 2 || (steps == 1 && have_prev))) rls_fresh = false;
     have_prev = true;
     cur ^= (steps & 1);
     return 0;
@@ -749,14 +832,14 @@ struct Impl : kmpc_handle {
     if (st) HIPCHK(hipMemsetAsync(st, 0, sizeof(int32_t) * (size_t)B, s));
     if (it) HIPCHK(hipMemsetAsync(it, 0, sizeof(int32_t) * (size_t)B, s));
     if (n != 2) FAIL(-3, "plants are two-state systems");
-    if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
+    if (!plant_id_ok(plant)) FAIL(-3, "unknown plant");
     if (steps > 0 && fused_rollout_ok())
       return rollout_fused(plant, X, ref, rpt, steps, step0, switch_step, hs, Ulog, Xlog, st, it, s);
     for (int i = 0; i < steps; ++i) {
       const int gi = step0 + i;
       T* u = Ulog ? (T*)Ulog + (size_t)i * B : dU0;
       if (n != 2) FAIL(-3, "plants are two-state systems");
-      if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
+      if (!plant_id_ok(plant)) FAIL(-3, "unknown plant");
       accumulate = true;
       fuse_plant = plant; fuse_switched = (switch_step >= 0 && gi >= switch_step) ? 1 : 0; fuse_h = hs;
       int rc = step(X, ref, rpt, u, nullptr, st, it, s);  // lift kernel + fused RLS/condense/QP/plant kernel
@@ -773,6 +856,7 @@ struct Impl : kmpc_handle {
   double *dGram = nullptr, *dPartial = nullptr;
   T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr, *dTs = nullptr;
   T* dWt = nullptr;  // PN - Qw I (terminal block of Q_bar)
+  std::vector<double> hostPN;  // P_N as given to kmpc_set_terminal_weight
   bool have_wterm = false;
   // kmpc_terminal_from_dare: Riccati workspace and the block(s) it produced ([1] or [B][q*q], PN - Qw I)
   double* dDareP = nullptr; int32_t* dDareIt = nullptr; double* dWtB = nullptr;
@@ -822,7 +906,7 @@ struct Impl : kmpc_handle {
                          int switched, double hstep, hipStream_t s) override {
     if (!X) FAIL(-3, "kmpc_shared_solve_plant: null pointer");
     if (n != 2) FAIL(-3, "plants are two-state systems");
-    if (plant < KMPC_PLANT_DUFFING || plant > KMPC_PLANT_TANK) FAIL(-3, "unknown plant");
+    if (!plant_id_ok(plant)) FAIL(-3, "unknown plant");
     fuse_plant = plant; fuse_switched = switched ? 1 : 0; fuse_h = hstep; fuse_X = X;
     const int rc = shared_solve(delta, ref, U0, Useq, st, it, s);
     fuse_plant = -1; fuse_X = nullptr;
@@ -987,6 +1071,17 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMemcpy(&hd, o, sizeof(hd), hipMemcpyDefault)); o += sizeof(hd);
     if (hd.magic != 0x4b4d5043 || hd.version != 2 || hd.dtype != cfg.dtype || hd.n != n || hd.L != L || hd.N != N || hd.B != B)
       FAIL(-3, "kmpc_state_import: blob does not match this handle");
+    // a consistent header: flags are 0 / 1, the number of terminal blocks is what the flags imply, Riccati blocks only where
+    // kmpc_terminal_from_dare would have produced them (float64)  (round-1 blobs, version 1, are not accepted: they carry no
+    // shared-model / terminal sections and were written with another state order)
+    auto flag01 = [](int32_t v) { return v == 0 || v == 1; };
+    if (!flag01(hd.have_prev) || !flag01(hd.rls_fresh) || !flag01(hd.has_shared) || !flag01(hd.shared_has_samples) || !flag01(hd.have_wterm) ||
+        !flag01(hd.wterm_from_dare) || !flag01(hd.wterm_per_traj))
+      FAIL(-3, "kmpc_state_import: inconsistent header (flags)");
+    const int32_t want_blocks = !hd.have_wterm ? 0 : ((hd.wterm_from_dare && hd.wterm_per_traj) ? B : 1);
+    if (hd.wterm_blocks != want_blocks || (!hd.have_wterm && (hd.wterm_from_dare || hd.wterm_per_traj)) || (hd.wterm_per_traj && !hd.wterm_from_dare))
+      FAIL(-3, "kmpc_state_import: inconsistent header (terminal blocks)");
+    if (hd.wterm_from_dare && sizeof(T) != 8) FAIL(-3, "kmpc_state_import: Riccati terminal blocks need a float64 handle");
     const int64_t wb = !hd.have_wterm ? 0 : (hd.wterm_from_dare ? (int64_t)sizeof(double) : (int64_t)sizeof(T)) * hd.wterm_blocks * q * q;
     const int64_t sb = hd.has_shared ? (int64_t)sizeof(double) * gram_elems() + (int64_t)sizeof(T) * ((int64_t)L * p + (int64_t)n * L) : 0;
     if (bytes < (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * base_elems() + sb + wb) FAIL(-3, "kmpc_state_import: buffer too small");
@@ -1161,6 +1256,7 @@ int kmpc_generate_and_fit(kmpc_handle* h, int plant, const void* X0, const void*
 int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, void* s) { NN(h); return h->qp_solve(H, f, U, st, it, B, (hipStream_t)s); }
 int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
 int kmpc_set_applied_input(kmpc_handle* h, const void* U, int B, void* s) { NN(h); return h->set_applied_input(U, B, (hipStream_t)s); }
+int kmpc_set_online_update(kmpc_handle* h, int on) { NN(h); return h->set_online_update(on); }
 int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NN(h); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
 int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NN(h); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
 int kmpc_offline_fit(kmpc_handle* h, const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A, void* B, void* C, void* s) { NN(h); return h->offline_fit(X, Y, U, M, ridge, init_rls, A, B, C, (hipStream_t)s); }

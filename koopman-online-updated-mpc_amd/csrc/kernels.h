@@ -92,6 +92,7 @@ template <typename T> struct RolloutArgs {
   T* psi[2];                // [B][L] ping-pong: psi[cur] receives the lift of the first step
   int cur;
   int steps, step0, switch_step, have_prev, rls_fresh;
+  int no_update;            // 1: the loop without the online update (duffing.py:738-805): no RLS phase, the model stays as it is
   int wstride;              // per-wave LDS region in elements
   int wbase;                // LDS offset (elements) of the first per-wave region (register-state step: behind the lift scratch)
   int keep_off;             // LDS offset (elements) of the part the lift scratch does not overlay

@@ -16,8 +16,11 @@ template <typename T> __device__ __forceinline__ void plant_f(int plant, int sw,
   }
 }
 
-// (x1, x2) <- plant(x1, x2, u)
+// (x1, x2) <- plant(x1, x2, u).  Bit 4 of `plant` (KMPC_PLANT_RK4_MATLAB): the Runge-Kutta step as the MATLAB scripts write it,
+// k4 = f(x + h k1) instead of f(x + h k3) (Koopman_update.m:24).
 template <typename T> __device__ __forceinline__ void plant_apply(int plant, int sw, T h, T& x1, T& x2, T u) {
+  const bool k4_from_k1 = (plant & 16) != 0;
+  plant &= 15;
   if (plant == 2) {
     const T s1 = sqrt(x1 > T(0) ? x1 : T(0)), s2 = sqrt(x2 > T(0) ? x2 : T(0));
     T y1, y2;
@@ -31,7 +34,7 @@ template <typename T> __device__ __forceinline__ void plant_apply(int plant, int
   plant_f(plant, sw, x1, x2, u, k1a, k1b);
   plant_f(plant, sw, x1 + T(0.5) * h * k1a, x2 + T(0.5) * h * k1b, u, k2a, k2b);
   plant_f(plant, sw, x1 + T(0.5) * h * k2a, x2 + T(0.5) * h * k2b, u, k3a, k3b);
-  plant_f(plant, sw, x1 + h * k3a, x2 + h * k3b, u, k4a, k4b);
+  plant_f(plant, sw, x1 + h * (k4_from_k1 ? k1a : k3a), x2 + h * (k4_from_k1 ? k1b : k3b), u, k4a, k4b);
   const T n1 = x1 + (h / T(6.0)) * (k1a + T(2.0) * k2a + T(2.0) * k3a + k4a);
   const T n2 = x2 + (h / T(6.0)) * (k1b + T(2.0) * k2b + T(2.0) * k3b + k4b);
   x1 = n1;

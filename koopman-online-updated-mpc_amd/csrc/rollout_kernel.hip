@@ -335,13 +335,13 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       sv.psi_in_regs = 1;
       sv.psi_now_v = psi_i;
       sv.psi_prev_v = psi_prev_reg;
-      sv.phases = PH_CONDENSE | PH_QP | (have_prev ? PH_RLS : 0);
+      sv.phases = PH_CONDENSE | PH_QP | ((have_prev && !R.no_update) ? PH_RLS : 0);
       sv.first_update = fresh ? 1 : 0;
       sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
       sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
       sv.x_next = RBF ? nullptr : sXn + wv * 4;
-      sv.cov_done = k > 0 ? 1 : 0;
-      sv.cov_ahead = k + 1 < R.steps ? 1 : 0;
+      sv.cov_done = (k > 0 && !R.no_update) ? 1 : 0;
+      sv.cov_ahead = (k + 1 < R.steps && !R.no_update) ? 1 : 0;
       // (16 trajectories per CU with a long horizon -- the RBF roll-out of cfg3 -- : H re-read from LDS, and the active-set
       //  safeguard stays the fall-back on the global-scratch tableau instead of living in registers: 67 -> 51 spilled
       //  registers, 109.7 -> 117.8 M steps/s; its crawling solves are 14 of 327 680 on that workload)

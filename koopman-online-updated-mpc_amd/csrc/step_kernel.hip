@@ -74,14 +74,16 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
     }
   }
   if (lds > 160 * 1024) return hipErrorInvalidValue;
-  static size_t configured_dev[16] = {};  // (function attributes are per device)
-  size_t& configured = configured_dev[device_slot()];
-  if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&step_kernel<T, TPB, L_, N_, Q_>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    configured = lds;
-  }
+  static size_t configured_dev[3][16] = {};  // (function attributes are per device and per kernel symbol)
+  auto allow_lds = [&](const void* fn, int which, size_t bytes) -> hipError_t {
+    size_t& configured = configured_dev[which][device_slot()];
+    if (bytes > 64 * 1024 && bytes > configured) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e != hipSuccess) return e;
+      configured = bytes;
+    }
+    return hipSuccess;
+  };
   if constexpr (QPK) {
     if (qp_only && a.phases == PH_QP) {
       // (shared H and the register safeguard compiled in and not switched off: the solve never leaves for the LDS tableau)
@@ -89,13 +91,17 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
       if (a.h_shared && a.H_in && a.T_in && (a.qp_predict & 2) == 0 && !no_hg) {
         const int p = a.L + 1, setq = 3 * a.N > 2 * p + a.L ? 3 * a.N : 2 * p + a.L;
         k.r1 = 0;
-        hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_, true>), dim3(a.B), dim3(TPB), (size_t)(16 + a.N + setq) * sizeof(T), s, k);
+        const size_t lq = (size_t)(16 + a.N + setq) * sizeof(T);
+        if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&step_qp_kernel<T, TPB, L_, N_, Q_, true>), 1, lq); e != hipSuccess) return e;
+        hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_, true>), dim3(a.B), dim3(TPB), lq, s, k);
         return hipGetLastError();
       }
+      if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&step_qp_kernel<T, TPB, L_, N_, Q_, false>), 2, lds); e != hipSuccess) return e;
       hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_, false>), dim3(a.B), dim3(TPB), lds, s, k);
       return hipGetLastError();
     }
   }
+  if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&step_kernel<T, TPB, L_, N_, Q_>), 0, lds); e != hipSuccess) return e;
   hipLaunchKernelGGL((step_kernel<T, TPB, L_, N_, Q_>), dim3(a.B), dim3(TPB), lds, s, k);
   return hipGetLastError();
 }

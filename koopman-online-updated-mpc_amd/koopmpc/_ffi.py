@@ -16,6 +16,8 @@ KMPC_F32, KMPC_F64 = 0, 1
 KMPC_LIFT_MLP, KMPC_LIFT_RBF_PY, KMPC_LIFT_RBF_MATLAB = 0, 1, 2
 KMPC_OUT_CX, KMPC_OUT_LIFT = 0, 1
 KMPC_PLANT_DUFFING, KMPC_PLANT_VDP, KMPC_PLANT_TANK = 0, 1, 2
+KMPC_PLANT_RK4_MATLAB = 16
+KMPC_LIFT_OFFSET_NONE, KMPC_LIFT_OFFSET_PSI0, KMPC_LIFT_OFFSET_X_PSI0 = 0, 1, 2
 
 
 class KmpcConfig(C.Structure):
@@ -25,7 +27,7 @@ class KmpcConfig(C.Structure):
         ("output_kind", C.c_int32), ("dtype", C.c_int32), ("batch", C.c_int32),
         ("qp_max_iter", C.c_int32), ("threads", C.c_int32),
         ("delta_u", C.c_int32), ("out_row0", C.c_int32), ("out_rows", C.c_int32), ("c_skip_first", C.c_int32),
-        ("cold_start", C.c_int32), ("reserved0", C.c_int32),
+        ("cold_start", C.c_int32), ("lift_offset", C.c_int32),
         ("lam", C.c_double), ("P0", C.c_double), ("barQ0", C.c_double),
         ("Qw", C.c_double), ("Rw", C.c_double), ("lb", C.c_double), ("ub", C.c_double),
         ("rbf_eps", C.c_double), ("umin", C.c_double), ("umax", C.c_double),
@@ -70,6 +72,7 @@ SIGNATURES = {
     "kmpc_shared_solve_plant": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _D, _VP]),
     "kmpc_shared_get_model": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "kmpc_set_applied_input": (_I, [_VP, _VP, _I, _VP]),
+    "kmpc_set_online_update": (_I, [_VP, _I]),
     "kmpc_plant_step": (_I, [_VP, _I, _VP, _VP, _D, _I, _I, _VP]),
     "kmpc_rollout": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_state_bytes": (_I64, [_VP]),

@@ -79,12 +79,15 @@ class KoopmanMPC:
     P0=1e4 (duffing.py:929-930), barQ0=100 (duffing.py:946).
     ``output``: "Cx" -> y = C x with C adapted online (duffing.py); "lift" -> y = lifted state
     (vanderpol.py:456-459).
+    ``lift_offset``: None (the raw encoder, as the Python scripts lift), "psi0" -> psi(x) - psi(0)
+    (Koopman_update_Tracking_Lift.m:65), "x_psi0" -> [x; psi(x)] - [0; psi(0)] with L = n + the encoder's outputs
+    (Koopman_update.m:67).
     """
 
     def __init__(self, n=2, L=8, N=10, batch=1, lift="mlp", weights=None, centres=None, hidden=100, layers=3,
                  output="Cx", dtype=torch.float64, lam=1.0, P0=1e4, barQ0=100.0, Qw=100.0, Rw=1e-4, lb=-2.0,
                  ub=2.0, rbf_eps=1e-4, qp_max_iter=0, threads=0, device=None, delta_u=False, out_row0=0, out_rows=0,
-                 c_skip_first=False, umin=-8.0, umax=8.0, cold_start=False):
+                 c_skip_first=False, umin=-8.0, umax=8.0, cold_start=False, lift_offset=None):
         if not torch.cuda.is_available():
             raise RuntimeError("koopmpc needs a HIP device (MI355X); there is no CPU path")
         self.lib = _ffi.load()
@@ -103,7 +106,8 @@ class KoopmanMPC:
             dtype=_ffi.KMPC_F64 if dtype == torch.float64 else _ffi.KMPC_F32, batch=batch,
             qp_max_iter=qp_max_iter, threads=threads, lam=lam, P0=P0, barQ0=barQ0, Qw=Qw, Rw=Rw, lb=lb, ub=ub,
             rbf_eps=rbf_eps, delta_u=int(bool(delta_u)), out_row0=int(out_row0), out_rows=int(out_rows),
-            c_skip_first=int(bool(c_skip_first)), umin=umin, umax=umax, cold_start=int(bool(cold_start)), reserved0=0)
+            c_skip_first=int(bool(c_skip_first)), umin=umin, umax=umax, cold_start=int(bool(cold_start)),
+            lift_offset={None: 0, "none": 0, "psi0": _ffi.KMPC_LIFT_OFFSET_PSI0, "x_psi0": _ffi.KMPC_LIFT_OFFSET_X_PSI0}[lift_offset])
         self.cfg = cfg
         h = C.c_void_p()
         rc = self.lib.kmpc_create(C.byref(cfg), C.byref(h))
@@ -434,9 +438,22 @@ class KoopmanMPC:
         return A, Bm, Cm
 
     # ------------------------------------------------------------------ plant (adjacent)
+    @staticmethod
+    def _plant_id(kind):
+        """"duffing" | "vdp" | "tank"; a "_matlab" suffix selects the Runge-Kutta step as the MATLAB scripts write it
+        (k4 evaluated at x + h k1, Koopman_update.m:24)."""
+        base = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP, "tank": _ffi.KMPC_PLANT_TANK}
+        if kind.endswith("_matlab"):
+            return base[kind[:-7]] | _ffi.KMPC_PLANT_RK4_MATLAB
+        return base[kind]
+
+    def set_online_update(self, on=True):
+        """on=False: step / rollout run the reference's loop WITHOUT the online update (duffing.py:738-805): the model stays."""
+        self._chk(self.lib.kmpc_set_online_update(self.h, int(bool(on))), "kmpc_set_online_update")
+
     def plant_step(self, kind, X, U, h=0.05, switched=False):
         """X <- f_update(0, X, U) in place on the device (duffing.py:256-261)."""
-        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP, "tank": _ffi.KMPC_PLANT_TANK}[kind]
+        plant = self._plant_id(kind)
         assert X.is_cuda and X.dtype == self.dtype and X.is_contiguous()
         Uu = self._dev(U, (X.shape[1],))
         self._chk(self.lib.kmpc_plant_step(self.h, plant, self._p(X), self._p(Uu), float(h), int(bool(switched)),
@@ -449,7 +466,7 @@ class KoopmanMPC:
         (the reference flips them at the end of iteration 101).  X (n,B) device tensor, updated in place.
         self.status / self.iters receive each trajectory's worst QP status and total Newton solves.
         Returns (U_log (steps,B), X_log (steps,n,B)) when log=True."""
-        plant = {"duffing": _ffi.KMPC_PLANT_DUFFING, "vdp": _ffi.KMPC_PLANT_VDP, "tank": _ffi.KMPC_PLANT_TANK}[kind]
+        plant = self._plant_id(kind)
         assert X.is_cuda and X.dtype == self.dtype and X.is_contiguous() and tuple(X.shape) == (self.n, self.B)
         rr, per = self._ref(r)
         Ul = torch.empty(steps, self.B, dtype=self.dtype, device=self.device) if log else None

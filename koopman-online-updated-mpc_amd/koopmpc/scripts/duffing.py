@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=10)       # MPCHorizon = ControlHorizon, duffing.py:632-633
     ap.add_argument("--model", default=None, help=".npz with A0, B0, C0: the offline model instead of fitting one here")
     ap.add_argument("--out", default=None, help="np.savez the logs here (logXloc, logUloc, like duffing.py:1015)")
+    ap.add_argument("--no-update", action="store_true", help="the comparison loop WITHOUT the online update (duffing.py:738-805: logX, logU)")
     a = ap.parse_args()
 
     if a.weights:
@@ -48,6 +49,8 @@ def main():
     x_loc = torch.tensor(x0, dtype=torch.float64, device=mpc.device)
     r = np.concatenate([np.ones((1, N)), np.zeros((1, N))], axis=0)                 # duffing.py:834-842
     # the loop body duffing.py:847-992, enqueued from C++; plant parameters switch after iteration 101
+    if a.no_update:
+        mpc.set_online_update(False)
     logUloc, logXloc = mpc.rollout("duffing", x_loc, r, a.steps, step0=0, switch_step=102, log=True)
     torch.cuda.synchronize()
     print("worst QP status %d, mean Newton solves/step %.2f" % (int(mpc.status.max()), float(mpc.iters.double().mean()) / a.steps))

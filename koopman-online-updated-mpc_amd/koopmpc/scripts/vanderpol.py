@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--horizon", type=int, default=10)
     ap.add_argument("--model", default=None, help=".npz with A0, B0, C0: the offline model instead of fitting one here")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--no-update", action="store_true", help="the comparison loop WITHOUT the online update (vanderpol.py:645-722: logX, logU)")
     a = ap.parse_args()
     if a.weights:
         d = np.load(a.weights)
@@ -42,6 +43,8 @@ def main():
     r = np.tile(goal.reshape(Nlift, 1), (1, N))                                # the same lifted reference at every stage
     x0 = np.tile(np.array([[-2.0], [-2.0]]), (1, B)) if B == 1 else initial_states(B)
     x_loc = torch.tensor(x0, dtype=torch.float64, device=mpc.device)
+    if a.no_update:
+        mpc.set_online_update(False)
     logUloc, logXloc = mpc.rollout("vdp", x_loc, r, a.steps, step0=0, switch_step=102, log=True)
     torch.cuda.synchronize()
     print("fused roll-out: %s; worst QP status %d, mean Newton solves/step %.2f" % (mpc.rollout_is_fused(), int(mpc.status.max()),

@@ -54,6 +54,21 @@ def mlp_lift(weights, X):
     return H
 
 
+def mlp_lift_offset(weights, X, form):
+    """The lifts of the MATLAB scripts on top of the encoder:
+    form "psi0":   liftFun = @(x) [Encoder_VDP(x)] - [Encoder_VDP(zeros(2, 1))]                     VDP_Revise_2/Koopman_update_Tracking_Lift.m:65
+    form "x_psi0": liftFun = @(x) [x; Encoder_Duffing(x)] - [zeros(2, 1); Encoder_Duffing(zeros(2, 1))]   Revise_2/Koopman_update.m:67 (Nlift = n + 8, :70)"""
+    X = np.asarray(X, dtype=np.float64)
+    if X.ndim == 1:
+        X = X[:, None]
+    E = mlp_lift(weights, X) - mlp_lift(weights, np.zeros((X.shape[0], 1)))
+    if form == "psi0":
+        return E
+    if form == "x_psi0":
+        return np.concatenate([X, E], axis=0)
+    raise ValueError(form)
+
+
 def load_mlp_weights(npz):
     """[(W1,b1),...] from a tests/golden/weights_*.npz (b stored 1 x k as in the .mat)."""
     out = []
@@ -350,11 +365,12 @@ def solve_lbfgsb(AB, C, x0, r, N, lb, ub, Qw=100.0, Rw=1e-4):
 # ----------------------------------------------------------------------------------------
 
 
-def _rk4(f, x, u, h):
+def _rk4(f, x, u, h, matlab=False):
+    """duffing.py:256-261.  matlab=True: Revise_2/Koopman_update.m:21-25 -- its k4 is evaluated at x + k1 deltaT (not k3)."""
     k1 = f(x, u)
     k2 = f(x + 0.5 * h * k1, u)
     k3 = f(x + 0.5 * h * k2, u)
-    k4 = f(x + h * k3, u)
+    k4 = f(x + h * (k1 if matlab else k3), u)
     return x + (h / 6.0) * (k1 + 2.0 * k2 + 2.0 * k3 + k4)
 
 
@@ -373,9 +389,11 @@ def vdp_f(x, u, switched=False):
 
 
 def plant_step(kind, x, u, h=0.05, switched=False):
-    """One RK4 step (duffing.py:256-261) on x (2,) or (2,B) with input u scalar or (B,)."""
-    f = {"duffing": duffing_f, "vdp": vdp_f}[kind]
-    return _rk4(lambda xx, uu: f(xx, uu, switched), np.asarray(x, float), np.asarray(u, float), h)
+    """One RK4 step (duffing.py:256-261) on x (2,) or (2,B) with input u scalar or (B,); kind "duffing" | "vdp", with the
+    suffix "_matlab" the step as Koopman_update.m:21-25 writes it."""
+    matlab = kind.endswith("_matlab")
+    f = {"duffing": duffing_f, "vdp": vdp_f}[kind[:-7] if matlab else kind]
+    return _rk4(lambda xx, uu: f(xx, uu, switched), np.asarray(x, float), np.asarray(u, float), h, matlab)
 
 
 def tank_step(x, u, switched=False):
@@ -403,8 +421,9 @@ class OracleController:
     """
 
     def __init__(self, lift, L, n, N, lb, ub, A0, B0, C0, P0=1e4, barQ0=100.0, Qw=100.0, Rw=1e-4,
-                 output="Cx", solver="exact", rls="reference"):
+                 output="Cx", solver="exact", rls="reference", update=True):
         self.lift, self.L, self.n, self.N = lift, L, n, N
+        self.update = update  # False: the loop without the online update (duffing.py:738-805, vanderpol.py:645-722)
         self.lb, self.ub, self.Qw, self.Rw = lb, ub, Qw, Rw
         self.A, self.B, self.C = np.array(A0, float), np.array(B0, float).reshape(L, 1), np.array(C0, float)
         self.rls = RlsStateRef(L, 1, n, P0, barQ0)
@@ -416,7 +435,7 @@ class OracleController:
 
     def step(self, x, r):
         psi = self.lift(np.reshape(x, (-1, 1))).reshape(-1)
-        if self.prev is not None:
+        if self.prev is not None and self.update:
             ppsi, pu = self.prev
             if self.rls_form == "reference":
                 self.A, self.B, self.C = rls_update_reference(self.rls, ppsi, pu, psi, x)

@@ -335,3 +335,37 @@ def test_dare_and_dlqr_are_the_reference_functions():
     Co = np.array([[1.0, 2.0, 0.0], [0.0, 1.0, -1.0]])
     P = np.diag([1.0, 2.0, 3.0])
     assert np.allclose(ko.terminal_block(Co, P), Co @ P @ Co.T)
+
+
+# ------------------------------------------------------------------ round 3: reference variants
+def test_fixed_model_loop_of_the_oracle(duff):
+    """duffing.py:738-805: the loop without the online update (logX, logU).  The oracle with update=False, exact QP, free-running
+    from (-2, -2) with the reference's offline model lands on the reference's own log (its L-BFGS-B leaves ~1e-3 in u)."""
+    w = ko.load_mlp_weights(_load("weights_duffing.npz"))
+    ctl = ko.OracleController(lambda x: ko.mlp_lift(w, x), 8, 2, 10, -2.0, 2.0, duff["A0"], duff["B0"], duff["C0"], update=False)
+    r = duff["loop_r"][0]
+    x = np.array([-2.0, -2.0])
+    ex = eu = 0.0
+    for k in range(130):
+        u, _, _ = ctl.step(x, r)
+        x = ko.plant_step("duffing", x, u, switched=(k > 101))
+        ex = max(ex, np.abs(x - duff["logX"][:, k]).max())
+        eu = max(eu, abs(u - duff["logU"][0, k]))
+    assert np.array_equal(ctl.A, duff["A0"])  # the model never moved
+    assert ex < 1e-4 and eu < 3e-3, (ex, eu)
+
+
+def test_matlab_lift_forms_and_rk4():
+    """Koopman_update.m:67 / Koopman_update_Tracking_Lift.m:65: both lifts vanish at the origin, the long form starts with x;
+    Koopman_update.m:21-25: the MATLAB Runge-Kutta step differs from the Python scripts' at O(h^4) only."""
+    w = ko.load_mlp_weights(_load("weights_duffing.npz"))
+    X = np.array([[0.0, 0.3, -1.2], [0.0, -0.7, 0.4]])
+    a = ko.mlp_lift_offset(w, X, "psi0")
+    b = ko.mlp_lift_offset(w, X, "x_psi0")
+    assert a.shape == (8, 3) and b.shape == (10, 3)
+    assert np.abs(a[:, 0]).max() < 1e-15 and np.abs(b[:, 0]).max() < 1e-15  # (BLAS sums a 3-column product in another order)
+    assert np.array_equal(b[:2], X) and np.array_equal(b[2:], a)
+    assert np.allclose(a, ko.mlp_lift(w, X) - ko.mlp_lift(w, np.zeros((2, 1))), rtol=0, atol=1e-15)
+    x = np.array([0.4, -1.1])
+    xp, xm = ko.plant_step("duffing", x, 0.7), ko.plant_step("duffing_matlab", x, 0.7)
+    assert 1e-9 < np.abs(xp - xm).max() < 1e-4
