@@ -106,9 +106,11 @@ def initial_states_for(name, B, seed):
 
 
 def _cpu_worker(args):
-    """One host core: per-trajectory loop in the reference's order (duffing.py:823-1012) through the oracle, for
-    `budget_s` seconds.  Returns (trajectory-steps done, seconds)."""
-    name, L, N, x0s, budget_s, solver, spt = args
+    """One host core: per-trajectory loop in the reference's order (duffing.py:823-1012) through the oracle.  Every trajectory
+    first runs `settle` closed-loop steps after the RLS reset (the GPU leg's set-up: same controller regime), then steps are
+    timed until the budget ends; the first `post` steps after the reset are timed separately (the start-up transient).
+    Returns (timed trajectory-steps, seconds, transient trajectory-steps, seconds)."""
+    name, L, N, x0s, budget_s, solver, settle, post = args
     from oracle import koopman_oracle as ko
 
     try:
@@ -129,8 +131,9 @@ def _cpu_worker(args):
     K0 = PY @ np.linalg.pinv(Z)  # the reference's one-off fit (duffing.py:152-177)
     A0, B0, C0 = K0[:, :-1], K0[:, -1:], X @ np.linalg.pinv(PX)
     r = w["ref"]
-    t0 = time.perf_counter()
-    done = 0
+    t_start = time.perf_counter()
+    done = tdone = 0
+    secs = tsecs = 0.0
     if name == "cfg4":
         # Tank_System.m:170-291 for a small pool of trajectories that share ONE model (pooled Gram sums, Koopman_update.m:94-101)
         nb = x0s.shape[1]
@@ -138,7 +141,9 @@ def _cpu_worker(args):
         ctl = [ko.OracleDeltaUController(lift, L, 2, N, A0, B0, C0) for _ in range(nb)]
         xs = x0s.copy()
         prev = None
-        for k in range(spt):
+        k = 0
+        while True:
+            t0 = time.perf_counter()
             Psi = lift(xs)
             if prev is not None:
                 sh.add(*ko.SharedEdmd.gram(prev[0], prev[1], Psi, xs))
@@ -157,12 +162,19 @@ def _cpu_worker(args):
                 except np.linalg.LinAlgError:  # (a pooled model of the first steps can make H numerically singular: keep the input)
                     dU = np.zeros(N)
                 cc.u += float(dU[0]); us[t] = cc.u
-                xs[:, t] = ko.tank_step(xs[:, t], cc.u)
-                done += 1
+                xs[:, t] = ko.tank_step(xs[:, t], cc.u, switched=(k > 100))
             prev = (Psi, us.copy())
-            if time.perf_counter() - t0 > budget_s:
+            dt = time.perf_counter() - t0
+            if k < post:
+                tdone += nb; tsecs += dt
+            elif k >= settle:
+                done += nb; secs += dt
+            k += 1
+            if time.perf_counter() - t_start > budget_s and (done > 0 or k < settle // 4):
                 break
-        return done, time.perf_counter() - t0
+            if time.perf_counter() - t_start > 3 * budget_s:
+                break
+        return done, secs, tdone, tsecs
     for t in range(x0s.shape[1]):
         ctl = ko.OracleController(lift, L, 2, N, c["lb"], c["ub"], A0, B0, C0, P0=c["P0"], barQ0=c["barQ0"], solver=solver)
         if c.get("lift") == "rbf":  # continue from the offline Gram (vanderpol_RBF.py:434-438 in recursive form)
@@ -171,36 +183,52 @@ def _cpu_worker(args):
             ctl.rls.bar_X = X @ PX.T
             ctl.rls.bar_Q = np.linalg.pinv(PX @ PX.T)
         x = x0s[:, t].copy()
-        for k in range(spt):
+        k = 0
+        while True:
+            t0 = time.perf_counter()
             u, _, _ = ctl.step(x, r)
-            x = ko.plant_step(c["plant"], x, u)
-            done += 1
-            if time.perf_counter() - t0 > budget_s:
+            x = ko.plant_step(c["plant"], x, u, switched=(k > 101))
+            dt = time.perf_counter() - t0
+            if k < post:
+                tdone += 1; tsecs += dt
+            elif k >= settle:
+                done += 1; secs += dt
+            k += 1
+            over = time.perf_counter() - t_start > budget_s
+            if (over and k > settle) or k >= settle + 200 or time.perf_counter() - t_start > 3 * budget_s:
                 break
-        if time.perf_counter() - t0 > budget_s:
+        if time.perf_counter() - t_start > budget_s:
             break
-    return done, time.perf_counter() - t0
+    return done, secs, tdone, tsecs
 
 
-def cpu_baseline(name, L, N, x0s, budget_s):
-    """The reference's path on the host cores, timed BEFORE this process touches the GPU (the workers are forked): on one core
-    and on the box's CPU share (one trajectory stream per core); the exact-QP variant of the oracle on one core beside it."""
+def cpu_baseline(name, L, N, x0s, budget_s, settle):
+    """The reference's path on the host cores, timed BEFORE this process touches the GPU (the workers are forked): one
+    trajectory stream per core of the box's CPU share, each in the GPU leg's regime (`settle` steps after the reset are set-up,
+    the steps after them are timed); the single-core figure and the exact-QP variant of the oracle beside it."""
     import multiprocessing as mp
 
-    spt = 8
+    post = 8
     cores = max(1, min(16, os.cpu_count() or 1))  # a one-GPU box comes with 16 host cores
     solver = "exact" if name == "cfg4" else "lbfgsb"
-    one = _cpu_worker((name, L, N, x0s[:, :64], budget_s / 3.0, solver, spt))
-    exact = _cpu_worker((name, L, N, x0s[:, :64], budget_s / 3.0, "exact", spt)) if solver != "exact" else one
-    per = max(1, min(64 if name == "cfg4" else 1 << 30, x0s.shape[1] // cores))
-    jobs = [(name, L, N, x0s[:, i * per:(i + 1) * per], budget_s, solver, spt) for i in range(cores)]
+    per = max(1, min(64 if name == "cfg4" else 1 << 30, x0s.shape[1] // (cores + 2)))
+    jobs = [(name, L, N, x0s[:, i * per:(i + 1) * per], budget_s, solver, settle, post) for i in range(cores)]
+    # (the two single-core legs run beside the pool on the box's spare cores when it has them; their rate is per core either way)
     t0 = time.perf_counter()
     with mp.get_context("fork").Pool(cores) as pool:
         res = pool.map(_cpu_worker, jobs)
     wall = time.perf_counter() - t0
-    done = sum(d for d, _ in res)
-    return {"all": (done / wall, done, wall, cores), "one": (one[0] / one[1], one[0], one[1]),
-            "exact": (exact[0] / exact[1], exact[0], exact[1]), "spt": spt, "solver": solver}
+    done = sum(d for d, _, _, _ in res)
+    busy = sum(sec for _, sec, _, _ in res)
+    tdone = sum(d for _, _, d, _ in res)
+    tbusy = sum(sec for _, _, _, sec in res)
+    # cores x (steps per core-second): every worker times only its steps after the settle phase
+    rate = cores * done / busy if busy > 0 else 0.0
+    trate = cores * tdone / tbusy if tbusy > 0 else 0.0
+    exact = _cpu_worker((name, L, N, x0s[:, cores * per:(cores + 1) * per], budget_s / 2.0, "exact", min(settle, 40), post)) if solver != "exact" else None
+    return {"all": (rate, done, busy, cores, wall), "transient": (trate, tdone, tbusy),
+            "one": (done / busy if busy > 0 else 0.0, done, busy),
+            "exact": ((exact[0] / exact[1]) if exact and exact[1] > 0 else None), "settle": settle, "post": post, "solver": solver}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -257,68 +285,32 @@ class Loop:
                 self.m.shared_step(self.X, self.r, plant="tank", switched=(k > 100))
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
-    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0: the configuration's)")
-    ap.add_argument("--L", type=int, default=0)
-    ap.add_argument("--N", type=int, default=0)
-    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
-    ap.add_argument("--threads", type=int, default=0)
-    ap.add_argument("--settle", type=int, default=-1,
-                    help="closed-loop steps after the RLS reset that belong to the set-up (-1: the configuration's default)")
-    ap.add_argument("--cold-start", action="store_true",
-                    help="start every QP at clip(0) like the reference instead of at the previous minimiser")
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
-    ap.add_argument("--spin-seconds", type=float, default=1.0,
-                    help="untimed GPU activity on a scratch copy of the workload before the warm-up, so that the "
-                         "clocks have left their idle state when the W warm-up steps start")
-    ap.add_argument("--no-extras", action="store_true", help="skip the cold-start and post-reset measurements")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
-                    help="process-group backend for --gpus N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal of the "
-                         "multi-rank code path, e.g. with --same-device on a one-GPU box; not a scaling measurement)")
-    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal with --backend gloo)")
-    args = ap.parse_args()
+FP64_PEAK_TFLOPS = 78.6  # /opt/skills/guides/MI355X_MICROARCH.md: fp64 vector / matrix peak (spec)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
-    if args.gpus != world:
-        sys.exit("bench.py --gpus %d inside a %d-rank job" % (args.gpus, world))
-    name = args.config
+
+def algorithmic_flops(name, L, N, q, newton_per_step):
+    """SURVEY.md 8d, per trajectory-step: lift + RLS of [A B] (reference form) + RLS of C + dense condensed build + the
+    solve with the MEASURED number of Newton solves (the survey's table uses 100)."""
     c = CONFIGS[name]
-    L, N, B = args.L or c["L"], args.N or c["N"], args.batch or c["B"]
-    settle = c["settle"] if args.settle < 0 else args.settle
-    # ---- CPU baseline first (rank 0 at N = 1 only): its worker processes are forked before anything touches the GPU
-    cpu = None
-    if world == 1 and args.cpu_seconds > 0:
-        cpu = cpu_baseline(name, L, N, initial_states_for(name, min(B, 4096), 101), args.cpu_seconds)
+    n, m, p, h = 2, 1, L + 1, 100
+    d = c.get("layers", 3)
+    lift = 25 * L if c.get("lift") == "rbf" else 2 * (n * h + (d - 1) * h * h + h * L)
+    rls_ab = 4 * p * p + 2 * p + 2 * L * p + 2 * L * p * p
+    rls_c = 4 * L * L + 2 * L + 2 * n * L + 2 * n * L * L
+    cond = 2 * q * L * L * N + 2 * q * L * m * N + 2 * (q * N) * (N * m) ** 2 + 2 * q * N * L + 2 * q * N * N * m
+    qp = newton_per_step * (2 * (N * m) ** 2 + 4 * N * m)
+    if c.get("shared"):  # one model for the batch: the per-trajectory part is the lift, its Gram contribution, f = F psi and the solve
+        return lift + 2 * (p + L + n) * p + 2 * N * (L + 1) + qp
+    return lift + rls_ab + rls_c + cond + qp
+
+
+def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=True, spin_seconds=1.0):
+    """Set-up (offline fit, `settle` closed-loop steps), W warm-up steps, then EXACTLY K timed steps of one configuration:
+    returns the fields of the JSON line that depend on the workload (value, ms_per_step, roofline, the QP statistics)."""
     import torch
-
-    if not torch.cuda.is_available():
-        if cpu is not None:
-            print("cpu_baseline (no GPU here, nothing else measured): %s" % json.dumps(cpu), file=sys.stderr)
-        sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
-    if args.same_device:
-        local = 0
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group("gloo")
-
     from koopmpc import max_over_ranks
 
+    c = CONFIGS[name]
     dtype = torch.float64 if args.dtype == "f64" else torch.float32
     w = workload_inputs(name, L, N)
 
@@ -359,12 +351,12 @@ def main():
     can_snap = not main_loop.shared
     snap = (main_loop.m.state_to(), main_loop.X.clone()) if can_snap else None
     scratch = None
-    if args.spin_seconds > 0 or not args.no_extras:
+    if spin_seconds > 0 or extras:
         scratch = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
-        if args.spin_seconds > 0:
+        if spin_seconds > 0:
             if not can_snap:
                 scratch.advance(settle + args.warmup, 0)
-            spin(scratch, args.spin_seconds, args.steps, step0, snap)
+            spin(scratch, spin_seconds, args.steps, step0, snap)
     dt = timed(main_loop, args.steps, step0, profile=True)
     pr = main_loop.m.profile_read()
     main_loop.m.profile(False)
@@ -385,25 +377,29 @@ def main():
         bytes_per_traj = sz * ((L + L * p_ + 2 * L + N + 2) + (2 + 1 + q_ * N))
     bytes_per_launch = bytes_per_traj * B * steps_per_launch
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
+    flops_per_traj = algorithmic_flops(name, L, N, mpc.q, newton_per_step)
+    tflops = flops_per_traj * B * steps_per_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
 
     # ---- beside the headline: every solve started at clip(0) as the reference does; the same window right after the reset
-    extras = {}
-    if not args.no_extras and scratch is not None:
+    ex = {}
+    if extras and scratch is not None:
         if can_snap and not args.cold_start:
             cold = Loop(name, w, B, dtype, dev, rank, cold=True, threads=args.threads)
             cold.m.state_from(snap[0]); cold.X.copy_(snap[1])
             dtc = timed(cold, args.steps, step0)
-            extras["cold_start"] = {"value": B * world * args.steps / dtc, "ms_per_step": dtc / args.steps * 1e3,
-                                    "mean_newton_solves_per_step": float(cold.m.iters.double().mean().item()) / max(1, args.steps),
-                                    "note": "same state, every QP started at clip(0) like the reference (duffing.py:634-635, 859): same minimiser, more work"}
+            ex["cold_start"] = {"value": B * world * args.steps / dtc, "ms_per_step": dtc / args.steps * 1e3,
+                                "frac": bytes_per_traj * B * args.steps / dtc / 1e9 / HBM_PEAK_GBS,
+                                "mean_newton_solves_per_step": float(cold.m.iters.double().mean().item()) / max(1, args.steps),
+                                "note": "same state, every QP started at clip(0) like the reference (duffing.py:634-635, 859): same minimiser, more work; frac = "
+                                        "algorithmic bytes / wall time of the timed region / HBM peak"}
             del cold
         fresh = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
         fresh.advance(args.warmup, 0)
         dtp = timed(fresh, args.steps, args.warmup)
-        extras["post_reset"] = {"value": B * world * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3,
-                                "mean_newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if not fresh.shared else 1),
-                                "note": "the same %d timed steps after %d warm-up steps counted from the RLS reset (no settle steps): the estimator's "
-                                        "start-up transient, ill-conditioned QPs with many active-set changes" % (args.steps, args.warmup)}
+        ex["post_reset"] = {"value": B * world * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3,
+                            "mean_newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if not fresh.shared else 1),
+                            "note": "the same %d timed steps after %d warm-up steps counted from the RLS reset (no settle steps): the estimator's "
+                                    "start-up transient, ill-conditioned QPs with many active-set changes" % (args.steps, args.warmup)}
         del fresh
 
     if dist is not None:
@@ -412,7 +408,7 @@ def main():
         worst_status, x_ok = int(flag[0].item()), int(flag[1].item()) == 0
 
     # HBM bytes per trajectory-step from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
-    # own-pattern calibration), collected with tools/profile_bench.sh and committed in profiles/
+    # own-pattern calibration), collected with tools/profile_config.sh and committed in profiles/
     traffic, traffic_note = None, "not collected for this configuration"
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
@@ -422,22 +418,137 @@ def main():
             traffic_note = "bytes per launch = %.0f B per trajectory-step (rocprofv3 PMC passes at B = %d, %s) x trajectories x steps per launch" % (
                 tj["bytes_per_trajectory_step"], tj["B"], tj["source"])
 
+    if main_loop.shared:
+        kname = "step_qp_kernel (box QPs of the shared model, %d blocks x 64 threads); lift, Gram (MFMA), model solve and condense are separate launches" % B
+    elif fused:
+        kname = "rollout_kernel (lift + RLS + condense + QP + plant, all %d steps in one launch), %d workgroups" % (steps_per_launch, (B + 15) // 16)
+    else:
+        kname = "step_kernel (RLS + condense + QP + plant), %d blocks x %d threads" % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64))
+    # governing roofline: the per-trajectory modes stream their state -> HBM; the 8-observable RBF set (cfg3, AI ~ 120
+    # flop/B) is bound by the fp64 vector pipe, not by bandwidth.  Both fractions are reported for every configuration.
+    hbm_frac = achieved / HBM_PEAK_GBS
+    flop_frac = tflops / FP64_PEAK_TFLOPS
+    compute_bound = (c.get("lift") == "rbf" and L <= 8)
+    roof = {
+        "bound": "fp64_valu" if compute_bound else "hbm",
+        "kernel": kname,
+        "achieved": tflops if compute_bound else achieved,
+        "peak": FP64_PEAK_TFLOPS if compute_bound else HBM_PEAK_GBS,
+        "unit": "TFLOP/s" if compute_bound else "GB/s",
+        "frac": flop_frac if compute_bound else hbm_frac,
+        "hbm_frac": hbm_frac,
+        "hbm_achieved_GBs": achieved,
+        "flop_frac": flop_frac,
+        "flop_achieved_TFLOPs": tflops,
+        "algorithmic_flops_per_trajectory_step": flops_per_traj,
+        "flop_note": "SURVEY 8d formulas (dense condensed build, reference-form RLS) with the measured %.2f Newton solves per step; peak %.1f TFLOP/s fp64" % (newton_per_step, FP64_PEAK_TFLOPS),
+        "traffic": traffic,
+        "traffic_note": traffic_note,
+        "algorithmic_bytes_per_trajectory_step": bytes_per_traj,
+        "algorithmic_bytes_per_launch": bytes_per_launch,
+        "steps_per_launch": steps_per_launch,
+        "avg_kernel_ms": launch_ms,
+        "avg_lift_kernel_ms": lift_ms,
+        "kernel_time_source": "HIP events around the launches of the timed pass itself",
+    }
+    return {"dt": dt, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "roofline": roof, "extras": ex,
+            "worst_status": worst_status, "x_ok": x_ok, "newton_per_step": newton_per_step, "newton_max": newton_max,
+            "shared": main_loop.shared, "q": mpc.q, "text": c["text"]}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", default="cfg2", choices=sorted(CONFIGS))
+    ap.add_argument("--batch", type=int, default=0, help="trajectories per GPU (0: the configuration's)")
+    ap.add_argument("--L", type=int, default=0)
+    ap.add_argument("--N", type=int, default=0)
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--settle", type=int, default=-1,
+                    help="closed-loop steps after the RLS reset that belong to the set-up (-1: the configuration's default)")
+    ap.add_argument("--cold-start", action="store_true",
+                    help="start every QP at clip(0) like the reference instead of at the previous minimiser")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU baseline budget (0 = skip)")
+    ap.add_argument("--spin-seconds", type=float, default=1.0,
+                    help="untimed GPU activity on a scratch copy of the workload before the warm-up, so that the "
+                         "clocks have left their idle state when the W warm-up steps start")
+    ap.add_argument("--no-extras", action="store_true", help="skip the cold-start / post-reset measurements and the other configurations' legs")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend for --gpus N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal of the "
+                         "multi-rank code path, e.g. with --same-device on a one-GPU box; not a scaling measurement)")
+    ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal with --backend gloo)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.gpus != world:
+        sys.exit("bench.py --gpus %d inside a %d-rank job" % (args.gpus, world))
+    name = args.config
+    c = CONFIGS[name]
+    L, N, B = args.L or c["L"], args.N or c["N"], args.batch or c["B"]
+    settle = c["settle"] if args.settle < 0 else args.settle
+    # ---- CPU baseline first (rank 0 at N = 1 only): its worker processes are forked before anything touches the GPU
+    cpu = None
+    if world == 1 and args.cpu_seconds > 0:
+        cpu = cpu_baseline(name, L, N, initial_states_for(name, min(B, 4096), 101), args.cpu_seconds, settle)
+    import torch
+
+    if not torch.cuda.is_available():
+        if cpu is not None:
+            print("cpu_baseline (no GPU here, nothing else measured): %s" % json.dumps(cpu), file=sys.stderr)
+        sys.exit("bench.py needs a GPU: the hot path has no CPU implementation")
+    if args.same_device:
+        local = 0
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    pg_world, pg_backend = 1, "none (single process)"
+    if world > 1:
+        import torch.distributed as dist
+
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+        pg_world, pg_backend = dist.get_world_size(), dist.get_backend()
+        if pg_world != args.gpus:
+            sys.exit("bench.py --gpus %d but the process group has %d ranks" % (args.gpus, pg_world))
+
+    res = measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=not args.no_extras, spin_seconds=args.spin_seconds)
+
+    # ---- the other BASELINE configurations in the same run (short legs, no cold-start / post-reset pair, N = 1 only): what the
+    # driver's one line would otherwise not carry
+    others = {}
+    if name == "cfg2" and world == 1 and not args.no_extras and not (args.batch or args.L or args.N or args.cold_start):
+        for oname in ("cfg3", "cfg3-L20", "cfg4", "cfg5"):
+            oc = CONFIGS[oname]
+            try:
+                o = measure_config(oname, args, None, dev, 0, 1, oc["L"], oc["N"], oc["B"], oc["settle"], extras=False, spin_seconds=0.3)
+                others[oname] = {"value": o["value"], "unit": "steps/s", "ms_per_step": o["ms_per_step"], "frac": o["roofline"]["frac"],
+                                 "bound": o["roofline"]["bound"], "hbm_frac": o["roofline"]["hbm_frac"], "flop_frac": o["roofline"]["flop_frac"],
+                                 "kernel_ms": o["roofline"]["avg_kernel_ms"], "steps_per_launch": o["roofline"]["steps_per_launch"],
+                                 "worst_qp_status": o["worst_status"], "finite": o["x_ok"],
+                                 "mean_newton_solves_per_step": o["newton_per_step"], "trajectories": oc["B"], "workload": oc["text"]}
+            except Exception as e:  # (a leg that fails must not take the headline with it; it is reported)
+                others[oname] = {"error": "%s: %s" % (type(e).__name__, e)}
+            torch.cuda.empty_cache()
+
     if rank == 0:
         total = B * world
-        if main_loop.shared:
-            kname = "step_qp_kernel (box QPs of the shared model, %d blocks x 64 threads); lift, Gram (MFMA), model solve and condense are separate launches" % B
-        elif fused:
-            kname = "rollout_kernel (lift + RLS + condense + QP + plant, all %d steps in one launch), %d workgroups" % (steps_per_launch, (B + 15) // 16)
-        else:
-            kname = "step_kernel (RLS + condense + QP + plant), %d blocks x %d threads" % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64))
         out = {
             "metric": "MPC steps/s (lift+EDMD-update+QP, N=%d, %d-dim lift)" % (N, L),
-            "value": total * args.steps / dt,
+            "value": res["value"],
             "unit": "steps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
+            "ms_per_step": res["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -448,54 +559,48 @@ def main():
                             "warm-up; arithmetic in %s%s" % (c["text"], B, world, settle, args.dtype,
                                                             " (the config line names fp32; the reference computes in float64 and the 1e-6 bar on u needs it, DESIGN.md 4.1)" if name == "cfg2" else ""),
                 "global_batch": total,
+                "process_group": {"world_size": pg_world, "backend": pg_backend, "ranks_share_device": bool(args.same_device)},
                 **({"rehearsal": "ranks share cuda:0 / gloo collectives: exercises the multi-rank code path, NOT a scaling measurement"}
                    if (args.same_device or (world > 1 and args.backend != "nccl")) else {}),
-                "parallelism": ("trajectory-sharded x%d, one RCCL all-reduce of the %d-element Gram block per step" % (world, (2 * L + 3) * (L + 1))) if main_loop.shared
+                "parallelism": ("trajectory-sharded x%d, one RCCL all-reduce of the %d-element Gram block per step" % (world, (2 * L + 3) * (L + 1))) if res["shared"]
                                else "trajectory-sharded x%d, no collective on the step path" % world,
                 "qp": "exact box-QP (projected Newton), %s; mean Newton solves/step %.2f, worst trajectory total %d"
                       % ("each solve started at clip(0) like the reference" if args.cold_start else
                          "each solve started at the previous minimiser (the reference restarts at zeros: same minimiser, more work)",
-                         newton_per_step, newton_max),
-                "worst_qp_status": worst_status,
-                "finite": x_ok,
+                         res["newton_per_step"], res["newton_max"]),
+                "worst_qp_status": res["worst_status"],
+                "finite": res["x_ok"],
                 "u_tolerance": "controls within 1e-6 of the oracle in float64 (Van der Pol with P0 = 1e5: 1e-4, the re-association floor of the reference's own K_A inv_K_G product, DESIGN.md 2)",
             },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": kname,
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
-                "traffic_note": traffic_note,
-                "algorithmic_bytes_per_trajectory_step": bytes_per_traj,
-                "algorithmic_bytes_per_launch": bytes_per_launch,
-                "steps_per_launch": steps_per_launch,
-                "avg_kernel_ms": launch_ms,
-                "avg_lift_kernel_ms": lift_ms,
-                "kernel_time_source": "HIP events around the launches of the timed pass itself",
-            },
+            "roofline": res["roofline"],
         }
-        out.update(extras)
+        out.update(res["extras"])
+        if others:
+            out["other_configs"] = others
         if cpu is not None:
-            v, done, secs, cores = cpu["all"]
-            v1, done1, secs1 = cpu["one"]
-            ve, donee, secse = cpu["exact"]
+            v, done, busy, cores, wall = cpu["all"]
+            tv, tdone, tbusy = cpu["transient"]
+            regime = "settled"
+            if done == 0:  # (a configuration whose settle phase alone exceeds the budget: only the start-up transient was timed)
+                v, done, busy, regime = tv, tdone, tbusy, "post-reset transient only (the settle phase exceeded the CPU budget)"
             out["cpu_baseline"] = {
                 "value": v,
                 "unit": "steps/s",
                 "cores": cores,
                 "kind": "port",
-                "sample": "%d worker processes (one per core), each the first trajectories of its slice of the same workload x %d "
-                          "closed-loop steps: %d trajectory-steps in %.1f s; NumPy oracle, %s, one BLAS thread per worker; host reports %d cores"
-                          % (cores, cpu["spt"], done, secs,
+                "regime": regime,
+                "sample": "%d worker processes (one per core), each the first trajectories of its slice of the same workload: %d closed-loop steps "
+                          "after the RLS reset as set-up (the GPU leg's regime), then timed steps: %d trajectory-steps in %.1f core-seconds "
+                          "(%.1f s of wall time for the whole sample); value = cores x steps per core-second; NumPy oracle, %s, one BLAS thread per "
+                          "worker; host reports %d cores"
+                          % (cores, cpu["settle"], done, busy, wall,
                              "SciPy L-BFGS-B exactly as duffing.py:857-859" if cpu["solver"] == "lbfgsb" else
                              "exact active-set QP in place of quadprog (Tank_System.m:190), one pooled model per worker's 64 trajectories",
                              os.cpu_count()),
-                "single_core_value": v1,
-                "single_core_sample": "%d trajectory-steps in %.1f s" % (done1, secs1),
-                "exact_qp_variant_single_core_value": ve,
+                "single_core_value": cpu["one"][0],
+                "post_reset_value": tv,
+                "post_reset_sample": "the first %d steps after the reset of the same trajectories: %d trajectory-steps in %.1f core-seconds" % (cpu["post"], tdone, tbusy),
+                "exact_qp_variant_single_core_value": cpu["exact"],
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

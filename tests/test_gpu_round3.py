@@ -287,3 +287,87 @@ def test_mpc_solve_keeps_the_handles_terminal_block(torch_mod, KM):
         _, _, Ho, fo, co = ko.condense(A, Bm, Cm, psi[:, b].cpu().numpy(), r, N, 100.0, 1e-4, PN=PN)
         Ub = U[:, b].cpu().numpy()
         assert abs(float(fun[b]) - (Ub @ Ho @ Ub + fo @ Ub + co)) <= 1e-9 * max(1.0, abs(co))
+
+
+# ------------------------------------------------------------------ multi-rank readiness that a one-GPU box can prove
+def _bench_child(extra, timeout=900):
+    import json
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py")] + extra
+    p = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=timeout)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]  # rank 0 prints ONE line
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
+def test_bench_two_ranks_as_a_child_process(torch_mod, cfg):
+    """`python bench.py --gpus 2 --backend gloo --same-device` as the driver would start it for N > 1, minus the second GPU:
+    bench.py spawns its own two ranks (torch.distributed.run as a child, before any GPU call), they rendezvous on 127.0.0.1,
+    shard the trajectories, run the timed region between barriers and reduce the MAX; cfg4 also all-reduces the Gram block
+    between the two stages of every step.  The JSON line must say what the process group reported."""
+    d = _bench_child(["--gpus", "2", "--backend", "gloo", "--same-device", "--config", cfg, "--steps", "4", "--warmup", "2",
+                      "--cpu-seconds", "0", "--spin-seconds", "0", "--no-extras", "--settle", "6", "--batch", "512"])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2
+    pg = d["config"]["process_group"]
+    assert pg["world_size"] == 2 and pg["backend"] == "gloo" and pg["ranks_share_device"] is True
+    assert d["config"]["global_batch"] == 2 * 512
+    assert d["config"]["worst_qp_status"] == 0 and d["config"]["finite"] is True
+    assert d["value"] > 0 and abs(d["value"] - 2 * 512 * 4 / (d["ms_per_step"] * 4e-3)) < 1e-6 * d["value"]
+    assert "rehearsal" in d["config"]  # (never to be read as a scaling figure)
+
+
+_RCCL_CHILD = r"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.join(%(root)r, "koopman-online-updated-mpc_amd"))
+import numpy as np, torch
+from koopmpc import KoopmanMPC, _ffi
+# the RCCL of this process: torch's own copy when it exports the symbols, else the system library
+proc = C.CDLL(None)
+try:
+    proc.ncclCommInitRank
+    rccl = proc
+except AttributeError:
+    rccl = C.CDLL("librccl.so", mode=C.RTLD_GLOBAL)
+class UID(C.Structure):
+    _fields_ = [("b", C.c_char * 128)]
+uid = UID()
+rc = rccl.ncclGetUniqueId(C.byref(uid))
+comm = C.c_void_p()
+if rc == 0:
+    rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+    rc = rccl.ncclCommInitRank(C.byref(comm), 1, uid, 0)
+if rc != 0:
+    print("NO_COMM", rc); sys.exit(0)
+m = KoopmanMPC(n=2, L=8, N=10, batch=64, lift="rbf", centres=np.random.RandomState(0).rand(8, 2))
+lib = _ffi.load()
+ne = int(lib.kmpc_gram_elems(m.h))
+g = torch.arange(ne, dtype=torch.float64, device="cuda:0") * 0.5 + 1.0
+ref = g.clone()
+rc = lib.kmpc_allreduce_gram(m.h, C.c_void_p(g.data_ptr()), comm, C.c_void_p(torch.cuda.current_stream().cuda_stream))
+torch.cuda.synchronize()
+print("RC", rc, "EQUAL", bool(torch.equal(g, ref)), "ELEMS", ne)
+rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+rccl.ncclCommDestroy(comm)
+"""
+
+
+def test_allreduce_gram_through_rccl(torch_mod):
+    """kmpc_allreduce_gram on a real RCCL communicator (one rank: the sum over ranks is the block itself): the library resolves
+    ncclAllReduce from the process, passes the handle's element count as float64 / sum on the caller's stream and maps the
+    result code.  Run in a child process; when the box cannot create a communicator at all the test says so and skips."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run([sys.executable, "-c", _RCCL_CHILD % {"root": ROOT}], cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                       text=True, timeout=600)
+    out = p.stdout.strip().splitlines()
+    if p.returncode == 0 and out and out[-1].startswith("NO_COMM"):
+        pytest.skip("RCCL could not create a one-rank communicator on this box: %s" % out[-1])
+    assert p.returncode == 0, p.stderr[-3000:]
+    assert out and out[-1].startswith("RC 0 EQUAL True"), (p.stdout[-500:], p.stderr[-1500:])
