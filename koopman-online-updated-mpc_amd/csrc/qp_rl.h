@@ -143,6 +143,10 @@ __device__ __forceinline__ void rl_sweep_set(double (&M)[N_], double& rs, double
   }
 }
 
+// row stride of H / the tableau in LDS: even (16-byte row accesses) with an odd half, so that 16 consecutive rows start in 16
+// different groups of four banks -- N = 20 becomes 22 (with stride 20 the rows of lanes 8 apart collide), N = 30 and 10 stay
+constexpr int rl_stride(int N) { return ((((N + 1) & ~1) / 2) & 1) ? ((N + 1) & ~1) : ((N + 1) & ~1) + 2; }
+
 struct QpCarry {  // what a solve leaves for the next one (registers of the step loop; the rows themselves wait in LDS)
   unsigned smask;   // variables swept into the carried tableau
   int valid;        // 0: no tableau (rebuild), 1: carried
@@ -172,7 +176,8 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   const int max_iter = a.max_iter;
   constexpr unsigned ownmask = N_ >= 32 ? 0xffffffffu : ((1u << N_) - 1u);
   const int rowi = own ? t : N_ - 1;
-  const double* const hrow = sR + rowi * N_;
+  constexpr int NS = rl_stride(N_);
+  const double* const hrow = sR + rowi * NS;
   auto load_h_rows = [&]() {
     if constexpr ((N_ & 1) == 0) {
       const d2_t* h2 = reinterpret_cast<const d2_t*>(__builtin_assume_aligned(hrow, 16));
@@ -263,7 +268,21 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
           carried = false;
           rebuild = false;
         }
-        if (Smask != Fmask) rl_sweep_set<N_>(M, rs, rsi, Smask ^ Fmask, Smask, Fmask, broke, pass == 1, t, half);  // (one test instead of N when nothing changes sides)
+        if (Smask != Fmask) {  // (one test instead of N when nothing changes sides)
+          // more variables change sides than F has members: sweeping F into a fresh 2H is the shorter way
+          // (a saturated solution met from the all-free tableau, or the other way round)
+          if (__builtin_popcount(Smask ^ Fmask) > __builtin_popcount(Fmask) + 2) {
+            if (!half) {
+              load_h_rows();
+#pragma unroll
+              for (int j = 0; j < N_; ++j) M[j] *= 2.0;
+            }
+            rs = 1.0; rsi = 1.0;
+            Smask = 0u;
+            carried = false;
+          }
+          rl_sweep_set<N_>(M, rs, rsi, Smask ^ Fmask, Smask, Fmask, broke, pass == 1, t, half);
+        }
         if (!broke || pass == 1) break;
         if (!carried) ++refresh;  // (a carried tableau that breaks down is simply replaced; only fresh ones count towards giving up)
         rebuild = true;  // pass 1: from 2H, dropping a variable whose pivot fails
@@ -298,13 +317,18 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
       if (!predict || broke || rounds >= N_) break;
       const double cand = x + pdir;
       const double over = isF ? (cand - ub > lb - cand ? cand - ub : lb - cand) : -1.0;
-      if ((unsigned)__ballot(over > 0.0) == 0u) break;  // (the usual case: the Newton point is feasible)
+      const unsigned offenders = (unsigned)__ballot(over > 0.0);
+      if (offenders == 0u) break;  // (the usual case: the Newton point is feasible)
+      // prediction is for the one or two inputs that cross a bound from step to step; a Newton point with many offenders
+      // (a solve started far from its solution, e.g. at zeros with a saturated minimiser) is projected as a whole instead:
+      // one iteration moves them all, where the rounds would take one sweep and one Newton point each
+      if (rounds == 0 && __builtin_popcount(offenders) > 2) break;
       const double worst = half_max(over);
       const int jl = __ffs((int)(unsigned)__ballot(over == worst)) - 1;  // the variable (= its lane in the lower half)
       const double bj = cand > ub ? ub : lb;
       const double delta = lane_bcast(bj - x, jl);
       if (tid == jl) qx_out[jl] = bj;
-      if (own) g += 2.0 * sR[t * N_ + jl] * delta;  // gradient at the new base point (H is intact in LDS)
+      if (own) g += 2.0 * sR[t * NS + jl] * delta;  // gradient at the new base point (H is intact in LDS)
       Fmask &= ~(1u << jl);
       ++rounds;
     }
@@ -398,7 +422,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   // iterations leaves nothing: the next one starts from 2H.
   const bool keep = status == 0 && !(carried && (it >= 4 || nref >= 5));
   if (keep && own && !half) {
-    double* const trow = sR + t * N_;
+    double* const trow = sR + t * NS;
     if constexpr ((N_ & 1) == 0) {
       d2_t* t2 = reinterpret_cast<d2_t*>(__builtin_assume_aligned(trow, 16));
 #pragma unroll

@@ -36,7 +36,7 @@ static constexpr bool step_v2_dims(int L, int N, int q) { return q != L && q > 0
 //   zp   N q     zeros: e_j beyond the horizon (the f lanes of the H / f pass read past the end)             persistent
 //   vec  red 16 | f N | predicted bounds N | e (one q-block in front, N q) ... zp ... | g (N+1) q | dump 64 + (N+1) q
 // (the fall-back solver's vectors alias g and the dump).  Nothing here is overlaid by the lift scratch.
-static constexpr int v2_region1(int N) { return (N * N + 1) & ~1; }
+static constexpr int v2_region1(int N) { return (N * rl_stride(N) + 1) & ~1; }  // (padded row stride: qp_rl.h)
 static constexpr int v2_carry_elems() { return 130; }
 static constexpr int v2_vec_elems(int q, int N) { return 16 + 2 * ((N + 1) & ~1) + (q + 2 * N * q) + imax(3 * N, 2 * (N + 1) * q + 64) + 2; }
 static constexpr size_t v2_lds_elems(int L, int q, int N) { return ((size_t)v2_region1(N) + v2_carry_elems() + v2_vec_elems(q, N) + 1) & ~(size_t)1; }
@@ -303,7 +303,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     cs.smask = (unsigned)__builtin_amdgcn_readfirstlane(ci[0]);  // (wave-uniform: the solve branches on them)
     cs.valid = __builtin_amdgcn_readfirstlane(ci[1]);
     if (cs.valid) {
-      const double* const trow = sR + (t < N_ ? t : N_ - 1) * N_;
+      const double* const trow = sR + (t < N_ ? t : N_ - 1) * rl_stride(N_);
       if constexpr ((N_ & 1) == 0) {
         const d2_t* t2 = reinterpret_cast<const d2_t*>(__builtin_assume_aligned(trow, 16));
 #pragma unroll
@@ -327,7 +327,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     const dq_t* const gq = reinterpret_cast<const dq_t*>(__builtin_assume_aligned(sG, Q_ == 2 ? 16 : 8));
     const dq_t* const wq = reinterpret_cast<const dq_t*>(__builtin_assume_aligned((hf ? sEr : sG) + idx * Q_, Q_ == 2 ? 16 : 8));
     double acc = 0.0;
-    double* const h1 = sR - idx * N_;
+    constexpr int NS = rl_stride(N_);
+    double* const h1 = sR - idx * NS;
     double* const h2 = sR - idx;
     const double Qw = a.Qw, rdiag = idx == 0 ? a.Rw : 0.0;  // (read once: inside the masked regions below every use was a scalar load of its own)
 #pragma unroll
@@ -342,8 +343,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       }
       if (tid < N_ - tt) {  // lanes idx < N - tt of the lower half: (aa, bb) = (N-1-tt-idx, N-1-tt) is inside H
         const double hv = Qw * acc + rdiag;
-        h1[(N_ - 1 - tt) * (N_ + 1)] = hv;
-        h2[(N_ - 1 - tt) * (N_ + 1)] = hv;
+        h1[(N_ - 1 - tt) * (NS + 1)] = hv;
+        h2[(N_ - 1 - tt) * (NS + 1)] = hv;
       }
     }
     if (hf && idx < N_) sf[idx] = 2.0 * Qw * acc;
@@ -360,7 +361,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       double acc = 0.0;
       for (int r = 0; r < q; ++r)
         for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * (0.5 * (Wt[r * q + s2] + Wt[s2 * q + r])) * gb[s2];
-      sR[e] += acc;
+      sR[aa * rl_stride(N_) + bb] += acc;
     }
     for (int aa = tid; aa < N; aa += 64) {
       const double* ga = sG + (N - 1 - aa) * q;
@@ -383,7 +384,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       // LDS tableau in its place
       block_sync<64>();
       double* const Hg = a.qp_scratch + (size_t)b * N * N;
-      for (int e = tid; e < N * N; e += 64) Hg[e] = sR[e];
+      for (int e = tid; e < N * N; e += 64) Hg[e] = sR[(e / N) * rl_stride(N_) + (e % N)];
       __threadfence_block();
       block_sync<64>();
       qp_lds<double, 64>(Hg, sf, sR, qxo, qxa, qg, red, a, sv, b, N, true);
