@@ -248,6 +248,28 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       // waves only take part in the barriers.
       const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
       const bool hid = wv < MTH, out = wv < MTO;
+      if (V2 && !hid && !out) {
+        // A wave without a tile of the encoder only takes part in its barriers (2 + layers of them).  Register-state step: it
+        // does the covariance half of its trajectory's RLS update meanwhile -- inv_K_G, bar_Q only need [psi(x_{k-1}); u_{k-1}]
+        // -- and meets the others at the second and third barrier from inside v2_rls_cov.  (The waves WITH a tile did theirs at
+        // the end of the previous step: they are the oldest of their SIMDs and finish the step body first.)
+        __syncthreads();
+        if constexpr (V2) {
+          if (live && k > 0 && !R.no_update) {
+            int woff0 = R.wbase + wv * R.wstride, bk0 = b;
+            asm volatile("" : "+s"(woff0), "+s"(bk0));
+            double* const wsm0 = smem + woff0;
+            const double uk = a.u_prev[bk0];  // u_{k-1}: the previous step stored it (u_store) when its solve ended
+            const int t0 = lane & 31;
+            const double z0 = t0 < L_ ? psi_prev_reg : (t0 == L_ ? uk : 0.0);
+            v2_cov_slot<N_>(wsm0)[lane] = v2_rls_cov<L_, true>(R.img + (size_t)bk0 * R.img_stride, z0, a.lam);
+          } else {
+            __syncthreads();
+            __syncthreads();
+          }
+        }
+        for (int i = 0; i < R.nhh; ++i) __syncthreads();
+      } else {
       // A-fragments in two alternating batches of 8 k-steps: the first batch of a layer is requested a layer ahead
       // (it travels across the barrier), every further batch while the previous one is being multiplied
       double af[2][RO_KB2];
@@ -316,6 +338,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
         }
         __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
       }
+      }
       if ((lane & PSI_MASK) < L) psi_i = sPsi[(lane & PSI_MASK) * 16 + wv];
     }
 
@@ -341,7 +364,9 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
       sv.x_next = RBF ? nullptr : sXn + wv * 4;
       sv.cov_done = (k > 0 && !R.no_update) ? 1 : 0;
-      sv.cov_ahead = (k + 1 < R.steps && !R.no_update) ? 1 : 0;
+      // (waves without an encoder tile do the next step's covariance half inside the next lift instead: see above)
+      const bool tile_wave = RBF || NW == 4 || wv < ((KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp) >> 4) || wv < (R.Lp >> 4);
+      sv.cov_ahead = (k + 1 < R.steps && !R.no_update && tile_wave) ? 1 : 0;
       // (16 trajectories per CU with a long horizon -- the RBF roll-out of cfg3 -- : H re-read from LDS, and the active-set
       //  safeguard stays the fall-back on the global-scratch tableau instead of living in registers: 67 -> 51 spilled
       //  registers, 109.7 -> 117.8 M steps/s; its crawling solves are 14 of 327 680 on that workload)

@@ -100,6 +100,68 @@ __device__ __forceinline__ void halves_both(double a, double& lo, double& hi) {
 // ---------------------------------------------------------------------------------------
 // the step
 // ---------------------------------------------------------------------------------------
+// The covariance half of the RLS update on the wave image: inv_K_G <- (inv_K_G - Pz Pz' / d) / lam, bar_Q <- bar_Q - (Q psi)(Q psi)' / dc
+// (duffing.py:931-932, 947-951), z = [psi; u] in the lanes of both halves.  Returns lanes < p: g_i = (P z)_i / d, lanes 32 + i:
+// h_i = (bar_Q psi)_i / dc (the gains of the model half).  SYNC: the caller is a wave of a roll-out workgroup that has no tile
+// of the cooperative encoder -- it does this work in the encoder's shadow and meets the other waves at the encoder's second
+// and third barrier from inside (request | barrier | products, d | barrier | downdate, write back).
+template <int L_, bool SYNC>
+__device__ __forceinline__ double v2_rls_cov(double* const img, const double z, const double lam) {
+  typedef double d2_t __attribute__((ext_vector_type(2)));
+  constexpr int P_ = L_ + 1, CP = (L_ + 2) / 2, NC = 2 * CP, S2 = 2 * L_ + 1;
+  const int tid = local_tid<64>(), half = tid >> 5, t = tid & 31;
+  const d2_t* const im = reinterpret_cast<const d2_t*>(img);
+  d2_t* const imw = reinterpret_cast<d2_t*>(img);
+  const int slot2 = half ? P_ + (t < L_ ? t : L_ - 1) : (t < P_ ? t : P_ - 1);
+  double R2[NC];
+#pragma unroll
+  for (int c = 0; c < CP; ++c) {
+    const d2_t v = im[c * S2 + slot2];
+    R2[2 * c] = v.x; R2[2 * c + 1] = v.y;
+  }
+  if constexpr (SYNC) __syncthreads();
+  double zv0, zv1;
+  half_gather(z, zv0, zv1);
+  double a2[4] = {0.0, 0.0, 0.0, 0.0};
+  rowdot1<P_, NC>(a2, zv0, zv1, R2);
+  const double acc2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);  // lanes < p: (P z)_i ; lanes 32 + i: (bar_Q psi)_i
+  // d = lam + z'Pz (lanes 0-31), dc = 1 + psi' bar_Q psi (lanes 32-63): one sum per half
+  double s = ((half && t >= L_) ? 0.0 : z) * acc2;
+  s += dpp_shr(s, 1);
+  s += dpp_shr(s, 2);
+  s += dpp_shr(s, 4);
+  s += dpp_shr(s, 8);
+  double rt = 0.0;
+  fmac_rowbcast<15, true>(rt, s, 1.0);  // the total of this lane's 16-lane row
+  double r0, r1;
+  half_gather(rt, r0, r1);
+  const double dd = (half ? 1.0 : lam) + (r0 + r1);
+  const double dinv = 1.0 / dd;
+  const double c2 = -acc2 * dinv;
+  if constexpr (SYNC) __syncthreads();
+  double w0, w1;
+  half_gather(acc2, w0, w1);
+  rowupd<P_, NC, L_>(R2, w0, w1, c2);
+  if (lam != 1.0) {
+    const double sc = half ? 1.0 : 1.0 / lam;
+#pragma unroll
+    for (int c = 0; c < P_; ++c) R2[c] *= sc;
+  }
+  if (half ? t < L_ : t < P_) {
+#pragma unroll
+    for (int c = 0; c < CP; ++c) {
+      d2_t v;
+      v.x = R2[2 * c]; v.y = R2[2 * c + 1];
+      imw[c * S2 + slot2] = v;
+    }
+  }
+  return acc2 * dinv;
+}
+// LDS slots of a wave's region that the roll-out kernel touches itself: the gains of a covariance update done ahead, the
+// first move of the last solve
+template <int N_> __device__ __forceinline__ double* v2_cov_slot(double* sm) { return sm + v2_region1(N_) + 66; }
+template <int N_> __device__ __forceinline__ double* v2_first_move_slot(double* sm) { return sm + v2_region1(N_) + v2_carry_elems() + 15; }
+
 // sv.psi_now_v / psi_prev_v: lane with (lane & 31) = i < L carries psi_i (BOTH halves).  img: this trajectory's wave image.
 template <int L_, int N_, int Q_, bool LOWREG, bool ASREG>
 __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar<double>& sv, const int b, double* const sm, double* const img) {
@@ -150,52 +212,6 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   const d2_t* const im = reinterpret_cast<const d2_t*>(img);
   d2_t* const imw = reinterpret_cast<d2_t*>(img);
   const double psin = sv.psi_now_v;
-  // inv_K_G <- (inv_K_G - Pz Pz' / d) / lam ; bar_Q <- bar_Q - (Q psi)(Q psi)' / dc        duffing.py:931-932, 947-951
-  // returns lanes < p: g_i = (P z)_i / d, lanes 32 + i: h_i = (bar_Q psi)_i / dc  (the gains of the model half)
-  auto rls_cov = [&](const double z) -> double {
-    const int slot2 = half ? P_ + (t < L_ ? t : L_ - 1) : (t < P_ ? t : P_ - 1);
-    double R2[NC];
-#pragma unroll
-    for (int c = 0; c < CP; ++c) {
-      const d2_t v = im[c * S2 + slot2];
-      R2[2 * c] = v.x; R2[2 * c + 1] = v.y;
-    }
-    double zv0, zv1;
-    half_gather(z, zv0, zv1);
-    double a2[4] = {0.0, 0.0, 0.0, 0.0};
-    rowdot1<P_, NC>(a2, zv0, zv1, R2);
-    const double acc2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);  // lanes < p: (P z)_i ; lanes 32 + i: (bar_Q psi)_i
-    // d = lam + z'Pz (lanes 0-31), dc = 1 + psi' bar_Q psi (lanes 32-63): one sum per half
-    double s = ((half && t >= L_) ? 0.0 : z) * acc2;
-    s += dpp_shr(s, 1);
-    s += dpp_shr(s, 2);
-    s += dpp_shr(s, 4);
-    s += dpp_shr(s, 8);
-    double rt = 0.0;
-    fmac_rowbcast<15, true>(rt, s, 1.0);  // the total of this lane's 16-lane row
-    double r0, r1;
-    half_gather(rt, r0, r1);
-    const double dd = (half ? 1.0 : a.lam) + (r0 + r1);
-    const double dinv = 1.0 / dd;
-    const double c2 = -acc2 * dinv;
-    double w0, w1;
-    half_gather(acc2, w0, w1);
-    rowupd<P_, NC, L_>(R2, w0, w1, c2);
-    if (a.lam != 1.0) {
-      const double sc = half ? 1.0 : 1.0 / a.lam;
-#pragma unroll
-      for (int c = 0; c < P_; ++c) R2[c] *= sc;
-    }
-    if (half ? t < L_ : t < P_) {
-#pragma unroll
-      for (int c = 0; c < CP; ++c) {
-        d2_t v;
-        v.x = R2[2 * c]; v.y = R2[2 * c + 1];
-        imw[c * S2 + slot2] = v;
-      }
-    }
-    return acc2 * dinv;
-  };
   if (sv.phases & PH_RLS) {
     const bool fu = sv.first_update != 0;
     if (!fu) {
@@ -214,7 +230,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     // z = [psi(x_{k-1}); u_{k-1}] in the lanes of both halves
     const double z = t < L_ ? sv.psi_prev_v : (t == L_ ? up : 0.0);
     KTRACE(1);
-    const double u2 = sv.cov_done ? sCov[tid] : rls_cov(z);
+    const double u2 = sv.cov_done ? sCov[tid] : v2_rls_cov<L_, false>(img, z, a.lam);
     KTRACE(2);
     double zv0, zv1;
     half_gather(z, zv0, zv1);
@@ -405,7 +421,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     if (sv.cov_ahead) {
       // the covariance half of the NEXT step's update: its regressor [psi(x_k); u_k] is complete now
       const double uk = (a.du_mode ? up : 0.0) + red[15];  // (the solve leaves its first move there)
-      sCov[tid] = rls_cov(t < L_ ? psin : (t == L_ ? uk : 0.0));
+      sCov[tid] = v2_rls_cov<L_, false>(img, t < L_ ? psin : (t == L_ ? uk : 0.0), a.lam);
     }
   }
 }
