@@ -29,7 +29,12 @@ m.reset()
 m.offline_fit(*offline_data())
 X.copy_(X0)
 m.iters.zero_()
-m.rollout("duffing", X, r, steps, step0=0)
+pre = int(os.environ.get("KMPC_TRACE_PRE", "0"))  # closed-loop steps in an earlier launch (the traced launch then starts settled)
+if pre:
+    m.rollout("duffing", X, r, pre, step0=0)
+    torch.cuda.synchronize()
+    m.iters.zero_()
+m.rollout("duffing", X, r, steps, step0=pre)
 torch.cuda.synchronize()
 nb = min(B, 8192)
 buf = np.zeros(8192 * 32, dtype=np.uint64)
@@ -94,3 +99,17 @@ if fused:
         sel = order[int(lo * nb):int(hi * nb)]
         print("  waves finishing in quartile %.2f-%.2f: finish %.0f-%.0f us, wait+lift %.2f, body %.2f us/step"
               % (lo, hi, fin[sel].min(), fin[sel].max(), sl[sel].mean(), sb[sel].mean()))
+if fused and os.environ.get("KMPC_TRACE_WG"):
+    # which workgroups are slow: finish time against the Newton solves of its trajectories and against its index (placement)
+    wgfin = (t[:, 18].reshape(-1, G).max(1) - t[:, 19].min()) / 100.0
+    itw = t[:, 15].reshape(-1, G)
+    itsum = m.iters.cpu().numpy()[:nb].reshape(-1, G)
+    order = np.argsort(wgfin)
+    print("workgroup finish: min %.0f median %.0f p90 %.0f max %.0f us" % (wgfin.min(), np.median(wgfin), np.percentile(wgfin, 90), wgfin.max()))
+    print("corr(finish, sum of Newton solves of the WG) %.2f, corr(finish, max over its trajectories) %.2f, corr(finish, WG index %% 8 = XCD) %.2f"
+          % (np.corrcoef(wgfin, itsum.sum(1))[0, 1], np.corrcoef(wgfin, itsum.max(1))[0, 1], np.corrcoef(wgfin, np.arange(len(wgfin)) % 8)[0, 1]))
+    for name, sel in (("fastest 10%", order[:len(order) // 10]), ("slowest 10%", order[-(len(order) // 10):])):
+        print("  %s: finish %.0f us, Newton solves per trajectory-step mean %.2f max %.2f, WG indices mod 8: %s" % (
+            name, wgfin[sel].mean(), itsum[sel].mean() / steps, itsum[sel].max() / steps, np.bincount(sel % 8, minlength=8).tolist()))
+    xcd = [wgfin[np.arange(len(wgfin)) % 8 == i].mean() for i in range(8)]
+    print("  mean finish by WG index mod 8:", " ".join("%.0f" % v for v in xcd))
