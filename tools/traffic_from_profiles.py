@@ -1,8 +1,10 @@
 """Dev tool: profiles/traffic.json entries from the PMC passes of tools/profile_config.sh.
     python tools/traffic_from_profiles.py <config> <gpurun_out/prof_dir> <profiles/summary name>
-HBM bytes per trajectory-step of the dominant kernel = (FETCH_SIZE x 1.593 + WRITE_SIZE) KiB per launch / (trajectories x steps
-per launch); 1.593 is round 1's own-pattern calibration of FETCH_SIZE (8-byte-per-lane coalesced reads report 0.628 of the
-bytes, profiles/r1_traffic.json); the counters are the mean over the last third of the kernel's launches (summary.txt)."""
+HBM bytes per trajectory-step of the dominant kernel = (FETCH_SIZE x c + WRITE_SIZE) KiB per launch / (trajectories x steps
+per launch).  c = 2 for the register-state roll-outs (round 3: the state is read as 16-byte-per-lane coalesced loads, for which
+gfx950's FETCH_SIZE reports exactly half of the bytes, MI355X_MICROARCH.md "HBM"); c = 1.593 for the kernels that still read
+8 bytes per lane (round 1's own-pattern calibration, profiles/r1_traffic.json).  The counters are the mean over the last third
+of the kernel's launches (summary.txt)."""
 import json, os, re, sys
 cfg, d, summary_name = sys.argv[1], sys.argv[2], sys.argv[3]
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -25,11 +27,13 @@ L, N = [int(x) for x in re.search(r"N=(\d+), (\d+)-dim", bf["metric"]).groups()]
 units = B * bf["roofline"]["steps_per_launch"]
 fetch_raw = vals[("fetch", "FETCH_SIZE")] * 1024.0 / units
 write = vals[("write", "WRITE_SIZE")] * 1024.0 / (B * bw["roofline"]["steps_per_launch"])
-entry = {"L": L, "N": N, "B": B, "bytes_per_trajectory_step": fetch_raw * 1.593 + write,
-         "fetch_bytes_per_trajectory_step_raw": fetch_raw, "write_bytes_per_trajectory_step": write, "fetch_calibration": 1.593,
-         "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x 1.593 (own-pattern calibration of "
-                   "round 1: 8-byte-per-lane coalesced reads report 0.628 of the bytes) + WRITE, dominant kernel %s, last third of its "
-                   "launches" % (summary_name, dom)}
+wide = fused and (L + 2 <= 32) and "y = C x" in bf["config"]["workload"] or (fused and cfg in ("cfg2", "cfg3", "cfg3-L20"))
+cal = 2.0 if wide else 1.593
+entry = {"L": L, "N": N, "B": B, "bytes_per_trajectory_step": fetch_raw * cal + write,
+         "fetch_bytes_per_trajectory_step_raw": fetch_raw, "write_bytes_per_trajectory_step": write, "fetch_calibration": cal,
+         "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x %s (%s) + WRITE, dominant kernel %s, "
+                   "last third of its launches" % (summary_name, cal, "16-byte-per-lane coalesced reads: gfx950 reports half the bytes, MI355X_MICROARCH.md" if wide
+                                                   else "own-pattern calibration of round 1: 8-byte-per-lane coalesced reads report 0.628 of the bytes", dom)}
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tp))
 key = "%s:f64:%s" % (cfg, "fused" if fused else "steps")
