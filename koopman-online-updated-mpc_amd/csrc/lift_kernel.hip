@@ -12,6 +12,7 @@
 // v_mfma_f64_16x16x4_f64 / v_mfma_f32_16x16x4_f32: A lane l holds A[l&15][l>>4],
 // B lane l holds B[l>>4][l&15]; bias + ReLU are fused on the accumulator registers.
 #include "kernels.h"
+#include "plant_device.h"
 #include <cstdlib>
 
 namespace kmpc {
@@ -293,7 +294,7 @@ template <typename T> __global__ __launch_bounds__(256) void lift_rbf_kernel(con
           const T d = x[i] - scx[j * n + i];
           r2 += d * d;
         }
-        v = r2 > T(0) ? r2 * log(sqrt(r2)) : T(0);  // NaN -> 0 (rbf.m:28)
+        v = r2 > T(0) ? r2 * kmpc_logT<T>(sqrt(r2)) : T(0);  // NaN -> 0 (rbf.m:28)
       } else {
         // sklearn euclidean_distances: sqrt(max(|x|^2 - 2 x.c + |c|^2, 0))
         T xx = T(0), cc = T(0), xc = T(0);
@@ -306,7 +307,7 @@ template <typename T> __global__ __launch_bounds__(256) void lift_rbf_kernel(con
         T d2 = xx - T(2) * xc + cc;
         d2 = d2 > T(0) ? d2 : T(0);
         const T d = sqrt(d2);
-        v = d * d * log(d + a.eps);
+        v = d * d * kmpc_logT<T>(d + a.eps);  // (the same logarithm as the fused roll-out's lift: plant_device.h)
       }
       a.Psi[(size_t)j * a.ps_l + (size_t)b * a.ps_b] = v;
     }

@@ -41,4 +41,45 @@ template <typename T> __device__ __forceinline__ void plant_apply(int plant, int
   x2 = n2;
 }
 
+
+// ---------------------------------------------------------------------------------------
+// Natural logarithm for the thin-plate RBF dictionary (vanderpol_RBF.py:21-22, rbf.m:26-29), positive normal arguments.
+// The library log() keeps its dozen polynomial coefficients in vector registers for the whole kernel once the step loop of a
+// roll-out makes them loop-invariant (24 VGPRs of the 128 a trajectory has: the N = 30 roll-out spilled because of them and
+// re-read them from scratch memory at every step).  Here every coefficient is written into its register where it is used, by
+// an instruction the optimiser cannot move (two v_mov_b32 each: 32 instructions a step).  Algorithm: the classical reduction
+// x = 2^k (1 + f), sqrt(1/2) <= 1 + f < sqrt(2), s = f / (2 + f), log(1 + f) = f - f^2/2 + s (f^2/2 + R(s^2)) with the degree-7
+// minimax polynomial R of fdlibm's e_log.c (error < 1 ulp).
+// ---------------------------------------------------------------------------------------
+template <unsigned HI, unsigned LO> __device__ __forceinline__ double kmpc_const() {
+  int h, l;
+  asm volatile("v_mov_b32 %0, %2\n\tv_mov_b32 %1, %3" : "=v"(l), "=v"(h) : "n"(LO), "n"(HI));
+  return __hiloint2double(h, l);
+}
+__device__ __forceinline__ double kmpc_log(double x) {
+  int k = __builtin_amdgcn_frexp_exp(x);          // x = m 2^k, 0.5 <= m < 1
+  double m = __builtin_amdgcn_frexp_mant(x);
+  if (m < kmpc_const<0x3fe6a09eu, 0x667f3bcdu>()) { m *= 2.0; k -= 1; }  // sqrt(1/2)
+  const double f = m - 1.0;
+  const double s = f / (2.0 + f);
+  const double z = s * s, w = z * z;
+  double t1 = kmpc_const<0x3fc39a09u, 0xd078c69fu>();                    // Lg6
+  t1 = __builtin_fma(w, t1, kmpc_const<0x3fcc71c5u, 0x1d8e78afu>());     // Lg4
+  t1 = __builtin_fma(w, t1, kmpc_const<0x3fd99999u, 0x9997fa04u>());     // Lg2
+  t1 *= w;
+  double t2 = kmpc_const<0x3fc2f112u, 0xdf3e5244u>();                    // Lg7
+  t2 = __builtin_fma(w, t2, kmpc_const<0x3fc74664u, 0x96cb03deu>());     // Lg5
+  t2 = __builtin_fma(w, t2, kmpc_const<0x3fd24924u, 0x94229359u>());     // Lg3
+  t2 = __builtin_fma(w, t2, kmpc_const<0x3fe55555u, 0x55555593u>());     // Lg1
+  t2 *= z;
+  const double R = t2 + t1;
+  const double hfsq = 0.5 * f * f;
+  const double dk = (double)k;
+  // k ln2_hi - ((hfsq - (s (hfsq + R) + k ln2_lo)) - f)
+  return dk * kmpc_const<0x3fe62e42u, 0xfee00000u>() - ((hfsq - (s * (hfsq + R) + dk * kmpc_const<0x3dea39efu, 0x35793c76u>())) - f);
+}
+template <typename T> __device__ __forceinline__ T kmpc_logT(T x);
+template <> __device__ __forceinline__ double kmpc_logT<double>(double x) { return kmpc_log(x); }
+template <> __device__ __forceinline__ float kmpc_logT<float>(float x) { return logf(x); }
+
 }  // namespace kmpc

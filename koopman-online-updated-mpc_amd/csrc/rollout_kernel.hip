@@ -91,7 +91,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
     sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? ra.s.X_rw[(size_t)(tid0 & 63) * B + b] : 0.0;
 
   if constexpr (ro_v2<L_, N_, Q_>()) {
-    if (live) step_v2_init<N_, Q_>(smem + ra.wbase + wave * ra.wstride);
+    if (live) step_v2_init<L_, N_, Q_>(smem + ra.wbase + wave * ra.wstride);
   }
   bool have_prev = ra.have_prev != 0, fresh = ra.rls_fresh != 0;
   int cur = ra.cur;
@@ -129,14 +129,14 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
         if (R.rbf_matlab) {
           double r2 = 0.0;
           for (int i = 0; i < n; ++i) { const double d = x[i] - c[i]; r2 += d * d; }
-          psi_i = r2 > 0.0 ? r2 * log(sqrt(r2)) : 0.0;
+          psi_i = r2 > 0.0 ? r2 * kmpc_log(sqrt(r2)) : 0.0;
         } else {
           double xx = 0.0, cc = 0.0, xc = 0.0;
           for (int i = 0; i < n; ++i) { xx += x[i] * x[i]; cc += c[i] * c[i]; xc += x[i] * c[i]; }
           double d2 = xx - 2.0 * xc + cc;
           d2 = d2 > 0.0 ? d2 : 0.0;
           const double d = sqrt(d2);
-          psi_i = d * d * log(d + R.eps);
+          psi_i = d * d * kmpc_log(d + R.eps);
         }
       }
     } else if constexpr (NW == 4) {  // (written for 4 or 8 columns; with 8 the 16x16x4 path below measures better: 89 vs 87 M steps/s)
@@ -262,7 +262,8 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
             const double uk = a.u_prev[bk0];  // u_{k-1}: the previous step stored it (u_store) when its solve ended
             const int t0 = lane & 31;
             const double z0 = t0 < L_ ? psi_prev_reg : (t0 == L_ ? uk : 0.0);
-            v2_cov_slot<N_>(wsm0)[lane] = v2_rls_cov<L_, true>(R.img + (size_t)bk0 * R.img_stride, z0, a.lam);
+            const double gains0 = v2_rls_cov<L_, true>(R.img + (size_t)bk0 * R.img_stride, z0, a.lam);
+            if (lane < 32 || t0 < L_) v2_cov_slot<N_>(wsm0)[v2_cov_index<L_>(lane)] = gains0;
           } else {
             __syncthreads();
             __syncthreads();

@@ -37,9 +37,13 @@ static constexpr bool step_v2_dims(int L, int N, int q) { return q != L && q > 0
 //   vec  red 16 | f N | predicted bounds N | e (one q-block in front, N q) ... zp ... | g (N+1) q | dump 64 + (N+1) q
 // (the fall-back solver's vectors alias g and the dump).  Nothing here is overlaid by the lift scratch.
 static constexpr int v2_region1(int N) { return (N * rl_stride(N) + 1) & ~1; }  // (padded row stride: qp_rl.h)
-static constexpr int v2_carry_elems() { return 130; }
-static constexpr int v2_vec_elems(int q, int N) { return 16 + 2 * ((N + 1) & ~1) + (q + 2 * N * q) + imax(3 * N, 2 * (N + 1) * q + 64) + 2; }
-static constexpr size_t v2_lds_elems(int L, int q, int N) { return ((size_t)v2_region1(N) + v2_carry_elems() + v2_vec_elems(q, N) + 1) & ~(size_t)1; }
+static constexpr int v2_cov_elems(int L) { return 32 + ((L + 1) & ~1); }  // gains of a covariance update done ahead: lanes 0-31, lanes 32 .. 32+L-1
+static constexpr int v2_carry_elems(int L) { return 66 + v2_cov_elems(L); }
+// long horizons (N >= 30): the recursion's stores are masked instead of sending the lanes without an output to a dump area --
+// the kilobyte is the difference between 14 and 16 trajectories per CU there
+static constexpr bool v2_chain_dump(int N) { return N < 30; }
+static constexpr int v2_vec_elems(int q, int N) { return 16 + 2 * ((N + 1) & ~1) + (q + 2 * N * q) + imax(2 * N, (N + 1) * q + (v2_chain_dump(N) ? (N + 1) * q + 64 : 0)) + 2; }
+static constexpr size_t v2_lds_elems(int L, int q, int N) { return ((size_t)v2_region1(N) + v2_carry_elems(L) + v2_vec_elems(q, N) + 1) & ~(size_t)1; }
 
 // ---------------------------------------------------------------------------------------
 // row products on DPP
@@ -160,7 +164,8 @@ __device__ __forceinline__ double v2_rls_cov(double* const img, const double z, 
 // LDS slots of a wave's region that the roll-out kernel touches itself: the gains of a covariance update done ahead, the
 // first move of the last solve
 template <int N_> __device__ __forceinline__ double* v2_cov_slot(double* sm) { return sm + v2_region1(N_) + 66; }
-template <int N_> __device__ __forceinline__ double* v2_first_move_slot(double* sm) { return sm + v2_region1(N_) + v2_carry_elems() + 15; }
+// (its element of lane `lane`: lanes 0-31 as they are, lanes 32 .. 32+L-1 behind them; the other lanes of the upper half share the last slot)
+template <int L_> __device__ __forceinline__ int v2_cov_index(int lane) { return lane < 32 ? lane : (lane - 32 < L_ ? lane : 32 + L_ - 1 + (L_ & 1)); }
 
 // sv.psi_now_v / psi_prev_v: lane with (lane & 31) = i < L carries psi_i (BOTH halves).  img: this trajectory's wave image.
 template <int L_, int N_, int Q_, bool LOWREG, bool ASREG>
@@ -176,7 +181,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   double* const sR = sm;                          // H / carried tableau
   double* const sCs = sR + v2_region1(N_);        // rs[32] | rsi[32] | {smask, valid} | gains of rls_cov [64]
   double* const sCov = sCs + 66;
-  double* const vec = sCs + v2_carry_elems();
+  double* const vec = sCs + v2_carry_elems(L_);
   double* const red = vec;
   constexpr int NE = (N_ + 1) & ~1;               // (even offsets: g and e are read as 16-byte vectors)
   double* const sf = red + 16;
@@ -230,7 +235,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     // z = [psi(x_{k-1}); u_{k-1}] in the lanes of both halves
     const double z = t < L_ ? sv.psi_prev_v : (t == L_ ? up : 0.0);
     KTRACE(1);
-    const double u2 = sv.cov_done ? sCov[tid] : v2_rls_cov<L_, false>(img, z, a.lam);
+    const double u2 = sv.cov_done ? sCov[v2_cov_index<L_>(tid)] : v2_rls_cov<L_, false>(img, z, a.lam);
     KTRACE(2);
     double zv0, zv1;
     half_gather(z, zv0, zv1);
@@ -289,14 +294,16 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     // delta-u form (Tank_System.m:110-113): x+ = A x + B s, s = 1 on the v chain and u_prev on the w chain
     const double bs = (a.du_mode && isA) ? R1[L_] * (half ? up : 1.0) : 0.0;
     const int ro = t - L_ - a.cy0;
-    double* const optr = (ro >= 0 && ro < q) ? (half ? sEr - q + ro : sG + ro) : dump + tid;
+    const bool isO = ro >= 0 && ro < q;
+    double* const optr = isO ? (half ? sEr - q + ro : sG + ro) : dump + tid;
     KTRACE(5);
 #pragma unroll
     for (int j = 0; j <= N_; ++j) {
       double ac4[4] = {bs, 0.0, 0.0, 0.0};
       rowdot1<L_, NC>(ac4, v0, v1, R1);
       const double acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
-      optr[j * q] = acc;
+      if constexpr (v2_chain_dump(N_)) optr[j * q] = acc;
+      else if (isO) optr[j * q] = acc;
       if (j < N_) half_gather(acc, v0, v1);
     }
     block_sync<64>();
@@ -421,16 +428,17 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     if (sv.cov_ahead) {
       // the covariance half of the NEXT step's update: its regressor [psi(x_k); u_k] is complete now
       const double uk = (a.du_mode ? up : 0.0) + red[15];  // (the solve leaves its first move there)
-      sCov[tid] = v2_rls_cov<L_, false>(img, t < L_ ? psin : (t == L_ ? uk : 0.0), a.lam);
+      const double gains = v2_rls_cov<L_, false>(img, t < L_ ? psin : (t == L_ ? uk : 0.0), a.lam);
+      if (!half || t < L_) sCov[v2_cov_index<L_>(tid)] = gains;
     }
   }
 }
 
 // once per launch, before the first step: no carried tableau, zeros behind e_N
-template <int N_, int Q_> __device__ __forceinline__ void step_v2_init(double* const sm) {
+template <int L_, int N_, int Q_> __device__ __forceinline__ void step_v2_init(double* const sm) {
   const int tid = local_tid<64>();
   double* const sCs = sm + v2_region1(N_);
-  double* const sEr = sCs + v2_carry_elems() + 16 + 2 * ((N_ + 1) & ~1) + Q_;
+  double* const sEr = sCs + v2_carry_elems(L_) + 16 + 2 * ((N_ + 1) & ~1) + Q_;
   if (tid == 0) {
     int* const ci = reinterpret_cast<int*>(sCs + 64);
     ci[0] = 0;
