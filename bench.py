@@ -60,7 +60,7 @@ CONFIGS = {
                      text="BASELINE cfg3 with L = 20 centres (SURVEY 8d asks for it beside L = 8): Van der Pol closed loop as "
                           "vanderpol_RBF.py, 20 thin-plate RBF observables, y = C x, box +-2, storage update, horizon N=30, RK4 plant on "
                           "device, parameter switch at step 102"),
-    "cfg4": dict(L=32, N=40, B=8192, plant="tank", lift="mlp", layers=2, shared=True, settle=160,
+    "cfg4": dict(L=32, N=40, B=8192, plant="tank", lift="mlp", layers=2, shared=True, settle=260,
                  text="BASELINE cfg4: cascaded tanks (Tank_System.m), 32-dim MLP lift (2-100-100-32, random init seed 9), N=40, "
                       "delta-u form with Cy = [0 1], ONE model for all trajectories of all ranks from the all-reduced EDMD Gram "
                       "block (the only collective), plant switch at step 100; 65536 / 8 trajectories per GPU"),

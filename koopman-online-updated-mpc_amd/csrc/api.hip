@@ -829,10 +829,15 @@ struct Impl : kmpc_handle {
               void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s) override {
     if (!X || !ref || steps < 0) FAIL(-3, "kmpc_rollout: bad arguments");
     if (!dU0) HIPCHK(hipMalloc(&dU0, sizeof(T) * (size_t)B));
-    if (st) HIPCHK(hipMemsetAsync(st, 0, sizeof(int32_t) * (size_t)B, s));
-    if (it) HIPCHK(hipMemsetAsync(it, 0, sizeof(int32_t) * (size_t)B, s));
     if (n != 2) FAIL(-3, "plants are two-state systems");
     if (!plant_id_ok(plant)) FAIL(-3, "unknown plant");
+    // (the fused roll-out with the MLP lift accumulates status / iterations in LDS and WRITES them when it ends: no zeroing
+    //  launches in front of it -- two of the ~70 us a 20-step call spends outside its kernel)
+    const bool kernel_writes_totals = steps > 0 && fused_rollout_ok() && cfg.lift_kind == KMPC_LIFT_MLP;
+    if (!kernel_writes_totals) {
+      if (st) HIPCHK(hipMemsetAsync(st, 0, sizeof(int32_t) * (size_t)B, s));
+      if (it) HIPCHK(hipMemsetAsync(it, 0, sizeof(int32_t) * (size_t)B, s));
+    }
     if (steps > 0 && fused_rollout_ok())
       return rollout_fused(plant, X, ref, rpt, steps, step0, switch_step, hs, Ulog, Xlog, st, it, s);
     for (int i = 0; i < steps; ++i) {
