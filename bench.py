@@ -23,10 +23,13 @@ measurement right after the reset is reported beside the headline as `post_reset
 
 Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: algorithmic bytes (SURVEY.md 8d
 formula, kmpc_algorithmic_bytes_per_step) x trajectories x steps per launch / its duration measured with
-HIP events on the launch stream in the timed pass itself.  `cpu_baseline` times the NumPy oracle run the
-way the reference runs (per-trajectory Python loop, SciPy L-BFGS-B on the shooting cost,
-duffing.py:857-859) on a bounded sample of the same workload: one worker process per host core of the
-box's CPU share (16), forked before the GPU is touched; the single-core figure is reported beside it.
+HIP events on the launch stream in the timed pass itself; `flop_frac` (SURVEY 8d flop formulas with the
+measured Newton-solve count / 78.6 TFLOP/s) beside `hbm_frac`, `bound` = the governing one of the two.
+The default run (cfg2, one GPU) appends `other_configs`: short legs of cfg3, cfg3-L20, cfg4, cfg5 with the
+same K / W.  `cpu_baseline` times the NumPy oracle run the way the reference runs (per-trajectory Python
+loop, SciPy L-BFGS-B on the shooting cost, duffing.py:857-859) on a bounded sample of the same workload IN
+THE SAME REGIME (the settle steps after the reset are set-up, the steps after them are timed): one worker
+process per host core of the box's CPU share (16), forked before the GPU is touched.
 """
 import argparse
 import json
