@@ -114,6 +114,10 @@ struct Impl : kmpc_handle {
   double* dImg = nullptr;
   long sImg = 0;
   bool use_img = false, img_valid = false, dense_valid = true;
+  // four-wave solver (threads = 256, float64): every trajectory's last tableau and its variable set, kept from step to step
+  // (StepArgs::qp_carry); any change of the model from outside forgets them (the next solve starts from 2H)
+  T* dQpCarry = nullptr;
+  int32_t* dQpCarrySet = nullptr;
   T* dWarm = nullptr;  // [N][B] last minimiser = start of the next solve (the reference restarts at zeros, duffing.py:634-635)
   int cur = 0;
   bool have_prev = false;  // a previous (psi, u) exists -> next step runs the RLS update
@@ -165,6 +169,11 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMemset(dPsi[1], 0, sizeof(T) * (size_t)L * B));
     HIPCHK(hipMemset(dUprev, 0, sizeof(T) * (size_t)B));
     HIPCHK(hipMemset(dWarm, 0, sizeof(T) * (size_t)N * B));
+    if (sizeof(T) == 8 && threads == 256 && !getenv("KMPC_QP_NO_CARRY")) {  // (the variable is a measurement aid)
+      HIPCHK(hipMalloc(&dQpCarry, sizeof(T) * (size_t)B * N * N));
+      HIPCHK(hipMalloc(&dQpCarrySet, sizeof(int32_t) * (size_t)B * 4));
+      HIPCHK(hipMemset(dQpCarrySet, 0, sizeof(int32_t) * (size_t)B * 4));
+    }
     if constexpr (sizeof(T) == 8) {
       use_img = threads == 64 && c.output_kind != KMPC_OUT_LIFT && rollout_uses_image(n, L, N, q) &&
                 rollout_fused_available<T>(n, L, N, q, threads, c.lift_kind != KMPC_LIFT_MLP);
@@ -211,7 +220,7 @@ struct Impl : kmpc_handle {
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
                       (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
-                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dImg})
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -236,6 +245,7 @@ struct Impl : kmpc_handle {
     if (will_modify) img_valid = false;
     return 0;
   }
+  // (called where the model or the state is replaced from outside: set_model, reset, offline fit, checkpoint import)
   int ensure_image(hipStream_t s) {
     if constexpr (sizeof(T) == 8) {
       if (!img_valid) {
@@ -244,6 +254,11 @@ struct Impl : kmpc_handle {
       }
       dense_valid = false;  // (the roll-out writes the image)
     }
+    return 0;
+  }
+
+  int forget_tableaux(hipStream_t s) {
+    if (dQpCarrySet) HIPCHK(hipMemsetAsync(dQpCarrySet, 0, sizeof(int32_t) * (size_t)B * 4, s));
     return 0;
   }
 
@@ -332,6 +347,7 @@ struct Impl : kmpc_handle {
       k[(size_t)r * p + L] = (T)Bm[r];
     }
     { int rc = ensure_dense(nullptr, true); if (rc) return rc; }
+    { int rc = forget_tableaux(nullptr); if (rc) return rc; }
     HIPCHK(hipMemcpy(dTmp, k.data(), k.size() * sizeof(T), hipMemcpyHostToDevice));
     HIPCHK(launch_broadcast<T>(dK, sK, dTmp, L * p, B, nullptr));
     if (cfg.output_kind == KMPC_OUT_CX) {
@@ -431,6 +447,7 @@ struct Impl : kmpc_handle {
     if (dGram) HIPCHK(hipMemsetAsync(dGram, 0, sizeof(double) * (size_t)gram_elems(), s));
     shared_has_samples = false;
     { int rc = ensure_dense(s, true); if (rc) return rc; }
+    { int rc = forget_tableaux(s); if (rc) return rc; }
     HIPCHK(launch_fill_state<T>(dP, sP, p, (T)cfg.P0, dQ, sQ, L, (T)cfg.barQ0, nullptr, sK, nullptr, sC, n, B, s));
     HIPCHK(hipMemsetAsync(dWarm, 0, sizeof(T) * (size_t)N * B, s));  // first solve starts at clip(0) like the reference's (duffing.py:634-635)
     have_prev = false;
@@ -706,6 +723,7 @@ struct Impl : kmpc_handle {
     a.ref = (const T*)ref; a.ref_per_traj = rpt;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
     a.x_warm = cfg.cold_start ? nullptr : dWarm;
+    a.qp_carry = dQpCarry; a.qp_carry_set = dQpCarrySet;
     a.accumulate = accumulate ? 1 : 0;
     if (fuse_plant >= 0) { a.plant = fuse_plant; a.plant_switched = fuse_switched; a.plant_h = (T)fuse_h; a.X_rw = (T*)const_cast<void*>(X); }
     HIPCHK(launch_step<T>(a, threads, s));
@@ -980,6 +998,7 @@ struct Impl : kmpc_handle {
     int rc = shared_alloc();
     if (rc) return rc;
     if ((rc = ensure_dense(s, true))) return rc;
+    if ((rc = forget_tableaux(s))) return rc;
     DevTmp tpx, tpy, tpinv, tg;
     if (init_rls) HIPCHK(hipMalloc(&tpinv.p, sizeof(T) * (size_t)(p * p + L * L)));
     HIPCHK(hipMalloc(&tpx.p, sizeof(T) * (size_t)L * M));
@@ -1045,6 +1064,7 @@ struct Impl : kmpc_handle {
   int state_export(void* blob, int64_t bytes) override {
     if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_export: buffer too small");
     { int rc = ensure_dense(nullptr, false); if (rc) return rc; }
+    { int rc = forget_tableaux(nullptr); if (rc) return rc; }  // (a checkpoint is a synchronisation point: exporter and importer continue alike)
     HIPCHK(hipDeviceSynchronize());
     BlobHeader hd{};
     hd.magic = 0x4b4d5043; hd.version = 2; hd.dtype = cfg.dtype; hd.n = n; hd.L = L; hd.N = N; hd.B = B;
@@ -1092,6 +1112,7 @@ struct Impl : kmpc_handle {
     if (bytes < (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * base_elems() + sb + wb) FAIL(-3, "kmpc_state_import: buffer too small");
     HIPCHK(hipDeviceSynchronize());
     dense_valid = true; img_valid = false;  // (the blob overwrites every dense block)
+    { int rc = forget_tableaux(nullptr); if (rc) return rc; }
     if (hd.has_shared) { int rc = shared_alloc(); if (rc) return rc; }
     if (hd.have_wterm) {
       if (hd.wterm_from_dare) {

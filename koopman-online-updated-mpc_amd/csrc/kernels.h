@@ -55,6 +55,10 @@ struct StepArgs {
   T* qp_scratch;   // [B][N*N] global scratch: tableau of the register solvers' fall-back (never touched otherwise)
   T* x_warm;       // [N][B] previous minimiser = start of the next solve, or null: start at clip(0) as the reference
                    // does (its pastRes_loc stays zeros, duffing.py:634-635, 859); same minimiser, less work
+  // four-wave solver (cfg5 sizes): the swept tableau of a trajectory's last solve, kept from step to step in global memory and used
+  // as an approximate inverse that is refined against H (see qp_regs256); null: every solve builds its tableau from 2H
+  T* qp_carry;             // [B][N*N]
+  int32_t* qp_carry_set;   // [B][4]: variable set of that tableau (low, high word), valid flag, unused
   int qp_predict;  // 1: active-set prediction rounds inside a Newton iteration of the box QP (step_body.h), 0: plain projected Newton
   const T* Wterm;  // q x q, PN - Qw I: terminal block of Q_bar (Koopman_update.m:381), or null
   int wterm_per_traj;  // Wterm is [B][q*q]: every trajectory its own block (kmpc_terminal_from_dare)

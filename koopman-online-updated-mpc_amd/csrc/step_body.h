@@ -876,6 +876,27 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       if constexpr (HREG) Hm[r][c] = h;
       Tm[r][c] = T(2) * h;
     }
+  // Round 3: the tableau of the trajectory's last solve (global memory, a.qp_carry) instead of 2H.  The model moves by a rank-one
+  // update per step and the free set rarely changes, so it is an approximate inverse of the new 2 H_FF: the Newton direction
+  // below is refined against H itself (two products per pass, each pass gains a factor |I - T 2H|) instead of paying the N
+  // sweeps -- N barrier rounds -- that build a fresh tableau.  The answer does not depend on it: the KKT test uses H.
+  bool carried = false;
+  unsigned long long Smask0 = 0ull;
+  if (a.qp_carry) {
+    const int32_t* const cs = a.qp_carry_set + 4 * (size_t)b;
+    if (__builtin_amdgcn_readfirstlane(cs[2]) != 0) {
+      const T* const Tg = a.qp_carry + (size_t)b * N_ * N_;
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RM; ++c) {
+          const int i = ti + 16 * r, j = tj + 16 * c;
+          Tm[r][c] = (i < N_ && j < N_) ? Tg[i * N_ + j] : T(0);
+        }
+      Smask0 = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(cs[0]) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(cs[1]) << 32);
+      carried = true;
+    }
+  }
   const T fi = own ? sf[myvar] : T(0);
   if (tid < 64) qv[tid] = T(0);  // (entries beyond N stay zero)
   // y_i = sum_j M_ij v_j for the owner of variable i (v given by the owners)
@@ -913,8 +934,9 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   T x = own ? (a.x_warm ? tclip(a.x_warm[(size_t)myvar * a.B + b], lb, ub) : c0) : T(0);
   T hx = matvec(Hel, x);
   T J0 = block_sum<T, 256>(own ? x * (hx + fi) : T(0), red);
-  unsigned long long Smask = 0ull;
-  int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0, rtot = 0;
+  unsigned long long Smask = Smask0;
+  int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0, rtot = 0, nref = 0;
+  bool rebuild = false;
   bool nopredict = false;
   KTRACE(8);
 
@@ -950,6 +972,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     }
     if (it >= a.max_iter || refresh > 4) { status = 1; break; }
     if (it >= N_ + 10) { status = 3; break; }  // crawling: the active-set loop of qp_lds finishes from here
+    if (carried && it >= 4 && Bmask != 0ull) rebuild = true;  // (a carried tableau that has not converged in four iterations)
     unsigned long long Fmask = ~Imask & allmask;
     if (it == 0) KTRACE(9);
 
@@ -961,6 +984,16 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     while (true) {
       broke = false;
       for (int pass = 0; pass < 2; ++pass) {
+        // from 2H again: asked for above, or more variables change sides than F has members
+        if (rebuild || (carried && __builtin_popcountll(Smask ^ Fmask) > __builtin_popcountll(Fmask) + 2)) {
+#pragma unroll
+          for (int r = 0; r < RM; ++r)
+#pragma unroll
+            for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
+          Smask = 0ull;
+          carried = false;
+          rebuild = false;
+        }
         unsigned long long diff = Smask ^ Fmask;
         while (diff) {
           const int k = __ffsll((long long)diff) - 1;
@@ -992,19 +1025,35 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
           Smask ^= (1ull << k);
         }
         if (!broke || pass == 1) break;
-        ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
+        if (!carried) ++refresh;  // rebuild T = 2H and sweep the free set in from scratch
 #pragma unroll
         for (int r = 0; r < RM; ++r)
 #pragma unroll
           for (int c = 0; c < RM; ++c) Tm[r][c] = T(2) * Hel(r, c);
         Smask = 0ull;
+        carried = false;
       }
       Fmask = Smask;
       if (it == 0 && rounds == 0) KTRACE(10);
 
-      // Newton direction on F
+      // Newton direction on F; with a carried tableau refined against H: p <- p + T (g + 2 H p)_F
       isF = own && ((Fmask >> myvar) & 1ull);
       pdir = matvec(Tel, isF ? g : T(0));
+      if (carried) {
+        bool stale = false;
+        for (int kr = 0;; ++kr) {
+          const T hp = matvec(Hel, isF ? pdir : T(0));
+          const T rr = isF ? g + T(2) * hp : T(0);
+          if (!__syncthreads_or(!(tabs(rr) <= (T)1e-13 * gs) && isF)) break;
+          if (kr >= 6) { stale = true; break; }
+          pdir += matvec(Tel, rr);
+          ++nref;
+        }
+        if (stale) {  // the carried tableau does not contract: this direction again from 2H
+          rebuild = true;
+          continue;
+        }
+      }
       if (!predict || broke || rounds >= N_) break;
       // the free variable whose Newton value lies furthest outside the box is fixed at that bound
       const T cand = x + pdir;
@@ -1056,9 +1105,11 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       Ja = pJa;
       const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
       if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
+      if (carried) { redo = true; break; }  // a stale tableau gave a poor direction: this iteration again with a fresh one
       alpha *= T(0.25);
     }
     if (redo) {
+      if (carried && rounds == 0) { rebuild = true; continue; }
       nopredict = true;
       continue;
     }
@@ -1075,12 +1126,32 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   if (status == 3) {
     __syncthreads();
     if (own) qx_out[myvar] = x;
+    if (a.qp_carry && tid == 0) a.qp_carry_set[4 * (size_t)b + 2] = 0;
     return true;
   }
   const int B = a.B;
   if (own) {
     if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
     if (a.x_warm) a.x_warm[(size_t)myvar * B + b] = x;
+  }
+  if (a.qp_carry) {  // the tableau stays for the next solve (a carried one that needed many iterations does not: 2H next time)
+    const bool keep = status == 0 && !(carried && (it >= 4 || nref >= 5));
+    if (keep) {
+      T* const Tg = a.qp_carry + (size_t)b * N_ * N_;
+#pragma unroll
+      for (int r = 0; r < RM; ++r)
+#pragma unroll
+        for (int c = 0; c < RM; ++c) {
+          const int i = ti + 16 * r, j = tj + 16 * c;
+          if (i < N_ && j < N_) Tg[i * N_ + j] = Tm[r][c];
+        }
+    }
+    if (tid == 0) {
+      int32_t* const cs = a.qp_carry_set + 4 * (size_t)b;
+      cs[0] = (int32_t)(unsigned)(Smask & 0xffffffffull);
+      cs[1] = (int32_t)(unsigned)(Smask >> 32);
+      cs[2] = keep ? 1 : 0;
+    }
   }
   if (tid == 0) {  // thread 0 owns variable 0
     const T uout = a.du_mode ? uprev + x : x;
