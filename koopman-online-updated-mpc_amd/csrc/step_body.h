@@ -1921,6 +1921,52 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         block_sync<TPB>();
         cur ^= 1;
       }
+    } else if constexpr (ONE_REGION && sizeof(T) == 8 && L_ == 64) {
+      // Round 3 -- four-wave trajectories, y = C x (cfg5: L = 64), float64: threads 0-127 run the v-chain, 128-255 the w-chain; a
+      // 16-lane DPP row holds HALF rows of A for 16 consecutive rows (rows 16 m .. 16 m + 15, columns 32 hh .. 32 hh + 31 with
+      // hh = the row's parity within its wave), 32 registers a lane.  A step multiplies with v_fmac_f64_dpp ... row_newbcast: the
+      // 32 vector elements a row needs are two registers of its lanes (element 32 hh + l and 32 hh + 16 + l in lane l: two 8-byte LDS
+      // reads per lane and step).  The version below read them as 16 broadcast ds_read_b128 per lane and step -- 64 KB of LDS
+      // traffic per trajectory and step, which is what the recursion's 0.58 us per step was: with four trajectories on a CU the
+      // LDS pipe, not the multiply-adds, set its pace.  The two halves of a row meet through one v_permlane16_swap per dword.
+      const int chain = tid >> 7, g16 = (tid & 127) >> 4, l16 = tid & 15;
+      const int hh = g16 & 1, rr = (g16 >> 1) * 16 + l16;
+      const int ln = tid & 63, corow = (tid >> 6) & 1;
+      double row[32];
+#pragma unroll
+      for (int l = 0; l < 32; ++l) row[l] = sK[rr * p + hh * 32 + l];
+      const double co = (ln < L && corow < q) ? sC[(a.cy0 + corow) * L + ln] : 0.0;
+      const double bs = a.du_mode ? sK[rr * p + L] * (chain ? up : 1.0) : 0.0;
+      block_sync<TPB>();  // (C may sit where g is written from now on)
+      int cur = 0;
+      for (int j0 = 0; j0 <= N; j0 += 4) {  // (the outputs of four steps are reduced together: wave_sum4)
+        double pc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u;
+          if (j <= N) {
+            double* const vb = (chain ? sW : sV) + cur * L;
+            const double x0 = vb[hh * 32 + l16], x1 = vb[hh * 32 + 16 + l16];
+            pc[u] = co * vb[ln < L ? ln : 0];
+            double ac4[4] = {0.0, 0.0, 0.0, 0.0};
+            chain_dot<32>(ac4, x0, x1, row);
+            const double part = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
+            double pa, pb;
+            half_gather(part, pa, pb);  // the two 16-lane rows of a pair: this row's other half sits in the neighbouring one
+            const double acc = (pa + pb) + bs;
+            if (hh == 0 && j < N) (chain ? sW : sV)[(cur ^ 1) * L + rr] = acc;  // v_{j+1} / w_{j+1}
+            block_sync<TPB>();
+            cur ^= 1;
+          }
+        }
+        const double g4 = wave_sum4(pc[0], pc[1], pc[2], pc[3], ln);
+        const int j = j0 + ln;  // lane u < 4 of the wave holds the output of step j0 + u
+        if (ln < 4 && corow < q && j <= N) {
+          if (chain == 0) { if (j < N) sG[j * q + corow] = g4; }       // g_j = Co v_j
+          else if (j >= 1) sEr[(j - 1) * q + corow] += g4;             // e_j = Co w_j - r_{j-1}
+        }
+      }
+      block_sync<TPB>();  // (the last outputs)
     } else if constexpr (ONE_REGION) {
       // Four-wave trajectories, y = C x (cfg5 sizes, L = 64): threads 0-127 run the v-chain, 128-255 the w-chain; a PAIR of
       // threads keeps one row of A in registers for the whole recursion, half a row each (32 of the 64 columns: every
