@@ -374,6 +374,13 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
     launches = max(1, pr["count"] // steps_per_launch)
     launch_ms = pr["step_ms"] / launches
     lift_ms = pr["lift_ms"] / launches
+    qp_launch_ms = None
+    if main_loop.shared:
+        # the shared-model step is six dependent launches and the box QPs are no longer the longest of them (the interior
+        # trajectories are finished on the matrix cores, the one-workgroup model solve is half of the step): the roofline is
+        # taken over the WHOLE step -- wall time of the timed region, launch gaps included
+        qp_launch_ms = launch_ms
+        launch_ms = dt / max(1, args.steps) * 1e3
     bytes_per_traj = mpc.algorithmic_bytes_per_step()
     if main_loop.shared:  # the shared-model mode drops the per-trajectory state term 2 (p^2 + L p + L^2 + n L)
         sz, p_, q_ = (8 if args.dtype == "f64" else 4), L + 1, mpc.q
@@ -422,7 +429,10 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
                 tj["bytes_per_trajectory_step"], tj["B"], tj["source"])
 
     if main_loop.shared:
-        kname = "step_qp_kernel (box QPs of the shared model, %d blocks x 64 threads); lift, Gram (MFMA), model solve and condense are separate launches" % B
+        kname = ("whole shared-model step = six dependent launches: lift_coop_kernel (MFMA), gram_kernel (MFMA), gram_reduce_kernel, shared_model_kernel "
+                 "(ONE workgroup: two Gram inverses, model, condense, T0 -- serial, about half of the step), shared_fast_kernel (interior trajectories, "
+                 "16 per wave on MFMA), step_qp_kernel (only the trajectories whose box binds; %d blocks x 64 threads that exit at once otherwise); "
+                 "per-kernel times: profiles/r3_cfg4_summary.txt" % B)
     elif fused:
         kname = "rollout_kernel (lift + RLS + condense + QP + plant, all %d steps in one launch), %d workgroups" % (steps_per_launch, (B + 15) // 16)
     else:
@@ -452,8 +462,11 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
         "steps_per_launch": steps_per_launch,
         "avg_kernel_ms": launch_ms,
         "avg_lift_kernel_ms": lift_ms,
-        "kernel_time_source": "HIP events around the launches of the timed pass itself",
+        "kernel_time_source": ("wall time of the timed region / steps (all launches of a step and the gaps between them)" if main_loop.shared
+                               else "HIP events around the launches of the timed pass itself"),
     }
+    if qp_launch_ms is not None:
+        roof["qp_launches_ms"] = qp_launch_ms  # shared_fast_kernel + step_qp_kernel between HIP events
     return {"dt": dt, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "roofline": roof, "extras": ex,
             "worst_status": worst_status, "x_ok": x_ok, "newton_per_step": newton_per_step, "newton_max": newton_max,
             "shared": main_loop.shared, "q": mpc.q, "text": c["text"]}

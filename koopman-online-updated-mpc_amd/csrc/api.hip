@@ -220,7 +220,7 @@ struct Impl : kmpc_handle {
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
                       (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
-                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet})
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -878,6 +878,7 @@ struct Impl : kmpc_handle {
   // ---- shared-model mode -----------------------------------------------------------------------------
   double *dGram = nullptr, *dPartial = nullptr;
   T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr, *dTs = nullptr;
+  int32_t* dNeed = nullptr;  // [B] flags of shared_fast_kernel
   T* dWt = nullptr;  // PN - Qw I (terminal block of Q_bar)
   std::vector<double> hostPN;  // P_N as given to kmpc_set_terminal_weight
   bool have_wterm = false;
@@ -981,6 +982,14 @@ struct Impl : kmpc_handle {
       }
       HIPCHK(hipEventRecord(ev[ev_used], s));
       HIPCHK(hipEventRecord(ev[ev_used + 1], s));
+    }
+    // the trajectories whose unconstrained minimiser lies inside the box are finished 16 per wave on the matrix cores
+    // (shared_fast_kernel); the solve-only kernel then only runs for the flagged rest
+    const bool no_fast = getenv("KMPC_SHARED_NO_FAST") != nullptr;  // measurement / test aid (read per call): every trajectory through the QP kernel
+    if (one_launch && sizeof(T) == 8 && N <= 64 && !no_fast) {
+      if (!dNeed) HIPCHK(hipMalloc(&dNeed, sizeof(int32_t) * (size_t)B));
+      HIPCHK(launch_shared_fast<T>(a, dNeed, s));
+      a.qp_need = dNeed;
     }
     HIPCHK(launch_step<T>(a, threads, s));
     if (rec) {

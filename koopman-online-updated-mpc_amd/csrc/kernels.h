@@ -47,6 +47,8 @@ struct StepArgs {
   int h_shared;                  // H_in is ONE matrix for the whole batch (shared-model mode)
   const T* T_in;                 // shared-model mode: -(2 H_in)^-1 (N x N), the swept tableau of the free set "all inputs"; or null
   const T* F_in; const T* f0_in; // shared-model mode: f_b = F psi_b + f0 (F: N x L), psi from psi_now
+  const int32_t* qp_need;        // shared-model mode: [B] flags written by shared_fast_kernel -- 0: that kernel has already written this
+                                 // trajectory's result (its unconstrained minimiser lies inside the box), the solve-only kernel skips it
   // QP
   T* Useq;           // (N x B) or null
   T* U0;             // [B] or null
@@ -181,6 +183,10 @@ template <typename T>
 hipError_t launch_shared_model(double* gram, const double* delta, double forget, const T* ref, int Lm, int n, int q, int N, double dP, double dQ, int use_C,
                                int have_samples, double Qw, double Rw, T* Kio, T* Cio, T* Hout, T* Fout, T* f0out, T* Tout,
                                const T* Wt, int du_mode, int cy0, hipStream_t s);
+// the interior trajectories of a shared-model step, 16 per wave on the matrix cores (u = T0 (F psi + f0), certified against H);
+// need[b] = 1 where the box binds or the certificate fails: those are left to the solve-only kernel (a.qp_need)
+template <typename T>
+hipError_t launch_shared_fast(const StepArgs<T>& a, int32_t* need, hipStream_t s);
 bool shared_model_available(int Lm, int n, int q, int N, int du_mode);
 template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s);
 // [A B] and C given as dense per-trajectory blocks (A [B][L][L], Bv [B][L], C [B][n][L]; stride 0 = one model for all)

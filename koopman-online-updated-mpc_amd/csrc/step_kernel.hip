@@ -32,6 +32,7 @@ template <typename T, int TPB, int L_, int N_, int Q_>
 //  from LDS in the solve: 128 registers, 38.5 KB)
 __global__ __launch_bounds__(TPB, (TPB == 256 ? (step_one_region<TPB, L_, N_, Q_>() ? 4 : 2) : 1)) void step_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (a.qp_need && a.phases == PH_QP && a.qp_need[blockIdx.x] == 0) return;  // (finished by shared_fast_kernel)
   const StepVar<T> sv{a.phases, a.first_update, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0)};
   step_body<T, TPB, L_, N_, Q_>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
@@ -44,6 +45,7 @@ __global__ __launch_bounds__(TPB, (TPB == 256 ? (step_one_region<TPB, L_, N_, Q_
 template <typename T, int TPB, int L_, int N_, int Q_, bool HG>
 __global__ __launch_bounds__(TPB, (HG ? KMPC_QP_HG_WAVES : 3)) void step_qp_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  if (a.qp_need && a.qp_need[blockIdx.x] == 0) return;  // (finished by shared_fast_kernel)
   const StepVar<T> sv{PH_QP, 0, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0), HG};
   step_body<T, TPB, L_, N_, Q_, true>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }

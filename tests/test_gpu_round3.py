@@ -304,6 +304,62 @@ def _bench_child(extra, timeout=900):
     return json.loads(lines[0])
 
 
+@pytest.mark.parametrize("B", [37, 256])
+def test_shared_step_interior_kernel_equals_the_per_trajectory_solve(torch_mod, KM, monkeypatch, B):
+    """The shared-model step finishes the trajectories whose unconstrained minimiser lies inside the box 16 per wave on the
+    matrix cores (shared_fast_kernel) and leaves the rest to the per-trajectory solve.  The same closed loop with that kernel
+    switched off (KMPC_SHARED_NO_FAST, read per call): same inputs, sequences, states and statuses; the loop starts with
+    saturated inputs (both kernels at work in one step) and settles into the interior (cfg4 sizes, delta-u tank form)."""
+    from koopmpc.synth import random_mlp_weights
+
+    L, N = 32, 40
+    w = random_mlp_weights(2, 100, 2, L, seed=9)
+    rng = np.random.RandomState(5)
+    Ub = 10 * rng.rand(60, 100) - 5
+    xc = np.maximum(4 * rng.rand(2, 100) - 2, 0.0)
+    Xs, Ys, Us = [], [], []
+    for i in range(60):
+        xn = ko.tank_step(xc, Ub[i])
+        Xs.append(xc); Ys.append(xn); Us.append(Ub[i][None, :]); xc = xn
+    Xd, Yd, Ud = np.concatenate(Xs, 1), np.concatenate(Ys, 1), np.concatenate(Us, 1)
+    lift_fn = lambda x: ko.mlp_lift(w, x)
+    V = np.concatenate([lift_fn(Xd), Ud], 0)
+    M = np.concatenate([lift_fn(Yd), Xd], 0) @ V.T @ np.linalg.pinv(V @ V.T)
+    X0 = np.abs(rng.rand(2, B)) * np.linspace(0.05, 2.0, B)[None, :]
+    r = np.ones((1, N))
+
+    def make():
+        mpc = KM(n=2, L=L, N=N, batch=B, weights=w, layers=2, lb=-0.5, ub=0.5, umin=-8.0, umax=8.0, Qw=10.0, Rw=1e-3, P0=1e4,
+                 barQ0=1e4, delta_u=True, out_row0=1, out_rows=1)
+        mpc.set_model(M[:L, :L], M[:L, L:], M[L:, :L])
+        return mpc
+
+    # two handles in lockstep on the SAME state and input history (the second one is told the first one's inputs), so that
+    # every step compares the two kernels on one problem instead of two closed loops that drift apart by rounding
+    fast, slow = make(), make()
+    X = X0.copy()
+    worst, interior, bound = 0.0, 0, 0
+    for k in range(40):
+        monkeypatch.delenv("KMPC_SHARED_NO_FAST", raising=False)
+        ua = fast.shared_step(X, r).cpu().numpy()
+        monkeypatch.setenv("KMPC_SHARED_NO_FAST", "1")
+        ub_ = slow.shared_step(X, r).cpu().numpy()
+        slow.set_applied_input(ua)
+        Ua, Ub_ = fast.Useq.cpu().numpy(), slow.Useq.cpu().numpy()
+        sa, sb = fast.status.cpu().numpy(), slow.status.cpu().numpy()
+        assert (sa == sb).all(), k
+        ok = sa == 0
+        worst = max(worst, np.abs(ua - ub_)[ok].max(), np.abs(Ua - Ub_)[:, ok].max())
+        at_bound = (np.abs(Ub_) >= 0.5 - 1e-9).any(axis=0)
+        interior += int((~at_bound).sum()); bound += int(at_bound.sum())
+        X = ko.tank_step(X, ua)
+    monkeypatch.delenv("KMPC_SHARED_NO_FAST", raising=False)
+    print("interior kernel: %d interior / %d bound solves, worst difference %.2e" % (interior, bound, worst))
+    assert interior > 0 and bound > 0
+    # (both points pass the same gradient certificate, 1e-12 of the gradient scale; H of this form has a condition number near
+    #  1e8 -- Rw = 1e-3 against Qw = 10 -- so the points themselves agree to about 1e-8, as two solver paths of one kernel do)
+    assert worst < 1e-7
+
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
 def test_bench_two_ranks_as_a_child_process(torch_mod, cfg):
     """`python bench.py --gpus 2 --backend gloo --same-device` as the driver would start it for N > 1, minus the second GPU:

@@ -35,7 +35,7 @@ for which in ("fetch", "write", "sq", "mfma"):
             d.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
         print("== %s pass: mean counter value per launch (number of launches)" % which)
         for k, d in per.items():
-            if not any(x in k for x in ("rollout", "step_kernel", "step_qp_kernel", "lift", "gram_kernel", "shared_model")):
+            if not any(x in k for x in ("rollout", "step_kernel", "step_qp_kernel", "lift", "gram_kernel", "gram_reduce", "shared_model", "shared_fast")):
                 continue
             print("  %s" % k[:90])
             for c, v in d.items():

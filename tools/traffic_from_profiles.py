@@ -12,7 +12,8 @@ def bench_line(name):
     return json.loads([l for l in open(os.path.join(d, "bench_%s.json" % name)) if l.startswith("{")][-1])
 bf, bw = bench_line("fetch"), bench_line("write")
 fused = "rollout_kernel" in bf["roofline"]["kernel"]
-dom = "rollout_kernel" if fused else ("step_qp_kernel" if "step_qp_kernel" in bf["roofline"]["kernel"] else "step_kernel")
+whole = bf["roofline"]["kernel"].startswith("whole shared-model step")  # cfg4: every launch of the step counts
+dom = "rollout_kernel" if fused else ("" if whole else ("step_qp_kernel" if "step_qp_kernel" in bf["roofline"]["kernel"] else "step_kernel"))
 vals, cur, sec = {}, None, None
 for l in open(os.path.join(d, "summary.txt")):
     if l.startswith("== "):
@@ -21,7 +22,7 @@ for l in open(os.path.join(d, "summary.txt")):
         cur = l.strip()
     elif l.startswith("      ") and cur and cur.startswith(dom):
         p = l.split()
-        vals[(sec, p[0])] = float(p[1])
+        vals[(sec, p[0])] = vals.get((sec, p[0]), 0.0) + float(p[1])  # (summed over the step's kernels when `whole`)
 B = int(re.search(r"(\d+) trajectories per GPU x", bf["config"]["workload"]).group(1))
 L, N = [int(x) for x in re.search(r"N=(\d+), (\d+)-dim", bf["metric"]).groups()][::-1]
 units = B * bf["roofline"]["steps_per_launch"]
@@ -31,9 +32,10 @@ wide = fused and (L + 2 <= 32) and "y = C x" in bf["config"]["workload"] or (fus
 cal = 2.0 if wide else 1.593
 entry = {"L": L, "N": N, "B": B, "bytes_per_trajectory_step": fetch_raw * cal + write,
          "fetch_bytes_per_trajectory_step_raw": fetch_raw, "write_bytes_per_trajectory_step": write, "fetch_calibration": cal,
-         "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x %s (%s) + WRITE, dominant kernel %s, "
+         "source": "profiles/%s: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x %s (%s) + WRITE, %s, "
                    "last third of its launches" % (summary_name, cal, "16-byte-per-lane coalesced reads: gfx950 reports half the bytes, MI355X_MICROARCH.md" if wide
-                                                   else "own-pattern calibration of round 1: 8-byte-per-lane coalesced reads report 0.628 of the bytes", dom)}
+                                                   else "own-pattern calibration of round 1: 8-byte-per-lane coalesced reads report 0.628 of the bytes",
+                                                   "summed over all kernels of the step" if whole else "dominant kernel " + dom)}
 tp = os.path.join(ROOT, "profiles", "traffic.json")
 tj = json.load(open(tp))
 key = "%s:f64:%s" % (cfg, "fused" if fused else "steps")
