@@ -209,7 +209,12 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     ra = hi;
   }
   const double gs = tabs(fi) + 2.0 * ra * xmaxb;
-  double x = own ? (warm ? tclip(xw_pre, lb, ub) : c0) : 0.0;
+  // A solve without a primal warm start (the reference's pastRes = zeros, duffing.py:634-635) starts at clip(0) -- moved onto the
+  // face the last minimiser lay on when a tableau is carried: the inputs the last solve held at a bound start at the bound the
+  // linear term pushes them to (the gradient at zero is f).  The carried tableau is that face's, so the first Newton point costs no
+  // sweeps; a wrong guess is an input at a bound with an inward gradient, which the first KKT test frees again.
+  const bool held = carried && !warm && !((Smask >> t) & 1u);
+  double x = own ? (warm ? tclip(xw_pre, lb, ub) : (held ? (fi > 0.0 ? lb : ub) : c0)) : 0.0;
   double hx;
   {
     double lo, hi;
@@ -307,7 +312,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
           if (kr >= 6 || !carried) { stale = carried; break; }  // (a fresh tableau is not refined: rounding in T costs an iteration, as before)
           halves_both_q(rs * rl_matvec<N_>(M, r), lo, hi);
           pdir += lo;
-          ++nref;
+          nref = kr + 1 > nref ? kr + 1 : nref;  // (the most passes one direction of this solve needed)
         }
         if (stale) {  // the carried tableau does not contract: this direction again from 2H
           rebuild = true;
@@ -419,7 +424,8 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     }
   }
   // the tableau takes H's place in LDS until the next solve.  A solve that worked with the carried tableau and needed many
-  // iterations leaves nothing: the next one starts from 2H.
+  // iterations, or five refinement passes for one direction (the contraction |I - T 2H| has worn: a solve from clip(0) refines a
+  // gradient of full size and takes three or four), leaves nothing: the next one starts from 2H.
   const bool keep = status == 0 && !(carried && (it >= 4 || nref >= 5));
   if (keep && own && !half) {
     double* const trow = sR + t * NS;

@@ -107,8 +107,9 @@ def test_rbf_lift(torch_mod, KM):
 
 
 # ------------------------------------------------------------------ RLS
-@pytest.mark.parametrize("gfile,P0,Q0", [("duffing_loop.npz", 1e4, 100.0), ("vanderpol_loop.npz", 1e5, 1e5)])
-def test_rls_replay_of_reference_loop(torch_mod, KM, gfile, P0, Q0):
+@pytest.mark.parametrize("gfile,P0,Q0,boundK,boundC", [("duffing_loop.npz", 1e4, 100.0, 1e-7, 1.1e-10),
+                                                        ("vanderpol_loop.npz", 1e5, 1e5, 8.5e-5, 1.5e-5)])
+def test_rls_replay_of_reference_loop(torch_mod, KM, gfile, P0, Q0, boundK, boundC):
     g = _load(gfile)
     B = 3
     mpc = KM(n=2, L=8, N=10, batch=B, weights=ko.load_mlp_weights(_load("weights_duffing.npz")), P0=P0, barQ0=Q0)
@@ -131,8 +132,9 @@ def test_rls_replay_of_reference_loop(torch_mod, KM, gfile, P0, Q0):
             floorC = max(floorC, np.abs(C_[b] - g["loop_C_prev"][k]).max() / max(1e-3, np.abs(Cg).max()))
         assert np.array_equal(A_[0], A_[1]) and np.array_equal(A_[0], A_[2])  # batch-invariant, bitwise
     print("%s: HIP (gain form) vs the reference's logged K_ext %.1e, C %.1e (relative)" % (gfile, floorK, floorC))
-    # the reference's K_A*inv_K_G evaluation is itself only reproducible to ~1e-9*inv_K_G0 .. 1e-8*inv_K_G0
-    assert floorK <= 1e-8 * P0 and floorC <= 1e-8 * max(P0, Q0)
+    # the reference's K_A*inv_K_G evaluation is itself only reproducible to ~1e-9*inv_K_G0 .. 1e-8*inv_K_G0: the bounds are twice
+    # what this (bitwise reproducible) path measures against the logs -- 5.0e-8 / 5.1e-11 (duffing), 4.1e-5 / 7.1e-6 (vanderpol)
+    assert floorK <= boundK and floorC <= boundC
 
 
 @pytest.mark.parametrize("L,B,threads", [(20, 130, 64), (32, 33, 64), (64, 9, 256), (20, 5, 256)])
