@@ -49,4 +49,6 @@ for name in ("trace", "fetch", "write", "sq", "mfma"):
     except Exception as e:
         print("== bench line under the %s pass: not available (%s)" % (name, e))
 PY
+# the raw traces are large (gpurun merges at most 64 MiB back): keep the summaries unless KEEP_RAW is set
+if [ -z "$KEEP_RAW" ]; then rm -rf "$out/trace" "$out/fetch" "$out/write" "$out/sq" "$out/mfma"; fi
 cat "$out/summary.txt"
