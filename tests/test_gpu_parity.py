@@ -625,7 +625,7 @@ def test_gram_kernel_mfma(torch_mod, KM, L, B):
     assert np.abs(d1 - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
 
 
-@pytest.mark.parametrize("L,N,B,layers", [(20, 20, 37, 3), (32, 40, 12, 2), (8, 10, 1, 3)])
+@pytest.mark.parametrize("L,N,B,layers", [(20, 20, 37, 3), (32, 40, 12, 2), (8, 10, 1, 3), (48, 50, 9, 2)])  # (48, 50: the widest interior-kernel tiling)
 def test_shared_model_closed_loop_vs_oracle(torch_mod, KM, L, N, B, layers):
     """Shared-model step (Gram -> model -> shared condense -> per-trajectory QP) vs the NumPy oracle
     (SharedEdmd + condense + qp_exact) in closed loop; the model to 1e-7, the controls to 1e-6."""
