@@ -393,10 +393,19 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
 
     # ---- beside the headline: every solve started at clip(0) as the reference does; the same window right after the reset
     ex = {}
+
+    def respin():
+        # (setting up a leg's controller -- allocations, uploads, the offline fit -- leaves the GPU idle long enough to fall back to
+        #  its idle clocks, and a leg of a few milliseconds does not bring them up again: round 3 measured the cold-start leg 25 %
+        #  slower than the same launches in a warm process.  Same remedy as for the headline: the scratch controller replays the region.)
+        if spin_seconds > 0:
+            spin(scratch, min(spin_seconds, 0.4), args.steps, step0, snap)
+
     if extras and scratch is not None:
         if can_snap and not args.cold_start:
             cold = Loop(name, w, B, dtype, dev, rank, cold=True, threads=args.threads)
             cold.m.state_from(snap[0]); cold.X.copy_(snap[1])
+            respin()
             dtc = timed(cold, args.steps, step0)
             ex["cold_start"] = {"value": B * world * args.steps / dtc, "ms_per_step": dtc / args.steps * 1e3,
                                 "frac": bytes_per_traj * B * args.steps / dtc / 1e9 / HBM_PEAK_GBS,
@@ -406,6 +415,7 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
             del cold
         fresh = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
         fresh.advance(args.warmup, 0)
+        respin()
         dtp = timed(fresh, args.steps, args.warmup)
         ex["post_reset"] = {"value": B * world * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3,
                             "mean_newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if not fresh.shared else 1),

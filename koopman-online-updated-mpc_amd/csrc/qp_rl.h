@@ -150,6 +150,7 @@ constexpr int rl_stride(int N) { return ((((N + 1) & ~1) / 2) & 1) ? ((N + 1) & 
 struct QpCarry {  // what a solve leaves for the next one (registers of the step loop; the rows themselves wait in LDS)
   unsigned smask;   // variables swept into the carried tableau
   int valid;        // 0: no tableau (rebuild), 1: carried
+  unsigned umask;   // of the others (held at a bound by that solve): those at the UPPER bound
 };
 
 // M: on entry lanes t < N of half 0 hold the carried tableau rows (cs.valid) -- loaded by the caller BEFORE H was written into
@@ -210,11 +211,11 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   }
   const double gs = tabs(fi) + 2.0 * ra * xmaxb;
   // A solve without a primal warm start (the reference's pastRes = zeros, duffing.py:634-635) starts at clip(0) -- moved onto the
-  // face the last minimiser lay on when a tableau is carried: the inputs the last solve held at a bound start at the bound the
-  // linear term pushes them to (the gradient at zero is f).  The carried tableau is that face's, so the first Newton point costs no
-  // sweeps; a wrong guess is an input at a bound with an inward gradient, which the first KKT test frees again.
+  // face the last minimiser lay on when a tableau is carried: the inputs the last solve held at a bound start at that bound again.
+  // The carried tableau is that face's, so the first Newton point costs no sweeps; a wrong guess is an input at a bound with an
+  // inward gradient, which the first KKT test frees again.
   const bool held = carried && !warm && !((Smask >> t) & 1u);
-  double x = own ? (warm ? tclip(xw_pre, lb, ub) : (held ? (fi > 0.0 ? lb : ub) : c0)) : 0.0;
+  double x = own ? (warm ? tclip(xw_pre, lb, ub) : (held ? (((cs.umask >> t) & 1u) ? ub : lb) : c0)) : 0.0;
   double hx;
   {
     double lo, hi;
@@ -426,7 +427,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   // the tableau takes H's place in LDS until the next solve.  A solve that worked with the carried tableau and needed many
   // iterations, or five refinement passes for one direction (the contraction |I - T 2H| has worn: a solve from clip(0) refines a
   // gradient of full size and takes three or four), leaves nothing: the next one starts from 2H.
-  const bool keep = status == 0 && !(carried && (it >= 4 || nref >= 5));
+  const bool keep = status == 0 && !(carried && (it >= 4 || nref >= (warm ? 5 : 7)));
   if (keep && own && !half) {
     double* const trow = sR + t * NS;
     if constexpr ((N_ & 1) == 0) {
@@ -440,6 +441,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   }
   cs.valid = keep ? 1 : 0;
   cs.smask = Smask;
+  cs.umask = (unsigned)__ballot(own && x >= ub - eact);
   KTRACE(14);
   return false;
 }

@@ -325,6 +325,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     const int* const ci = reinterpret_cast<const int*>(sCs + 64);
     cs.smask = (unsigned)__builtin_amdgcn_readfirstlane(ci[0]);  // (wave-uniform: the solve branches on them)
     cs.valid = __builtin_amdgcn_readfirstlane(ci[1]);
+    cs.umask = (unsigned)__builtin_amdgcn_readfirstlane(ci[2]);
     if (cs.valid) {
       const double* const trow = sR + (t < N_ ? t : N_ - 1) * rl_stride(N_);
       if constexpr ((N_ & 1) == 0) {
@@ -423,6 +424,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       int* const ci = reinterpret_cast<int*>(sCs + 64);
       ci[0] = (int)cs.smask;
       ci[1] = cs.valid;
+      ci[2] = (int)cs.umask;
     }
     block_sync<64>();
     if (sv.cov_ahead) {
@@ -443,6 +445,7 @@ template <int L_, int N_, int Q_> __device__ __forceinline__ void step_v2_init(d
     int* const ci = reinterpret_cast<int*>(sCs + 64);
     ci[0] = 0;
     ci[1] = 0;
+    ci[2] = 0;
   }
   for (int e = tid; e < N_ * Q_; e += 64) sEr[N_ * Q_ + e] = 0.0;
 }
