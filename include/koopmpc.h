@@ -74,7 +74,10 @@ typedef struct kmpc_config {
   int32_t c_skip_first;/* 1: the first C update only downdates bar_Q (Tank_System.m:252-254)     */
   int32_t cold_start;  /* 0: kmpc_step / kmpc_rollout start each solve at the previous minimiser; 1: always at
                           clip(0), the reference's start (its pastRes_loc stays zeros, duffing.py:634-635, 859).
-                          The minimiser is unique, so this only changes the work, not the answer        */
+                          The minimiser is unique, so this only changes the work, not the answer.  No primal
+                          start is kept; inside a fused roll-out the solver still keeps its factorisation from
+                          step to step and with it the face of the box the last minimiser lay on: clip(0) is
+                          moved onto that face before the first Newton point (qp_rl.h)                        */
   int32_t lift_offset; /* KMPC_LIFT_OFFSET_* (0: the raw encoder, as the Python scripts use it)                 */
   double lambda;       /* RLS forgetting factor (1.0; Koopman_update.m:258)                */
   double P0;           /* inv_K_G init scale (1e4 duffing.py:929-930; 1e5 vanderpol.py:874)*/
