@@ -7,9 +7,10 @@ sys.path.insert(0, os.path.join(ROOT, "koopman-online-updated-mpc_amd"))
 import numpy as np, torch
 from koopmpc import KoopmanMPC
 from koopmpc.synth import initial_states, offline_data, random_mlp_weights
+cold_arg = len(sys.argv) > 1 and sys.argv[1] == "cold"  # every solve from clip(0)
 for (L, N, B, steps, layers) in [(20, 20, 4096, 1000, 3), (8, 10, 4096, 1000, 3), (8, 30, 4096, 300, 3), (32, 40, 2048, 300, 2), (64, 50, 512, 150, 3)]:
     w = random_mlp_weights(2, 100, layers, L)
-    mpc = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=w, layers=layers)
+    mpc = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=w, layers=layers, cold_start=cold_arg)
     mpc.offline_fit(*offline_data())
     X = torch.tensor(initial_states(B), dtype=torch.float64, device="cuda:0")
     r = torch.tensor(np.tile(np.array([[1.0], [0.0]]), (1, N)), dtype=torch.float64, device="cuda:0")
