@@ -511,6 +511,9 @@ def main():
                     help="process-group backend for --gpus N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal of the "
                          "multi-rank code path, e.g. with --same-device on a one-GPU box; not a scaling measurement)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal with --backend gloo)")
+    ap.add_argument("--force-process-group", action="store_true",
+                    help="--gpus 1 with a ONE-rank process group of --backend, and the path's collectives executed on it (barrier, MAX, the "
+                         "Gram all-reduce of cfg4): what a one-GPU box can prove about the RCCL calls; not a scaling measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -540,8 +543,15 @@ def main():
     dev = torch.device("cuda", local)
     dist = None
     pg_world, pg_backend = 1, "none (single process)"
-    if world > 1:
+    if world > 1 or args.force_process_group:
         import torch.distributed as dist
+
+        if world == 1:  # (one rank, no launcher: the rendezvous variables a launcher would have set)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 500))
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
+            os.environ["KMPC_FORCE_COLLECTIVES"] = "1"
 
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)

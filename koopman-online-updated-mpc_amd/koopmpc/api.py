@@ -22,6 +22,7 @@ import numpy as np
 import torch
 
 from . import _ffi
+from .sharding import force_collectives
 
 
 def _dptr(a):
@@ -420,7 +421,7 @@ class KoopmanMPC:
         import torch.distributed as dist
 
         delta = self.shared_local_gram(x)
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or force_collectives()):
             if dist.get_backend() == "gloo":  # (rehearsals of the multi-rank path on CPU-side collectives: gloo reduces host tensors)
                 hd = delta.cpu()
                 dist.all_reduce(hd, op=dist.ReduceOp.SUM)

@@ -15,12 +15,20 @@ def shard_range(total, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def force_collectives():
+    """KMPC_FORCE_COLLECTIVES=1: run the collectives of the path on a one-rank process group too (a rehearsal of the RCCL calls on a
+    one-GPU box: communicator set-up, dtype, stream order -- `bench.py --force-process-group`)."""
+    import os
+
+    return os.environ.get("KMPC_FORCE_COLLECTIVES", "") not in ("", "0")
+
+
 def max_over_ranks(value, device=None):
     """MAX all-reduce of a python float over the default process group (identity without one)."""
     import torch
     import torch.distributed as dist
 
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size() == 1 and not force_collectives()):
         return float(value)
     if dist.get_backend() == "gloo":
         device = None  # (gloo reduces host tensors)

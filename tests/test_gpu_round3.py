@@ -377,6 +377,24 @@ def test_bench_two_ranks_as_a_child_process(torch_mod, cfg):
     assert "rehearsal" in d["config"]  # (never to be read as a scaling figure)
 
 
+@pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
+def test_bench_on_a_one_rank_rccl_process_group(torch_mod, cfg):
+    """What a one-GPU box can prove about the `nccl` (= RCCL) branch the driver's multi-GPU runs take: `bench.py --gpus 1
+    --force-process-group` initialises a ONE-rank process group on RCCL and executes the path's collectives on it -- the barriers
+    around the timed region, the MAX of the elapsed time, and for cfg4 the all-reduce of the Gram block between the two stages of
+    every step (device tensors, torch's current stream, float64 SUM).  One rank: the sums are the identity, so the result must equal
+    the run without a process group up to the clock."""
+    args = ["--gpus", "1", "--config", cfg, "--steps", "4", "--warmup", "2", "--cpu-seconds", "0", "--spin-seconds", "0", "--no-extras",
+            "--settle", "6", "--batch", "512"]
+    d = _bench_child(args + ["--force-process-group"])
+    pg = d["config"]["process_group"]
+    assert pg["world_size"] == 1 and pg["backend"] == "nccl"
+    assert d["n_gpus"] == 1 and d["config"]["worst_qp_status"] == 0 and d["config"]["finite"] is True and d["value"] > 0
+    plain = _bench_child(args)
+    assert plain["config"]["process_group"]["backend"].startswith("none")
+    assert plain["config"]["qp"] == d["config"]["qp"]  # (same Newton-solve statistics: the forced collectives changed no number)
+
+
 _RCCL_CHILD = r"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(%(root)r, "koopman-online-updated-mpc_amd"))
