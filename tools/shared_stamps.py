@@ -18,3 +18,4 @@ names = ["inverses (p sweeps)", "model products", "condense set-up", "Gamma chai
 for i, nm in enumerate(names):
     print("%-28s %7.2f us" % (nm, (t[i + 1] - t[i]) / 100.0))
 print("total %.2f us" % ((t[8] - t[0]) / 100.0))
+print("Krylov stages (us since the chain started):", " ".join("%.2f" % ((t[9 + i] - t[3]) / 100.0) for i in range(6)))
