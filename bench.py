@@ -339,14 +339,14 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
 
     def spin(loop, seconds, steps, step0, snap):
         """bring the GPU out of its idle power state with the timed region's own launches on a scratch controller"""
-        # (back-to-back launches: restoring the snapshot before every one left the GPU idle for half of a 20-step cycle, and a GPU
-        #  that idles more than a few milliseconds in ten runs its next launch 7 % slower -- tools/dbg/launch_gap.py)
+        # (every launch is a replica of the timed region -- restored from the snapshot first --, so that the profiler's average over the
+        #  kernel's launches is the timed launch's duration; back-to-back launches without the restore were tried: same result for the
+        #  timed region, tools/dbg/launch_gap.py, but the scratch controller settles further and its launches get shorter)
         t_spin = time.perf_counter()
-        if snap is not None:
-            loop.m.state_from(snap[0]); loop.X.copy_(snap[1])
         while time.perf_counter() - t_spin < seconds:
-            for _ in range(max(1, 200 // max(1, steps))):
-                loop.advance(steps, step0)
+            if snap is not None:
+                loop.m.state_from(snap[0]); loop.X.copy_(snap[1])
+            loop.advance(steps, step0)
             torch.cuda.synchronize(dev)
 
     # ---- the workload's controller: set-up (offline fit, settle), warm-up (untimed), then EXACTLY --steps timed steps
