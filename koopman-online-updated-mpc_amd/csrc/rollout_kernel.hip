@@ -24,6 +24,10 @@ typedef double d4_t __attribute__((ext_vector_type(4)));
 // used when the batch would otherwise leave CUs without a workgroup).
 constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
 constexpr int ro_scratch() { return 2 * RO_ACT; }     // overlays the per-wave regions between two steps
+// eight-trajectory workgroups keep eight activation columns (the other eight MFMA columns repeat them): half the scratch, so that
+// TWO such workgroups fit on a CU beside their per-wave regions
+constexpr int ro_act8() { return 32 * 32; }
+static size_t ro_scratch_of(int waves) { return waves == 4 ? RO_ACT + 128 * 4 : (waves == 8 ? 2 * ro_act8() : ro_scratch()); }
 constexpr int RO_KB2 = 8;                             // A-fragments are fetched and multiplied in batches of 8 k-steps
 // not overlaid: psi (Lp x columns), x_{k+1} of the trajectories (columns x 4); 16 MFMA columns for 8 / 16 waves, 4 for 4
 static int ro_cols(int waves) { return waves == 4 ? 4 : 16; }
@@ -82,7 +86,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
   const bool live = b < B;
   // lift scratch (overlays the per-wave regions between two steps)
   double* const sAct0 = smem;
-  double* const sAct1 = sAct0 + RO_ACT;
+  double* const sAct1 = sAct0 + (NW == 8 ? ro_act8() : RO_ACT);
   double* const sPsi = smem + ra.keep_off;  // behind the per-wave regions: survives into the step
   double* const sXn = sPsi + ra.Lp * NC;
   if (!RBF && tid0 < 4 * NC) sXn[tid0] = 0.0;  // (columns of trajectories this workgroup does not have)
@@ -248,6 +252,10 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       // waves only take part in the barriers.
       const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
       const bool hid = wv < MTH, out = wv < MTO;
+      // B-fragment layout of an activation set: [k-step][4 k x 16 columns]; eight-trajectory workgroups store eight columns
+      // ([k-step][4 k x 8]) and the lanes of columns 8-15 read columns 0-7 again (their outputs are never stored)
+      constexpr int AR = NW == 8 ? 32 : 64;
+      const int bl = NW == 8 ? ((lane >> 4) << 3) + (lane & 7) : lane;
       if (V2 && !hid && !out) {
         // A wave without a tile of the encoder only takes part in its barriers (2 + layers of them).  Register-state step: it
         // does the covariance half of its trajectory's RLS update meanwhile -- inv_K_G, bar_Q only need [psi(x_{k-1}); u_{k-1}]
@@ -291,7 +299,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * wv + (lane >> 4) + 4 * r;
-          sAct0[(row >> 2) * 64 + ((row & 3) << 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
+          if (NW != 8 || (lane & 15) < 8) sAct0[(row >> 2) * AR + (row & 3) * (AR / 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
         }
       }
       __syncthreads();
@@ -316,9 +324,9 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
             if (kb + RO_KB2 < KS) ro_load_afrags(Wp, KS, wv, kb + RO_KB2, lane, af[(bt + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < RO_KB2; i += 2) {
-              if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i], act[(kb + i) * 64 + lane], acc0, 0, 0, 0);
+              if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i], act[(kb + i) * AR + bl], acc0, 0, 0, 0);
               if (kb + i + 1 < KS)
-                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i + 1], act[(kb + i + 1) * AR + bl], acc1, 0, 0, 0);
             }
           }
         }
@@ -329,7 +337,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
             const int row = 16 * wv + (lane >> 4) + 4 * r;
             const double v = acc0[r] + acc1[r];
             if (last) sPsi[row * 16 + col] = v;
-            else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+            else if (NW != 8 || col < 8) actn[(row >> 2) * AR + (row & 3) * (AR / 4) + col] = v > 0.0 ? v : 0.0;
           }
         }
         // the next layer's first fragments travel across the barrier
@@ -420,7 +428,7 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
   if (wstride) *wstride = (int)per_wave;
   size_t elems = per_wave * waves;
   if (rbf) return elems;
-  const size_t scratch = waves == 4 ? RO_ACT + 128 * 4 : ro_scratch();  // (sAct1 sits RO_ACT behind sAct0)
+  const size_t scratch = ro_scratch_of(waves);  // (sAct1 sits one activation set behind sAct0)
   if (v2) return scratch + elems + ro_keep(Lp, waves);  // (the regions carry the tableau from step to step: no overlay)
   if (elems < scratch) elems = scratch;
   return elems + ro_keep(Lp, waves);
@@ -495,7 +503,7 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   }
   const size_t elems = rollout_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, rbf, waves, a.Lp, &k.wstride);
   k.keep_off = rbf ? 0 : (int)(elems - ro_keep(a.Lp, waves));
-  k.wbase = (V2 && !rbf) ? (int)(waves == 4 ? RO_ACT + 128 * 4 : ro_scratch()) : 0;
+  k.wbase = (V2 && !rbf) ? (int)ro_scratch_of(waves) : 0;
   const size_t lds = elems * sizeof(double);
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
