@@ -222,8 +222,10 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     halves_both_q(rl_matvec<N_>(M, x), lo, hi);
     hx = own ? hi : 0.0;
   }
-  double J0, Jhi;  // (wave-uniform: the loop below branches on it)
-  half_sums_u(own ? x * (hx + fi) : 0.0, J0, Jhi);
+  // the cost at x (wave-uniform: the line search branches on it) is summed when a line search first needs it: the usual iteration of a
+  // running loop -- the refined Newton point of the face, unclipped -- cannot raise the cost of a convex quadratic and skips the sums
+  double J0 = 0.0, Jhi;
+  bool Jok = false;
   int it = 0, status = 1, refresh = 0, polish = 0, rtot = 0, ncrawl = 0, nref = 0;
   bool nopredict = false, rebuild = false;
   KTRACE(8);
@@ -244,7 +246,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     const unsigned Bmask = (unsigned)__ballot(bad);
     const bool refine = (unsigned)__ballot(loose) != 0u;
     const unsigned Imask = (unsigned)__ballot(inI);
-    if (!(J0 == J0) || tabs(J0) > 1e300) { status = 2; break; }
+    if ((unsigned)__ballot(own && !(tabs(g) <= 1e300)) != 0u || (Jok && (!(J0 == J0) || tabs(J0) > 1e300))) { status = 2; break; }
     if (Bmask == 0u && (it > 0 || !warm)) {
       if (!refine || polish >= 2) { status = 0; break; }
       ++polish;
@@ -258,7 +260,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
 
     const bool predict = !nopredict && predict_on;
     int rounds = 0;
-    bool broke = false, isF = false;
+    bool broke = false, isF = false, exact = false;  // exact: the direction's residual gradient on F is at rounding level
     double pdir = 0.0, hp = 0.0;
     while (true) {
       broke = false;
@@ -305,11 +307,12 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
         halves_both_q(rs * rl_matvec<N_>(M, isF ? g : 0.0), lo, hi);
         pdir = lo;
         bool stale = false;
+        exact = false;
         for (int kr = 0;; ++kr) {
           halves_both_q(rl_matvec<N_>(M, isF ? pdir : 0.0), lo, hi);
           hp = hi;  // (H p)_i
           const double r = isF ? g + 2.0 * hp : 0.0;
-          if ((unsigned)__ballot(!(tabs(r) <= 1e-13 * gs)) == 0u) break;
+          if ((unsigned)__ballot(!(tabs(r) <= 1e-13 * gs)) == 0u) { exact = true; break; }
           if (kr >= 6 || !carried) { stale = carried; break; }  // (a fresh tableau is not refined: rounding in T costs an iteration, as before)
           halves_both_q(rs * rl_matvec<N_>(M, r), lo, hi);
           pdir += lo;
@@ -360,6 +363,14 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
         halves_both_q(rl_matvec<N_>(M, xa), lo, hi);
         hxa = own ? hi : 0.0;
       }
+      if (plain && exact) {  // (the exact Newton point of the face, not clipped: accepted without the sums)
+        Jok = false;
+        break;
+      }
+      if (!Jok) {
+        half_sums_u(own ? x * (hx + fi) : 0.0, J0, Jhi);
+        Jok = true;
+      }
       const double pJa = own ? xa * (hxa + fi) : 0.0;
       if (rounds > 0) {
         half_sums_u(pJa, Ja, Jhi);
@@ -385,7 +396,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     rtot += rounds;
     x = xa;
     hx = hxa;
-    J0 = Ja;
+    if (Jok) J0 = Ja;
     if (it == 0) KTRACE(12);
     ++it;
   }

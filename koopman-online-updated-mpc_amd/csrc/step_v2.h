@@ -83,6 +83,14 @@ __device__ __forceinline__ void rowdot1(double (&ac)[4], double v0, double v1, c
     rowdot1<CNT, NCOL, l + 1>(ac, v0, v1, R);
   }
 }
+// ac += R[l] * vec[l], l < CNT <= 16: one accumulator
+template <int CNT, int NCOL, int l = 0>
+__device__ __forceinline__ void rowdot_one(double& ac, double v0, const double (&R)[NCOL]) {
+  if constexpr (l < CNT) {
+    fmac_rowbcast<l, l == 0>(ac, v0, R[l]);
+    rowdot_one<CNT, NCOL, l + 1>(ac, v0, R);
+  }
+}
 // R[l] += vec[l] * coef for l < CNT (coef is the lane's own); column LOWCOL only in lanes 0-31 (-1: none)
 template <int CNT, int NCOL, int LOWCOL, int l = 0>
 __device__ __forceinline__ void rowupd(double (&R)[NCOL], double v0, double v1, double coef) {
@@ -91,6 +99,13 @@ __device__ __forceinline__ void rowupd(double (&R)[NCOL], double v0, double v1, 
     else fmac_rowbcast_m<l - 16, l == 16, l == LOWCOL>(R[l], v1, coef);
     rowupd<CNT, NCOL, LOWCOL, l + 1>(R, v0, v1, coef);
   }
+}
+// half_gather for a vector whose elements AND readers all sit in the first 16-lane row of each half (ROWS <= 16: the small lifts --
+// p = 9 at L = 8): row_newbcast reads inside the reader's own row, so the lane's own register is the operand and nothing is
+// exchanged (two v_permlane16_swap and their moves per product: a tenth of the vector instructions of the cfg3 step)
+template <int ROWS> __device__ __forceinline__ void gather_rows(double a, double& v0, double& v1) {
+  if constexpr (ROWS <= 16) { v0 = a; v1 = a; }
+  else half_gather(a, v0, v1);
 }
 // lanes t and 32 + t exchange: lo = the value of lane t (lanes 0-31) in both halves, hi = that of lane 32 + t
 __device__ __forceinline__ void halves_both(double a, double& lo, double& hi) {
@@ -125,7 +140,7 @@ __device__ __forceinline__ double v2_rls_cov(double* const img, const double z, 
   }
   if constexpr (SYNC) __syncthreads();
   double zv0, zv1;
-  half_gather(z, zv0, zv1);
+  gather_rows<P_>(z, zv0, zv1);
   double a2[4] = {0.0, 0.0, 0.0, 0.0};
   rowdot1<P_, NC>(a2, zv0, zv1, R2);
   const double acc2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);  // lanes < p: (P z)_i ; lanes 32 + i: (bar_Q psi)_i
@@ -137,14 +152,15 @@ __device__ __forceinline__ double v2_rls_cov(double* const img, const double z, 
   s += dpp_shr(s, 8);
   double rt = 0.0;
   fmac_rowbcast<15, true>(rt, s, 1.0);  // the total of this lane's 16-lane row
-  double r0, r1;
-  half_gather(rt, r0, r1);
+  double r0, r1 = 0.0;
+  if constexpr (P_ <= 16) r0 = rt;  // (the second row of the half holds no element)
+  else half_gather(rt, r0, r1);
   const double dd = (half ? 1.0 : lam) + (r0 + r1);
   const double dinv = 1.0 / dd;
   const double c2 = -acc2 * dinv;
   if constexpr (SYNC) __syncthreads();
   double w0, w1;
-  half_gather(acc2, w0, w1);
+  gather_rows<P_>(acc2, w0, w1);
   rowupd<P_, NC, L_>(R2, w0, w1, c2);
   if (lam != 1.0) {
     const double sc = half ? 1.0 : 1.0 / lam;
@@ -238,7 +254,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     const double u2 = sv.cov_done ? sCov[v2_cov_index<L_>(tid)] : v2_rls_cov<L_, false>(img, z, a.lam);
     KTRACE(2);
     double zv0, zv1;
-    half_gather(z, zv0, zv1);
+    gather_rows<(S1 > P_ ? S1 : P_)>(z, zv0, zv1);
     double a1[4] = {0.0, 0.0, 0.0, 0.0};
     rowdot1<P_, NC>(a1, zv0, zv1, R1);
     const double acc1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);  // [A B] rows: (K z)_r ; C rows: (C psi)_r
@@ -249,8 +265,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       double gall, hall;
       halves_both(u2, gall, hall);
       double g0, g1, h0, h1;
-      half_gather(gall, g0, g1);
-      half_gather(hall, h0, h1);
+      gather_rows<(S1 > P_ ? S1 : P_)>(gall, g0, g1);
+      gather_rows<(S1 > P_ ? S1 : P_)>(hall, h0, h1);
       const bool isK = t < L_, isC = t >= L_ && t < S1;
       double eK = psin - acc1;
       if (a.lam != 1.0) {
@@ -290,7 +306,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   {
     const bool isA = t < L_;
     double v0, v1;
-    half_gather(isA ? (half ? psin : R1[L_]) : 0.0, v0, v1);
+    gather_rows<S1>(isA ? (half ? psin : R1[L_]) : 0.0, v0, v1);
     // delta-u form (Tank_System.m:110-113): x+ = A x + B s, s = 1 on the v chain and u_prev on the w chain
     const double bs = (a.du_mode && isA) ? R1[L_] * (half ? up : 1.0) : 0.0;
     const int ro = t - L_ - a.cy0;
@@ -299,12 +315,18 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     KTRACE(5);
 #pragma unroll
     for (int j = 0; j <= N_; ++j) {
-      double ac4[4] = {bs, 0.0, 0.0, 0.0};
-      rowdot1<L_, NC>(ac4, v0, v1, R1);
-      const double acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
+      double acc;
+      if constexpr (L_ <= 8) {  // (a short row: ONE chain of multiply-adds -- four partial sums cost four register clears and three adds per step)
+        acc = bs;
+        rowdot_one<L_, NC>(acc, v0, R1);
+      } else {
+        double ac4[4] = {bs, 0.0, 0.0, 0.0};
+        rowdot1<L_, NC>(ac4, v0, v1, R1);
+        acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
+      }
       if constexpr (v2_chain_dump(N_)) optr[j * q] = acc;
       else if (isO) optr[j * q] = acc;
-      if (j < N_) half_gather(acc, v0, v1);
+      if (j < N_) gather_rows<S1>(acc, v0, v1);
     }
     block_sync<64>();
     // e_j = C_o w_j - r_{j-1}
