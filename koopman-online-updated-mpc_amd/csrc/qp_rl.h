@@ -93,12 +93,28 @@ __device__ __forceinline__ void rl_upd(double (&M)[N_], double v0, double v1, do
   }
 }
 // y = M v for the rows in this lane's half (v: one element per lane of the half)
+template <int N_, int l = 0>
+__device__ __forceinline__ void rl_dot1(double& ac, double v0, double v1, const double (&M)[N_]) {
+  if constexpr (l < N_) {
+    if constexpr (l < 16) fmac_rowbcast<l, l == 0>(ac, v0, M[l]);
+    else fmac_rowbcast<l - 16, l == 16>(ac, v1, M[l]);
+    rl_dot1<N_, l + 1>(ac, v0, v1, M);
+  }
+}
 template <int N_> __device__ __forceinline__ double rl_matvec(const double (&M)[N_], double v) {
   double v0, v1;
   half_gather(v, v0, v1);
-  double ac[4] = {0.0, 0.0, 0.0, 0.0};
-  rl_dot<N_>(ac, v0, v1, M);
-  return (ac[0] + ac[1]) + (ac[2] + ac[3]);
+  if constexpr (N_ > 0) {
+    // (long horizons run sixteen trajectories per CU on a saturated vector pipe: ONE chain of multiply-adds -- the other waves cover
+    //  its latency -- instead of four partial sums with their four register clears and three adds)
+    double ac = 0.0;
+    rl_dot1<N_>(ac, v0, v1, M);
+    return ac;
+  } else {
+    double ac[4] = {0.0, 0.0, 0.0, 0.0};
+    rl_dot<N_>(ac, v0, v1, M);
+    return (ac[0] + ac[1]) + (ac[2] + ac[3]);
+  }
 }
 
 // Symmetric sweep of the tableau (lanes 0-31; lanes 32-63 hold H and must not change: their coefficient is zero) on variable K.

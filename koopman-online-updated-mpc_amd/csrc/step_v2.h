@@ -83,12 +83,14 @@ __device__ __forceinline__ void rowdot1(double (&ac)[4], double v0, double v1, c
     rowdot1<CNT, NCOL, l + 1>(ac, v0, v1, R);
   }
 }
-// ac += R[l] * vec[l], l < CNT <= 16: one accumulator
+// ac += R[l] * vec[l], l < CNT: ONE chain of multiply-adds (its latency is covered by the other waves of the SIMD; four partial sums
+// cost four register clears and three adds per product)
 template <int CNT, int NCOL, int l = 0>
-__device__ __forceinline__ void rowdot_one(double& ac, double v0, const double (&R)[NCOL]) {
+__device__ __forceinline__ void rowdot_one(double& ac, double v0, double v1, const double (&R)[NCOL]) {
   if constexpr (l < CNT) {
-    fmac_rowbcast<l, l == 0>(ac, v0, R[l]);
-    rowdot_one<CNT, NCOL, l + 1>(ac, v0, R);
+    if constexpr (l < 16) fmac_rowbcast<l, l == 0>(ac, v0, R[l]);
+    else fmac_rowbcast<l - 16, l == 16>(ac, v1, R[l]);
+    rowdot_one<CNT, NCOL, l + 1>(ac, v0, v1, R);
   }
 }
 // R[l] += vec[l] * coef for l < CNT (coef is the lane's own); column LOWCOL only in lanes 0-31 (-1: none)
@@ -141,9 +143,8 @@ __device__ __forceinline__ double v2_rls_cov(double* const img, const double z, 
   if constexpr (SYNC) __syncthreads();
   double zv0, zv1;
   gather_rows<P_>(z, zv0, zv1);
-  double a2[4] = {0.0, 0.0, 0.0, 0.0};
-  rowdot1<P_, NC>(a2, zv0, zv1, R2);
-  const double acc2 = (a2[0] + a2[1]) + (a2[2] + a2[3]);  // lanes < p: (P z)_i ; lanes 32 + i: (bar_Q psi)_i
+  double acc2 = 0.0;  // lanes < p: (P z)_i ; lanes 32 + i: (bar_Q psi)_i
+  rowdot_one<P_, NC>(acc2, zv0, zv1, R2);
   // d = lam + z'Pz (lanes 0-31), dc = 1 + psi' bar_Q psi (lanes 32-63): one sum per half
   double s = ((half && t >= L_) ? 0.0 : z) * acc2;
   s += dpp_shr(s, 1);
@@ -255,9 +256,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     KTRACE(2);
     double zv0, zv1;
     gather_rows<(S1 > P_ ? S1 : P_)>(z, zv0, zv1);
-    double a1[4] = {0.0, 0.0, 0.0, 0.0};
-    rowdot1<P_, NC>(a1, zv0, zv1, R1);
-    const double acc1 = (a1[0] + a1[1]) + (a1[2] + a1[3]);  // [A B] rows: (K z)_r ; C rows: (C psi)_r
+    double acc1 = 0.0;  // [A B] rows: (K z)_r ; C rows: (C psi)_r
+    rowdot_one<P_, NC>(acc1, zv0, zv1, R1);
     KTRACE(3);
     // [A B] <- ([A B] - K z g') / lam + y g' = K / lam + (e / lam + y (1 - 1/lam)) g',  g = Pz / d   (Koopman_update.m:270-274;
     // lam = 1: K + e g', duffing.py:927-938);  C <- C + (x_{k+1} - C psi) h',  h = bar_Q psi / dc          duffing.py:943-953
@@ -315,15 +315,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     KTRACE(5);
 #pragma unroll
     for (int j = 0; j <= N_; ++j) {
-      double acc;
-      if constexpr (L_ <= 8) {  // (a short row: ONE chain of multiply-adds -- four partial sums cost four register clears and three adds per step)
-        acc = bs;
-        rowdot_one<L_, NC>(acc, v0, R1);
-      } else {
-        double ac4[4] = {bs, 0.0, 0.0, 0.0};
-        rowdot1<L_, NC>(ac4, v0, v1, R1);
-        acc = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
-      }
+      double acc = bs;
+      rowdot_one<L_, NC>(acc, v0, v1, R1);
       if constexpr (v2_chain_dump(N_)) optr[j * q] = acc;
       else if (isO) optr[j * q] = acc;
       if (j < N_) gather_rows<S1>(acc, v0, v1);
