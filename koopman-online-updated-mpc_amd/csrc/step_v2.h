@@ -21,6 +21,7 @@
 // K += (y - K z) g', P -= (P z)(P z)' / d); sums over a row run in four partial sums.
 #pragma once
 #include "step_body.h"
+#include <type_traits>
 #include "qp_rl.h"
 
 namespace kmpc {
@@ -101,6 +102,23 @@ __device__ __forceinline__ void rowupd(double (&R)[NCOL], double v0, double v1, 
     else fmac_rowbcast_m<l - 16, l == 16, l == LOWCOL>(R[l], v1, coef);
     rowupd<CNT, NCOL, LOWCOL, l + 1>(R, v0, v1, coef);
   }
+}
+// compile-time loop: f(std::integral_constant<int, I>) for I = B .. E-1
+template <int B, int E, typename F> __device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B < E) {
+    f(std::integral_constant<int, B>{});
+    static_for<B + 1, E>(f);
+  }
+}
+// two LDS stores of v (addresses p1 + OFF, p2 + OFF bytes) by the lanes 0 .. CNT-1 only
+template <int CNT, int OFF> __device__ __forceinline__ void lds_store2_lanes(double* p1, double* p2, double v) {
+  typedef __attribute__((address_space(3))) double* lds_t;
+  const unsigned a1 = (unsigned)(size_t)(lds_t)p1, a2 = (unsigned)(size_t)(lds_t)p2;
+  constexpr unsigned LO = CNT >= 32 ? 0xffffffffu : ((1u << CNT) - 1u), HI = CNT > 32 ? ((1u << (CNT - 32)) - 1u) : 0u;
+  unsigned long long saved;
+  asm volatile("s_mov_b64 %0, exec\n\ts_mov_b32 exec_lo, %4\n\ts_mov_b32 exec_hi, %5\n\tds_write_b64 %1, %3 offset:%6\n\t"
+               "ds_write_b64 %2, %3 offset:%6\n\ts_mov_b64 exec, %0"
+               : "=&s"(saved) : "v"(a1), "v"(a2), "v"(v), "n"(LO), "n"(HI), "n"(OFF) : "memory");
 }
 // half_gather for a vector whose elements AND readers all sit in the first 16-lane row of each half (ROWS <= 16: the small lifts --
 // p = 9 at L = 8): row_newbcast reads inside the reader's own row, so the lane's own register is the operand and nothing is
@@ -370,8 +388,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     double* const h1 = sR - idx * NS;
     double* const h2 = sR - idx;
     const double Qw = a.Qw, rdiag = idx == 0 ? a.Rw : 0.0;  // (read once: inside the masked regions below every use was a scalar load of its own)
-#pragma unroll
-    for (int tt = 0; tt < N_; ++tt) {
+    static_for<0, N_>([&](auto TT) {
+      constexpr int tt = decltype(TT)::value;
       if constexpr (Q_ == 2) {
         const dq_t u = gq[tt], w = wq[tt];
         acc = tfma(u[0], w[0], acc);
@@ -380,12 +398,10 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
 #pragma unroll
         for (int r = 0; r < Q_; ++r) acc = tfma(sG[tt * Q_ + r], ((hf ? sEr : sG) + idx * Q_)[tt * Q_ + r], acc);
       }
-      if (tid < N_ - tt) {  // lanes idx < N - tt of the lower half: (aa, bb) = (N-1-tt-idx, N-1-tt) is inside H
-        const double hv = Qw * acc + rdiag;
-        h1[(N_ - 1 - tt) * (NS + 1)] = hv;
-        h2[(N_ - 1 - tt) * (NS + 1)] = hv;
-      }
-    }
+      // lanes tid < N - tt: (aa, bb) = (N-1-tt-idx, N-1-tt) is inside H.  The lane set is a compile-time constant: the two stores run
+      // under an exec mask written as an immediate (a compare, a saved mask and a branch per diagonal step otherwise)
+      lds_store2_lanes<N_ - tt, (N_ - 1 - tt) * (NS + 1) * 8>(h1, h2, Qw * acc + rdiag);
+    });
     if (hf && idx < N_) sf[idx] = 2.0 * Qw * acc;
   }
   if (a.Wterm) {
