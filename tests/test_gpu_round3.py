@@ -401,6 +401,39 @@ def test_cold_start_inside_a_fused_rollout_is_the_same_closed_loop(torch_mod, KM
     assert big <= 0.002 * dU.size and du < 1e-4 and np.median(dU) < 1e-9 and dx < 1e-5
 
 
+@pytest.mark.parametrize("L,N,lift", [(20, 20, "mlp"), (8, 30, "rbf")])
+def test_fused_rollout_reports_non_finite_data_per_trajectory(torch_mod, KM, L, N, lift):
+    """A trajectory whose state is not finite: the register-state solver (qp_rl.h) reports status 2 for it -- the test is on the
+    gradient, the cost sums are only formed when a line search needs them -- and hands back the feasible point clip(0), never a NaN;
+    its neighbours in the same workgroup are not touched (same inputs as a batch without the bad trajectory, bit for bit)."""
+    torch = torch_mod
+    from koopmpc.synth import initial_states, offline_data, random_mlp_weights
+
+    B, bad = 32, 5
+    rng = np.random.RandomState(3)
+    kw = dict(weights=random_mlp_weights(2, 100, 3, L, seed=4)) if lift == "mlp" else dict(lift="rbf", centres=4 * rng.rand(L, 2) - 2)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    x0 = initial_states(B, seed=9)
+    out = []
+    for poison in (False, True):
+        m = KM(n=2, L=L, N=N, batch=B, **kw)
+        assert m.rollout_is_fused()
+        m.offline_fit(*offline_data(), ridge=1e-8)
+        xs = x0.copy()
+        if poison:
+            xs[0, bad] = np.nan
+        X = torch.tensor(xs, dtype=torch.float64, device="cuda:0").contiguous()
+        U, _ = m.rollout("duffing", X, r, 4, log=True)
+        out.append((U.cpu().numpy(), m.status.cpu().numpy().copy()))
+    (Uok, sok), (Ubad, sbad) = out
+    others = np.arange(B) != bad
+    assert (sok == 0).all() and (sbad[others] == 0).all() and sbad[bad] == 2
+    assert np.array_equal(Uok[:, others], Ubad[:, others])
+    # (the encoder's ReLU / the RBF's r > 0 test map the NaN state to a finite lift, so the first step is an ordinary solve; from the
+    #  second step on the output-map update has seen the state itself: status 2, the input is clip(0) of the box [-2, 2])
+    assert np.isfinite(Ubad[:, bad]).all() and np.abs(Ubad[0, bad]) <= 2.0 and np.abs(Ubad[1:, bad]).max() == 0.0
+
+
 @pytest.mark.parametrize("cfg", ["cfg2", "cfg4"])
 def test_bench_two_ranks_as_a_child_process(torch_mod, cfg):
     """`python bench.py --gpus 2 --backend gloo --same-device` as the driver would start it for N > 1, minus the second GPU:
