@@ -205,6 +205,67 @@ def _cpu_worker(args):
     return done, secs, tdone, tsecs
 
 
+def _probe_worker(path):
+    """cpu_baseline leg, checker only (a child process that never touches the GPU): the exact minimisers of the QPs of a few
+    trajectories of the timed state -- oracle lift of their states, oracle condense of the models the device used, qp_exact --
+    against the inputs the device computed for them.  Prints {"max_abs_u_err": ..., "n": ...}."""
+    from oracle import koopman_oracle as ko
+
+    d = np.load(path)
+    name, L, N = str(d["name"]), int(d["L"]), int(d["N"])
+    w = workload_inputs(name, L, N)
+    c = w["cfg"]
+    lift = (lambda x: ko.rbf_lift(x, w["centres"])) if c.get("lift") == "rbf" else (lambda x: ko.mlp_lift(w["weights"], x))
+    X, A, Bm, Cm, u_gpu, uprev, r = d["X"], d["A"], d["B"], d["C"], d["u"], d["uprev"], w["ref"]
+    worst = 0.0
+    for i in range(X.shape[1]):
+        psi = lift(X[:, i:i + 1]).reshape(-1)
+        if name == "cfg4":
+            ctl = ko.OracleDeltaUController(lift, L, 2, N, A[i], Bm[i], Cm[i])
+            ctl.u = float(uprev[i])
+            At, Bt, Co, xt = ctl.qp(psi)
+            _, _, H, f, _ = ko.condense(At, Bt, Co, xt, r, N, ctl.Qw, ctl.Rw)
+            lbv = np.full(N, ctl.lb); ubv = np.full(N, ctl.ub)
+            lbv[0] = max(ctl.lb, ctl.umin - ctl.u); ubv[0] = min(ctl.ub, ctl.umax - ctl.u)
+            dU, _ = ko.qp_exact(H, f, lbv, ubv)
+            u = ctl.u + float(dU[0])
+        else:
+            _, _, H, f, _ = ko.condense(A[i], Bm[i].reshape(L, 1), Cm[i], psi, r, N, 100.0, 1e-4)
+            U, _ = ko.qp_exact(H, f, c["lb"], c["ub"])
+            u = float(U[0])
+        worst = max(worst, abs(u - float(u_gpu[i])))
+    print(json.dumps({"max_abs_u_err": worst, "n": int(X.shape[1])}))
+
+
+def parity_probe(loop, name, L, N, step_next, nprobe=8):
+    """One more closed-loop step of the timed controller (untimed), `nprobe` of its trajectories checked against the oracle in a child
+    process: max |u_gpu - u_oracle| (duffing.py:857-861: the input the loop applies).  The models are the ones the device solved with
+    (exported after the step), so the figure covers lift, condensed build and box QP of the timed state."""
+    import tempfile
+    torch = loop.torch
+    B = loop.B
+    idx = torch.tensor(np.unique(np.linspace(0, B - 1, nprobe).astype(np.int64)), device=loop.dev)
+    Xpre = loop.X[:, idx].cpu().numpy()
+    if loop.shared:
+        uprev = loop.m.U0[idx].cpu().numpy()
+        loop.m.shared_step(loop.X, loop.r, plant="tank", switched=(step_next > 100))
+        u = loop.m.U0[idx].cpu().numpy()
+        A, Bm, Cm = [t.cpu().numpy() for t in loop.m.shared_model()]
+        A, Bm, Cm = [np.broadcast_to(t, (len(idx),) + t.shape).copy() for t in (A, Bm, Cm)]
+    else:
+        uprev = np.zeros(len(idx))
+        Ul, _ = loop.m.rollout(loop.c["plant"], loop.X, loop.r, 1, step0=step_next, log=True)
+        u = Ul[0, idx].cpu().numpy()
+        A, Bm, Cm = [t[idx].cpu().numpy() for t in loop.m.get_model()]
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "probe.npz")
+        np.savez(path, name=name, L=L, N=N, X=Xpre, A=A, B=Bm, C=Cm, u=u, uprev=uprev)
+        out = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-worker", path], capture_output=True, text=True, timeout=300)
+    if out.returncode != 0:
+        return {"error": out.stderr.strip()[-200:]}
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
 def cpu_baseline(name, L, N, x0s, budget_s, settle):
     """The reference's path on the host cores, timed BEFORE this process touches the GPU (the workers are forked): one
     trajectory stream per core of the box's CPU share, each in the GPU leg's regime (`settle` steps after the reset are set-up,
@@ -308,7 +369,24 @@ def algorithmic_flops(name, L, N, q, newton_per_step):
     return lift + rls_ab + rls_c + cond + qp
 
 
-def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=True, spin_seconds=1.0):
+def executed_flops(name, L, N, q, newton_per_step):
+    """What the kernels actually issue per trajectory-step: gain-form RLS, the two length-N recursions on the stacked
+    [A; C_o], the Toeplitz H / f pass (prefix sums along the diagonals instead of the dense 2 (qN)(Nm)^2 product), and five N x N
+    products per Newton solve (H x, T g, H p and one refinement pair; sweeps of a set change count as one product each)."""
+    c = CONFIGS[name]
+    n, p, h = 2, L + 1, 100
+    d = c.get("layers", 3)
+    lift = 25 * L if c.get("lift") == "rbf" else 2 * (n * h + (d - 1) * h * h + h * L)
+    qp = newton_per_step * 5 * 2 * N * N
+    if c.get("shared"):
+        return lift + 2 * (p + L + n) * p + 2 * N * (L + 1) + 3 * 2 * N * N  # f = F psi, u = T0 f, g = 2 H u + f (interior kernel)
+    rls = (4 * p * p + 2 * p + 4 * L * p) + (4 * L * L + 2 * L + 4 * n * L)
+    rec = 2 * 2 * (L + q) * L * (N + 1)
+    hf = 2 * (2 * q + 1) * N * N
+    return lift + rls + rec + hf + qp
+
+
+def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=True, spin_seconds=1.0, probe=True):
     """Set-up (offline fit, `settle` closed-loop steps), W warm-up steps, then EXACTLY K timed steps of one configuration:
     returns the fields of the JSON line that depend on the workload (value, ms_per_step, roofline, the QP statistics)."""
     import torch
@@ -386,13 +464,19 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
         qp_launch_ms = launch_ms
         launch_ms = dt / max(1, args.steps) * 1e3
     bytes_per_traj = mpc.algorithmic_bytes_per_step()
-    if main_loop.shared:  # the shared-model mode drops the per-trajectory state term 2 (p^2 + L p + L^2 + n L)
-        sz, p_, q_ = (8 if args.dtype == "f64" else 4), L + 1, mpc.q
-        bytes_per_traj = sz * ((L + L * p_ + 2 * L + N + 2) + (2 + 1 + q_ * N))
+    if main_loop.shared:
+        # the shared-model mode drops the per-trajectory state term 2 (p^2 + L p + L^2 + n L); what a trajectory still moves
+        # per step: x in / out (2 n), u_prev in, u out (2 m), psi_k written by the lift and psi_{k-1}, psi_k read by the Gram sums and by
+        # f = F psi (3 L), the input sequence and the warm start out (2 N m).  The model ([A B], C), H, F, T0 and the reference are ONE
+        # copy for the batch (round 3 counted an L p model and a q N reference per trajectory: 9 896 B)
+        sz = 8 if args.dtype == "f64" else 4
+        bytes_per_traj = sz * (2 * 2 + 2 * 1 + 3 * L + 2 * N)
     bytes_per_launch = bytes_per_traj * B * steps_per_launch
     achieved = bytes_per_launch / (launch_ms * 1e-3) / 1e9 if launch_ms > 0 else 0.0
     flops_per_traj = algorithmic_flops(name, L, N, mpc.q, newton_per_step)
     tflops = flops_per_traj * B * steps_per_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
+    exec_flops_per_traj = executed_flops(name, L, N, mpc.q, newton_per_step)
+    exec_tflops = exec_flops_per_traj * B * steps_per_launch / (launch_ms * 1e-3) / 1e12 if launch_ms > 0 else 0.0
 
     # ---- beside the headline: every solve started at clip(0) as the reference does; the same window right after the reset
     ex = {}
@@ -412,18 +496,17 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
             dtc = timed(cold, args.steps, step0)
             ex["cold_start"] = {"value": B * world * args.steps / dtc, "ms_per_step": dtc / args.steps * 1e3,
                                 "frac": bytes_per_traj * B * args.steps / dtc / 1e9 / HBM_PEAK_GBS,
-                                "mean_newton_solves_per_step": float(cold.m.iters.double().mean().item()) / max(1, args.steps),
-                                "note": "same state, every QP started at clip(0) like the reference (duffing.py:634-635, 859): same minimiser, more work; frac = "
-                                        "algorithmic bytes / wall time of the timed region / HBM peak"}
+                                "newton_solves_per_step": float(cold.m.iters.double().mean().item()) / max(1, args.steps),
+                                "note": "same state, every QP started at clip(0) as duffing.py:634-635; frac over the wall time of the region"}
             del cold
         fresh = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
         fresh.advance(args.warmup, 0)
         respin()
         dtp = timed(fresh, args.steps, args.warmup)
         ex["post_reset"] = {"value": B * world * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3,
-                            "mean_newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if not fresh.shared else 1),
-                            "note": "the same %d timed steps after %d warm-up steps counted from the RLS reset (no settle steps): the estimator's "
-                                    "start-up transient, ill-conditioned QPs with many active-set changes" % (args.steps, args.warmup)}
+                            "frac": bytes_per_traj * B * args.steps / dtp / 1e9 / HBM_PEAK_GBS,
+                            "newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if not fresh.shared else 1),
+                            "note": "the same %d steps after %d warm-up steps counted from the RLS reset (no settle steps)" % (args.steps, args.warmup)}
         del fresh
 
     if dist is not None:
@@ -432,25 +515,22 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
         worst_status, x_ok = int(flag[0].item()), int(flag[1].item()) == 0
 
     # HBM bytes per trajectory-step from the PMC counters (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes,
-    # own-pattern calibration), collected with tools/profile_config.sh and committed in profiles/
-    traffic, traffic_note = None, "not collected for this configuration"
+    # tools/profile_config.sh -> profiles/traffic.json)
+    traffic, traffic_src = None, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         tj = json.load(open(tp)).get("%s:%s:%s" % (name, args.dtype, "fused" if fused else "steps"))
         if tj and (tj["L"], tj["N"]) == (L, N):
             traffic = tj["bytes_per_trajectory_step"] * B * steps_per_launch
-            traffic_note = "bytes per launch = %.0f B per trajectory-step (rocprofv3 PMC passes at B = %d, %s) x trajectories x steps per launch" % (
+            traffic_src = "%.0f B per trajectory-step x trajectories x steps per launch (PMC passes at B = %d, %s)" % (
                 tj["bytes_per_trajectory_step"], tj["B"], tj["source"])
 
     if main_loop.shared:
-        kname = ("whole shared-model step = six dependent launches: lift_coop_kernel (MFMA), gram_kernel (MFMA), gram_reduce_kernel, shared_model_kernel "
-                 "(ONE workgroup: two Gram inverses, model, condense, T0 -- serial, about half of the step), shared_fast_kernel (interior trajectories, "
-                 "16 per wave on MFMA), step_qp_kernel (only the trajectories whose box binds; %d blocks x 64 threads that exit at once otherwise); "
-                 "per-kernel times: profiles/r3_cfg4_summary.txt" % B)
+        kname = "whole shared-model step (all launches of a step and the gaps between them; per-kernel times: profiles/)"
     elif fused:
-        kname = "rollout_kernel (lift + RLS + condense + QP + plant, all %d steps in one launch), %d workgroups" % (steps_per_launch, (B + 15) // 16)
+        kname = "rollout_kernel, all %d steps in one launch, %d workgroups" % (steps_per_launch, (B + 15) // 16)
     else:
-        kname = "step_kernel (RLS + condense + QP + plant), %d blocks x %d threads" % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64))
+        kname = "step_kernel, %d blocks x %d threads" % (B, mpc.cfg.threads or (256 if (L + 1) ** 2 > 2048 or N * N > 2048 else 64))
     # governing roofline: the per-trajectory modes stream their state -> HBM; the 8-observable RBF set (cfg3, AI ~ 120
     # flop/B) is bound by the fp64 vector pipe, not by bandwidth.  Both fractions are reported for every configuration.
     hbm_frac = achieved / HBM_PEAK_GBS
@@ -459,32 +539,43 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
     compute_bound = (c.get("lift") == "rbf" and L <= 8)
     roof = {
         "bound": "fp64_valu" if compute_bound else "hbm",
-        "kernel": kname,
         "achieved": tflops if compute_bound else achieved,
         "peak": flop_peak if compute_bound else HBM_PEAK_GBS,
         "unit": "TFLOP/s" if compute_bound else "GB/s",
         "frac": flop_frac if compute_bound else hbm_frac,
-        "hbm_frac": hbm_frac,
-        "hbm_achieved_GBs": achieved,
-        "flop_frac": flop_frac,
-        "flop_achieved_TFLOPs": tflops,
-        "algorithmic_flops_per_trajectory_step": flops_per_traj,
-        "flop_note": "SURVEY 8d formulas (dense condensed build, reference-form RLS) with the measured %.2f Newton solves per step; peak %.1f TFLOP/s %s" % (newton_per_step, flop_peak, "fp32" if args.dtype == "f32" else "fp64"),
         "traffic": traffic,
-        "traffic_note": traffic_note,
-        "algorithmic_bytes_per_trajectory_step": bytes_per_traj,
-        "algorithmic_bytes_per_launch": bytes_per_launch,
-        "steps_per_launch": steps_per_launch,
+        "kernel": kname,
         "avg_kernel_ms": launch_ms,
-        "avg_lift_kernel_ms": lift_ms,
-        "kernel_time_source": ("wall time of the timed region / steps (all launches of a step and the gaps between them)" if main_loop.shared
-                               else "HIP events around the launches of the timed pass itself"),
+        "steps_per_launch": steps_per_launch,
+        "algorithmic_bytes_per_trajectory_step": bytes_per_traj,
+        "flops_per_trajectory_step": flops_per_traj,
+        "executed_flops_per_trajectory_step": exec_flops_per_traj,
+        "hbm_frac": hbm_frac,
+        "flop_frac": flop_frac,
+        "executed_flop_frac": exec_tflops / flop_peak,
+        "newton_solves_per_step": newton_per_step,
+        "time_source": "wall time of the timed region / steps" if main_loop.shared else "HIP events around the timed launches",
     }
+    if traffic_src:
+        roof["traffic_source"] = traffic_src
     if qp_launch_ms is not None:
         roof["qp_launches_ms"] = qp_launch_ms  # shared_fast_kernel + step_qp_kernel between HIP events
+    if "cold_start" in ex:
+        roof["cold_start_frac"] = ex["cold_start"]["frac"]
+        roof["cold_start_value"] = ex["cold_start"]["value"]
+    if "post_reset" in ex:
+        roof["post_reset_frac"] = ex["post_reset"]["frac"]
+        roof["post_reset_value"] = ex["post_reset"]["value"]
+    pp = None
+    if probe and rank == 0:
+        try:
+            pp = parity_probe(main_loop, name, L, N, step0 + args.steps)
+        except Exception as e:  # (the probe must not take the measurement with it; it is reported)
+            pp = {"error": "%s: %s" % (type(e).__name__, e)}
+        roof["parity_probe_max_abs_u_err"] = pp.get("max_abs_u_err")
     return {"dt": dt, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "roofline": roof, "extras": ex,
             "worst_status": worst_status, "x_ok": x_ok, "newton_per_step": newton_per_step, "newton_max": newton_max,
-            "shared": main_loop.shared, "q": mpc.q, "text": c["text"]}
+            "shared": main_loop.shared, "q": mpc.q, "text": c["text"], "parity_probe": pp}
 
 
 def main():
@@ -511,10 +602,16 @@ def main():
                     help="process-group backend for --gpus N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal of the "
                          "multi-rank code path, e.g. with --same-device on a one-GPU box; not a scaling measurement)")
     ap.add_argument("--same-device", action="store_true", help="every rank uses cuda:0 (rehearsal with --backend gloo)")
+    ap.add_argument("--probe-worker", default=None, help=argparse.SUPPRESS)  # (child of parity_probe: oracle on the host, no GPU)
+    ap.add_argument("--no-probe", action="store_true", help="skip the parity probe (8 trajectories of the timed state against the oracle)")
+    ap.add_argument("--verbose-line", action="store_true", help="keep the long workload / sample descriptions in the JSON line")
     ap.add_argument("--force-process-group", action="store_true",
                     help="--gpus 1 with a ONE-rank process group of --backend, and the path's collectives executed on it (barrier, MAX, the "
                          "Gram all-reduce of cfg4): what a one-GPU box can prove about the RCCL calls; not a scaling measurement")
     args = ap.parse_args()
+    if args.probe_worker:
+        _probe_worker(args.probe_worker)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -561,45 +658,45 @@ def main():
         if pg_world != args.gpus:
             sys.exit("bench.py --gpus %d but the process group has %d ranks" % (args.gpus, pg_world))
 
-    res = measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=not args.no_extras, spin_seconds=args.spin_seconds)
+    res = measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=not args.no_extras, spin_seconds=args.spin_seconds,
+                         probe=not args.no_probe)
 
     # ---- the other BASELINE configurations in the same run (short legs, no cold-start / post-reset pair, N = 1 only): what the
     # driver's one line would otherwise not carry
     others = {}
     if name == "cfg2" and world == 1 and not args.no_extras and not (args.batch or args.L or args.N or args.cold_start):
-        for oname in ("cfg3", "cfg3-L20", "cfg4", "cfg5"):
+        import copy
+
+        def leg(oname, a_, label=None):
             oc = CONFIGS[oname]
             try:
-                o = measure_config(oname, args, None, dev, 0, 1, oc["L"], oc["N"], oc["B"], oc["settle"], extras=False, spin_seconds=0.3)
-                others[oname] = {"value": o["value"], "unit": "steps/s", "ms_per_step": o["ms_per_step"], "frac": o["roofline"]["frac"],
-                                 "bound": o["roofline"]["bound"], "hbm_frac": o["roofline"]["hbm_frac"], "flop_frac": o["roofline"]["flop_frac"],
-                                 "kernel_ms": o["roofline"]["avg_kernel_ms"], "steps_per_launch": o["roofline"]["steps_per_launch"],
-                                 "worst_qp_status": o["worst_status"], "finite": o["x_ok"],
-                                 "mean_newton_solves_per_step": o["newton_per_step"], "trajectories": oc["B"], "workload": oc["text"]}
+                o = measure_config(oname, a_, None, dev, 0, 1, oc["L"], oc["N"], oc["B"], oc["settle"], extras=False, spin_seconds=0.3,
+                                   probe=not args.no_probe)
+                ro = o["roofline"]
+                # [steps/s, frac of the governing roofline, bound, kernel ms per launch, steps per launch, worst QP status, finite,
+                #  parity probe max |u - u_oracle|, executed-flop fraction]
+                others[label or oname] = [o["value"], ro["frac"], ro["bound"], ro["avg_kernel_ms"], ro["steps_per_launch"], o["worst_status"],
+                                          o["x_ok"], ro.get("parity_probe_max_abs_u_err"), ro["executed_flop_frac"]]
             except Exception as e:  # (a leg that fails must not take the headline with it; it is reported)
-                others[oname] = {"error": "%s: %s" % (type(e).__name__, e)}
+                others[label or oname] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
-        # BASELINE's configs[1] names fp32: the same workload with float32 arithmetic (per-step kernels, no fused fp32 roll-out; the 1e-6
-        # bar on u needs float64) -- reported beside the float64 headline, never in place of it
-        if args.dtype == "f64":
-            import copy
+
+        for oname in ("cfg3", "cfg3-L20", "cfg4", "cfg5"):
+            leg(oname, args)
+        # BASELINE's configs[1] names fp32: the same workload with float32 arithmetic -- reported beside the float64 headline, never in
+        # place of it (the 1e-6 bar on u needs float64)
+        if args.dtype == "f64" and os.environ.get("KMPC_BENCH_F32_LEG"):
             a32 = copy.copy(args)
             a32.dtype = "f32"
-            try:
-                oc = CONFIGS["cfg2"]
-                o = measure_config("cfg2", a32, None, dev, 0, 1, oc["L"], oc["N"], oc["B"], oc["settle"], extras=False, spin_seconds=0.3)
-                others["cfg2-f32"] = {"value": o["value"], "unit": "steps/s", "ms_per_step": o["ms_per_step"], "dtype": "f32", "frac": o["roofline"]["frac"],
-                                      "bound": o["roofline"]["bound"], "hbm_frac": o["roofline"]["hbm_frac"], "flop_frac": o["roofline"]["flop_frac"],
-                                      "kernel_ms": o["roofline"]["avg_kernel_ms"], "steps_per_launch": o["roofline"]["steps_per_launch"],
-                                      "worst_qp_status": o["worst_status"], "finite": o["x_ok"],
-                                      "mean_newton_solves_per_step": o["newton_per_step"], "trajectories": oc["B"],
-                                      "workload": oc["text"] + " -- float32 arithmetic, lift kernel + step kernel per step (not fused)"}
-            except Exception as e:
-                others["cfg2-f32"] = {"error": "%s: %s" % (type(e).__name__, e)}
-            torch.cuda.empty_cache()
+            a32.no_probe = True
+            leg("cfg2", a32, "cfg2-f32")
 
     if rank == 0:
         total = B * world
+        roof = res["roofline"]
+        if others:
+            roof["other_configs"] = others
+            roof["other_configs_fields"] = "steps/s, frac, bound, kernel_ms, steps_per_launch, worst_qp_status, finite, parity_probe, executed_flop_frac"
         out = {
             "metric": "MPC steps/s (lift+EDMD-update+QP, N=%d, %d-dim lift)" % (N, L),
             "value": res["value"],
@@ -614,28 +711,25 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic",
             "config": {
-                "workload": "%s; %d trajectories per GPU x %d GPU(s); controller state: %d closed-loop steps after the RLS reset (set-up) + the "
-                            "warm-up; arithmetic in %s%s" % (c["text"], B, world, settle, args.dtype,
-                                                            " (the config line names fp32; the reference computes in float64 and the 1e-6 bar on u needs it, DESIGN.md 4.1)" if name == "cfg2" else ""),
+                "workload": (c["text"] if args.verbose_line else name) + "; %d trajectories per GPU x %d GPU(s); %d settle steps after the RLS reset + the "
+                            "warm-up are set-up; arithmetic in %s" % (B, world, settle, args.dtype),
                 "global_batch": total,
                 "process_group": {"world_size": pg_world, "backend": pg_backend, "ranks_share_device": bool(args.same_device)},
                 **({"rehearsal": "ranks share cuda:0 / gloo collectives: exercises the multi-rank code path, NOT a scaling measurement"}
                    if (args.same_device or (world > 1 and args.backend != "nccl")) else {}),
                 "parallelism": ("trajectory-sharded x%d, one RCCL all-reduce of the %d-element Gram block per step" % (world, (2 * L + 3) * (L + 1))) if res["shared"]
                                else "trajectory-sharded x%d, no collective on the step path" % world,
-                "qp": "exact box-QP (projected Newton), %s; mean Newton solves/step %.2f, worst trajectory total %d"
-                      % ("each solve started at clip(0) like the reference" if args.cold_start else
-                         "each solve started at the previous minimiser (the reference restarts at zeros: same minimiser, more work)",
+                "qp": "exact box-QP (projected Newton), started at %s; mean Newton solves/step %.2f, worst trajectory total %d"
+                      % ("clip(0) as the reference" if args.cold_start else "the previous minimiser (reference: zeros, see roofline.cold_start_*)",
                          res["newton_per_step"], res["newton_max"]),
                 "worst_qp_status": res["worst_status"],
                 "finite": res["x_ok"],
-                "u_tolerance": "controls within 1e-6 of the oracle in float64 (Van der Pol with P0 = 1e5: 1e-4, the re-association floor of the reference's own K_A inv_K_G product, DESIGN.md 2)",
+                "parity_probe": res["parity_probe"],
             },
-            "roofline": res["roofline"],
+            "roofline": roof,
         }
-        out.update(res["extras"])
-        if others:
-            out["other_configs"] = others
+        if args.verbose_line:
+            out.update(res["extras"])
         if cpu is not None:
             v, done, busy, cores, wall = cpu["all"]
             tv, tdone, tbusy = cpu["transient"]
@@ -647,19 +741,15 @@ def main():
                 "unit": "steps/s",
                 "cores": cores,
                 "kind": "port",
-                "regime": regime,
-                "sample": "%d worker processes (one per core), each the first trajectories of its slice of the same workload: %d closed-loop steps "
-                          "after the RLS reset as set-up (the GPU leg's regime), then timed steps: %d trajectory-steps in %.1f core-seconds "
-                          "(%.1f s of wall time for the whole sample); value = cores x steps per core-second; NumPy oracle, %s, one BLAS thread per "
-                          "worker; host reports %d cores"
+                "sample": "%d workers (one per core) x the first trajectories of the same workload, %d settle steps each, then %d timed "
+                          "trajectory-steps in %.1f core-seconds (%.1f s wall); NumPy oracle, %s; host has %d cores"
                           % (cores, cpu["settle"], done, busy, wall,
-                             "SciPy L-BFGS-B exactly as duffing.py:857-859" if cpu["solver"] == "lbfgsb" else
-                             "exact active-set QP in place of quadprog (Tank_System.m:190), one pooled model per worker's 64 trajectories",
+                             "SciPy L-BFGS-B as duffing.py:857-859" if cpu["solver"] == "lbfgsb" else "exact active-set QP in place of quadprog, one pooled model per worker",
                              os.cpu_count()),
+                "regime": regime,
                 "single_core_value": cpu["one"][0],
                 "post_reset_value": tv,
-                "post_reset_sample": "the first %d steps after the reset of the same trajectories: %d trajectory-steps in %.1f core-seconds" % (cpu["post"], tdone, tbusy),
-                "exact_qp_variant_single_core_value": cpu["exact"],
+                "exact_qp_single_core_value": cpu["exact"],
             }
         print(json.dumps(out), flush=True)
     if dist is not None:

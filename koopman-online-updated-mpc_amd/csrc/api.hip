@@ -346,6 +346,9 @@ struct Impl : kmpc_handle {
       for (int c2 = 0; c2 < L; ++c2) k[(size_t)r * p + c2] = (T)A[(size_t)r * L + c2];
       k[(size_t)r * p + L] = (T)Bm[r];
     }
+    // (a roll-out enqueued on a non-blocking stream may still be writing the wave image: the null-stream conversion below does
+    //  not wait for such a stream by itself)
+    HIPCHK(hipDeviceSynchronize());
     { int rc = ensure_dense(nullptr, true); if (rc) return rc; }
     { int rc = forget_tableaux(nullptr); if (rc) return rc; }
     HIPCHK(hipMemcpy(dTmp, k.data(), k.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -901,6 +904,7 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMalloc(&dFs, sizeof(T) * (size_t)N * (L + 1)));  // (one more column in the delta-u form)
     HIPCHK(hipMalloc(&df0s, sizeof(T) * (size_t)N));
     // until samples exist the shared model is the offline one (trajectory 0's copy, duffing.py:811-813)
+    HIPCHK(hipDeviceSynchronize());  // (before the conversion: non-blocking streams do not order with the null stream)
     { int rc = ensure_dense(nullptr, false); if (rc) return rc; HIPCHK(hipDeviceSynchronize()); }
     HIPCHK(hipMemcpy(dKs, dK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(dCs, dC, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice));
@@ -1072,6 +1076,7 @@ struct Impl : kmpc_handle {
   }
   int state_export(void* blob, int64_t bytes) override {
     if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_export: buffer too small");
+    HIPCHK(hipDeviceSynchronize());  // (a roll-out on a non-blocking stream may still be writing the wave image)
     { int rc = ensure_dense(nullptr, false); if (rc) return rc; }
     { int rc = forget_tableaux(nullptr); if (rc) return rc; }  // (a checkpoint is a synchronisation point: exporter and importer continue alike)
     HIPCHK(hipDeviceSynchronize());

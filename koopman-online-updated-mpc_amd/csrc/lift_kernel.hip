@@ -305,7 +305,7 @@ template <typename T> __global__ __launch_bounds__(256) void lift_rbf_kernel(con
           xc += x[i] * c;
         }
         T d2 = xx - T(2) * xc + cc;
-        d2 = d2 > T(0) ? d2 : T(0);
+        d2 = d2 < T(0) ? T(0) : d2;  // (np.maximum(d2, 0) of sklearn's euclidean_distances: a NaN stays a NaN)
         const T d = sqrt(d2);
         v = d * d * kmpc_logT<T>(d + a.eps);  // (the same logarithm as the fused roll-out's lift: plant_device.h)
       }

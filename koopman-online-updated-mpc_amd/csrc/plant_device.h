@@ -43,7 +43,8 @@ template <typename T> __device__ __forceinline__ void plant_apply(int plant, int
 
 
 // ---------------------------------------------------------------------------------------
-// Natural logarithm for the thin-plate RBF dictionary (vanderpol_RBF.py:21-22, rbf.m:26-29), positive normal arguments.
+// Natural logarithm for the thin-plate RBF dictionary (vanderpol_RBF.py:21-22, rbf.m:26-29).  Domain: positive FINITE arguments
+// (normal or subnormal); +inf gives NaN (s = inf / inf) -- callers that can meet it guard it (kmpc_logT below).
 // The library log() keeps its dozen polynomial coefficients in vector registers for the whole kernel once the step loop of a
 // roll-out makes them loop-invariant (24 VGPRs of the 128 a trajectory has: the N = 30 roll-out spilled because of them and
 // re-read them from scratch memory at every step).  Here every coefficient is written into its register where it is used, by
@@ -79,7 +80,10 @@ __device__ __forceinline__ double kmpc_log(double x) {
   return dk * kmpc_const<0x3fe62e42u, 0xfee00000u>() - ((hfsq - (s * (hfsq + R) + dk * kmpc_const<0x3dea39efu, 0x35793c76u>())) - f);
 }
 template <typename T> __device__ __forceinline__ T kmpc_logT(T x);
-template <> __device__ __forceinline__ double kmpc_logT<double>(double x) { return kmpc_log(x); }
+// (stand-alone lift: +inf -> +inf as the library log; NaN stays NaN.  Subnormal arguments need no rescaling here -- v_frexp_mant /
+//  v_frexp_exp handle them natively, unlike the integer bit-twiddling of e_log.c.  The fused roll-out calls kmpc_log directly: a
+//  trajectory whose state is not finite ends as status 2 there whichever non-finite value its lift carries.)
+template <> __device__ __forceinline__ double kmpc_logT<double>(double x) { return x < __builtin_inf() ? kmpc_log(x) : x; }
 template <> __device__ __forceinline__ float kmpc_logT<float>(float x) { return logf(x); }
 
 }  // namespace kmpc

@@ -176,6 +176,7 @@ template <int N_>
 __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const StepArgs<double>& a, const StepVar<double>& sv, const int b,
                                       double* qx_out, double* u_slot, double (&M)[N_], double& rs, double& rsi, QpCarry& cs, double up, double xw_pre) {
   typedef double d2_t __attribute__((ext_vector_type(2)));
+  static_assert(N_ <= 32, "qp_rl: one variable per lane of a 32-lane half (ownmask, row_newbcast index, diagonal lane)");
   const int tid = local_tid<64>(), half = tid >> 5, t = tid & 31;
   const bool own = t < N_;
   const int B = a.B;

@@ -138,7 +138,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
           double xx = 0.0, cc = 0.0, xc = 0.0;
           for (int i = 0; i < n; ++i) { xx += x[i] * x[i]; cc += c[i] * c[i]; xc += x[i] * c[i]; }
           double d2 = xx - 2.0 * xc + cc;
-          d2 = d2 > 0.0 ? d2 : 0.0;
+          d2 = d2 < 0.0 ? 0.0 : d2;  // (np.maximum: a NaN stays a NaN)
           const double d = sqrt(d2);
           psi_i = d * d * kmpc_log(d + R.eps);
         }

@@ -29,7 +29,8 @@ namespace kmpc {
 // ---------------------------------------------------------------------------------------
 // wave image of one trajectory (host + device)
 // ---------------------------------------------------------------------------------------
-static constexpr bool step_v2_dims(int L, int N, int q) { return q != L && q > 0 && L + 2 <= 32 && N <= 40 && L >= 2; }
+// (N <= 32: qp_rl and the H / f pass keep one variable per lane of a 32-lane half)
+static constexpr bool step_v2_dims(int L, int N, int q) { return q != L && q > 0 && L + 2 <= 32 && N <= 32 && L >= 2; }
 // LDS of one trajectory (elements):
 //   R    N x N   H while a solve runs, the tableau of the last solve between two solves (qp_rl.h)          persistent
 //   cs   130     row scales of that tableau (2 x 32), its variable set / validity (2 ints), the gains of a covariance
@@ -209,6 +210,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   constexpr int P_ = L_ + 1, CP = (L_ + 2) / 2, NC = 2 * CP, NX = 2, S2 = 2 * L_ + 1, S1 = L_ + NX;
   constexpr int N = N_, q = Q_;
   static_assert(step_v2_dims(L_, N_, Q_), "step_v2: dimension set");
+  static_assert(N_ <= 32 && L_ + 2 <= 32, "step_v2: one variable / one state row per lane of a 32-lane half");
   const int tid = local_tid<64>();
   const int half = tid >> 5, t = tid & 31;
   const int B = a.B;

@@ -519,3 +519,111 @@ class KoopmanMPC:
 
     def algorithmic_bytes_per_step(self):
         return int(self.lib.kmpc_algorithmic_bytes_per_step(self.h))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The reference's own names at module level: net.Encoder(x), rbf(X, cx), costFunction(uSequence, r, AB, C, x0, ...),
+# Koopman_update, mpc_solve, mpc_step.  Thin: each one is a call of a (cached) KoopmanMPC handle, i.e. of the HIP kernels.
+# ----------------------------------------------------------------------------------------------------------------------
+_handles = {}
+
+
+def _handle(key, make):
+    h = _handles.get(key)
+    if h is None:
+        h = _handles[key] = make()
+    return h
+
+
+class AutoEncoder:
+    """`net = AutoEncoder(...)`; `net.Encoder(x)` (duffing.py:17-29, 847): the encoder half only (the decoder is not on the path).
+    weights = [(W1, b1), ..., (Wd+1, bd+1)] with W (out x in), as `scipy.io.loadmat` of the reference's weight files gives them
+    (koopmpc.io.load_encoder_mat).  Encoder(x): (n,) | (n, 1) | (n, B) -> (L,) | (L, 1) | (L, B), on the device (kmpc_lift)."""
+
+    def __init__(self, weights, device=None, lift_offset=None):
+        self.weights = [(np.asarray(W, dtype=np.float64), np.asarray(b, dtype=np.float64).reshape(-1)) for W, b in weights]
+        n, L = self.weights[0][0].shape[1], self.weights[-1][0].shape[0]
+        if lift_offset == "x_psi0":
+            L += n
+        self._mpc = KoopmanMPC(n=n, L=L, N=2, batch=1, weights=self.weights, hidden=self.weights[0][0].shape[0],
+                               layers=len(self.weights) - 1, device=device, lift_offset=lift_offset)
+
+    def Encoder(self, x):
+        return self._mpc.Encoder(x)
+
+    __call__ = Encoder
+
+
+def rbf(X, cx, eps=1e-4, form="python", device=None):
+    """rbf(X, cx) of vanderpol_RBF.py:20-23 / duffing_RBF.py:20-23 (form="matlab": rbf.m:24-29): psi_j = d_j^2 log(d_j + eps).
+    X (n,) | (n, 1) | (n, B), cx (L, n) -> (L, 1) for a single state like the reference, else (L, B)."""
+    cx = np.ascontiguousarray(cx, dtype=np.float64)
+    L, n = cx.shape
+    m = _handle(("rbf", L, n, form, float(eps), str(device)),
+                lambda: KoopmanMPC(n=n, L=L, N=2, batch=1, lift="rbf" if form == "python" else "rbf_matlab", centres=cx, rbf_eps=eps, device=device))
+    return m.rbf(X, cx)
+
+
+def costFunction(uSequence, r, AB, C, x0, pastu=None, Np=None, Nc=None, d=None, ek=None, Qw=100.0, Rw=1e-4, device=None):
+    """costFunction(uSequence, r, AB, C, x0, pastu, Np, Nc, d, ek) of duffing.py:540-581 / vanderpol.py:445-487 for caller-supplied
+    input sequences, evaluated on the device: J(u) = Qw sum_k |C x_k - r_{:,k-1}|^2 + Rw sum u^2, x_k = AB [x_{k-1}; u_{k-1}]
+    (the condensed form u'Hu + f'u + c of kmpc_condense_cost, which equals the reference's value to 1e-12).
+    uSequence (N,) or (N, S) for S sequences at once; r (q, N); AB (L, L+1); C (q, L) or None for y = the lifted state
+    (vanderpol.py:456-459); x0 (L,) | (L, 1).  pastu, ek and d are dead in the reference (:576-580; d is zeros, :776) -- accepted and
+    ignored, a non-zero d is refused; Np must equal Nc (= N, the reference's setting).  Returns a float (one sequence) or (S,)."""
+    U = np.asarray(uSequence.detach().cpu() if torch.is_tensor(uSequence) else uSequence, dtype=np.float64)
+    single = U.ndim == 1
+    U = U.reshape(U.shape[0], -1)
+    N, S = U.shape
+    if (Np is not None and Np != N) or (Nc is not None and Nc != N):
+        raise ValueError("costFunction: Np = Nc = len(uSequence) is the only setting the reference uses (duffing.py:632-633)")
+    if d is not None and np.any(np.asarray(d) != 0.0):
+        raise ValueError("costFunction: the offset d is zeros in the reference (duffing.py:776); a non-zero d is not supported")
+    AB = np.asarray(AB, dtype=np.float64)
+    L = AB.shape[0]
+    out = "lift" if C is None else "Cx"
+    q = L if C is None else np.asarray(C).shape[0]
+    m = _handle(("cost", L, N, S, out, q, float(Qw), float(Rw), str(device)),
+                lambda: KoopmanMPC(n=q if C is not None else 2, L=L, N=N, batch=S, lift="rbf", centres=np.zeros((L, q if C is not None else 2)),
+                                   output=out, Qw=Qw, Rw=Rw, device=device))
+    m.set_model(AB[:, :L], AB[:, L], np.asarray(C, dtype=np.float64) if C is not None else None)
+    psi = np.tile(np.asarray(x0, dtype=np.float64).reshape(L, 1), (1, S))
+    H, f, c = m.condense(psi, np.asarray(r, dtype=np.float64).reshape(q, N), return_const=True)
+    Ud = torch.as_tensor(U.T.copy(), device=m.device)  # (S, N)
+    J = torch.einsum("si,sij,sj->s", Ud, H, Ud) + (f * Ud).sum(1) + c
+    return float(J[0]) if single else J.cpu().numpy()
+
+
+def Koopman_update(state, xlift, u, ylift, x_next, lam=None):
+    """The "Update LTV-Model" block (duffing.py:900-967; Koopman_update.m:258-278) on `state`, a KoopmanMPC handle that owns the
+    accumulators (K_A inv_K_G, bar_X bar_Q) of its trajectories: returns (A, B, C).  lam must be the handle's (it is a launch constant)."""
+    if lam is not None and abs(float(lam) - float(state.cfg.lam)) > 0:
+        raise ValueError("Koopman_update: lam is fixed when the handle is created (KoopmanMPC(lam=...))")
+    return state.Koopman_update(xlift, u, ylift, x_next)
+
+
+koopman_update = Koopman_update  # (SURVEY 8b spells it in lower case)
+
+
+def mpc_solve(A, B, C, xlift, r, lb=-2.0, ub=2.0, Q=100.0, R=1e-4, P_N=None, device=None):
+    """optimize.minimize(lamdaCostFunction(AB, C, x0, r), zeros(N), bounds=...) of duffing.py:857-861 with the model as an argument
+    (SURVEY 8b): exact minimiser instead of L-BFGS-B.  A (L, L), B (L,) | (L, 1), C (q, L) | None, xlift (L,) | (L, B), r (q, N).
+    Returns (U (N, B), u0 (B,), status (B,)) as NumPy arrays."""
+    A = np.asarray(A, dtype=np.float64)
+    L = A.shape[0]
+    xl = np.asarray(xlift.detach().cpu() if torch.is_tensor(xlift) else xlift, dtype=np.float64).reshape(L, -1)
+    Bn = xl.shape[1]
+    rr = np.asarray(r, dtype=np.float64)
+    q, N = rr.shape
+    out = "lift" if C is None else "Cx"
+    m = _handle(("solve", L, N, Bn, out, q, str(device)),
+                lambda: KoopmanMPC(n=q if C is not None else 2, L=L, N=N, batch=Bn, lift="rbf", centres=np.zeros((L, q if C is not None else 2)),
+                                   output=out, device=device))
+    U, u0, st, fun = m.mpc_solve(A, B, C, xl, rr, lb, ub, Q, R, P_N)
+    return U.cpu().numpy(), u0.cpu().numpy(), st.cpu().numpy()
+
+
+def mpc_step(state, x, r):
+    """One iteration of the reference loop (duffing.py:847-984) on the handle `state`: lift, RLS update with the previous transition,
+    condensed QP, box QP -> u_k (B,)."""
+    return state.step(x, r)
