@@ -237,7 +237,7 @@ def _probe_worker(path):
     print(json.dumps({"max_abs_u_err": worst, "n": int(X.shape[1])}))
 
 
-def parity_probe(loop, name, L, N, step_next, nprobe=8):
+def parity_probe(loop, name, L, N, step_next, nprobe=8, check=True):
     """One more closed-loop step of the timed controller (untimed), `nprobe` of its trajectories checked against the oracle in a child
     process: max |u_gpu - u_oracle| (duffing.py:857-861: the input the loop applies).  The models are the ones the device solved with
     (exported after the step), so the figure covers lift, condensed build and box QP of the timed state."""
@@ -257,6 +257,8 @@ def parity_probe(loop, name, L, N, step_next, nprobe=8):
         Ul, _ = loop.m.rollout(loop.c["plant"], loop.X, loop.r, 1, step0=step_next, log=True)
         u = Ul[0, idx].cpu().numpy()
         A, Bm, Cm = [t[idx].cpu().numpy() for t in loop.m.get_model()]
+    if not check:  # (the other ranks of a multi-rank run only take part in the step: cfg4's step holds a collective)
+        return None
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "probe.npz")
         np.savez(path, name=name, L=L, N=N, X=Xpre, A=A, B=Bm, C=Cm, u=u, uprev=uprev)
@@ -335,10 +337,26 @@ class Loop:
         self.X = torch.tensor(initial_states_for(name, B, 101 + rank), dtype=dtype, device=dev).contiguous()
         self.r = torch.tensor(w["ref"], dtype=dtype, device=dev)
         self.shared = bool(c.get("shared"))
+        # shared model: the native loop (kmpc_shared_rollout: every stage and the RCCL all-reduce enqueued from C++) unless the
+        # ranks rehearse on gloo (host-side sums) or KMPC_BENCH_PY_SHARED_LOOP asks for the Python loop of the stages
+        self.comm, self.native = None, False
+        if self.shared and os.environ.get("KMPC_BENCH_PY_SHARED_LOOP") is None:
+            import torch.distributed as dist
+            from koopmpc.sharding import NcclCommunicator, force_collectives
+
+            pg = dist.is_available() and dist.is_initialized()
+            if not pg or (dist.get_world_size() == 1 and not force_collectives()):
+                self.native = True
+            elif dist.get_backend() != "gloo":
+                self.comm = NcclCommunicator(dev)
+                self.native = True
 
     def advance(self, steps, step0):
         if not self.shared:
             self.m.rollout(self.c["plant"], self.X, self.r, steps, step0=step0)
+            return
+        if self.native:
+            self.m.shared_rollout("tank", self.X, self.r, steps, step0=step0, switch_step=101, comm=self.comm)
             return
         sep = os.environ.get("KMPC_BENCH_SEPARATE_PLANT") is not None  # (measurement aid: the plant as a launch of its own)
         for k in range(step0, step0 + steps):  # shared model: local Gram sums -> all-reduce -> model, QPs with the plant inside
@@ -447,7 +465,7 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
     main_loop.m.profile(False)
     mpc = main_loop.m
     worst_status = int(mpc.status.max().item())
-    newton_per_step = float(mpc.iters.double().mean().item()) / (max(1, args.steps) if not main_loop.shared else 1)
+    newton_per_step = float(mpc.iters.double().mean().item()) / (max(1, args.steps) if (not main_loop.shared or main_loop.native) else 1)
     newton_max = int(mpc.iters.max().item())
     x_ok = bool(torch.isfinite(main_loop.X).all().item())
     fused = bool(mpc.rollout_is_fused()) and not main_loop.shared
@@ -505,7 +523,7 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
         dtp = timed(fresh, args.steps, args.warmup)
         ex["post_reset"] = {"value": B * world * args.steps / dtp, "ms_per_step": dtp / args.steps * 1e3,
                             "frac": bytes_per_traj * B * args.steps / dtp / 1e9 / HBM_PEAK_GBS,
-                            "newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if not fresh.shared else 1),
+                            "newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if (not fresh.shared or fresh.native) else 1),
                             "note": "the same %d steps after %d warm-up steps counted from the RLS reset (no settle steps)" % (args.steps, args.warmup)}
         del fresh
 
@@ -522,8 +540,7 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
         tj = json.load(open(tp)).get("%s:%s:%s" % (name, args.dtype, "fused" if fused else "steps"))
         if tj and (tj["L"], tj["N"]) == (L, N):
             traffic = tj["bytes_per_trajectory_step"] * B * steps_per_launch
-            traffic_src = "%.0f B per trajectory-step x trajectories x steps per launch (PMC passes at B = %d, %s)" % (
-                tj["bytes_per_trajectory_step"], tj["B"], tj["source"])
+            traffic_src = "%.0f B per trajectory-step (PMC passes at B = %d, profiles/traffic.json)" % (tj["bytes_per_trajectory_step"], tj["B"])
 
     if main_loop.shared:
         kname = "whole shared-model step (all launches of a step and the gaps between them; per-kernel times: profiles/)"
@@ -567,12 +584,13 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
         roof["post_reset_frac"] = ex["post_reset"]["frac"]
         roof["post_reset_value"] = ex["post_reset"]["value"]
     pp = None
-    if probe and rank == 0:
+    if probe:
         try:
-            pp = parity_probe(main_loop, name, L, N, step0 + args.steps)
+            pp = parity_probe(main_loop, name, L, N, step0 + args.steps, check=(rank == 0))
         except Exception as e:  # (the probe must not take the measurement with it; it is reported)
             pp = {"error": "%s: %s" % (type(e).__name__, e)}
-        roof["parity_probe_max_abs_u_err"] = pp.get("max_abs_u_err")
+        if rank == 0:
+            roof["parity_probe_max_abs_u_err"] = pp.get("max_abs_u_err")
     return {"dt": dt, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "roofline": roof, "extras": ex,
             "worst_status": worst_status, "x_ok": x_ok, "newton_per_step": newton_per_step, "newton_max": newton_max,
             "shared": main_loop.shared, "q": mpc.q, "text": c["text"], "parity_probe": pp}

@@ -212,6 +212,18 @@ int kmpc_shared_solve(kmpc_handle* h, const double* delta_gram_dev, const void* 
 int kmpc_shared_solve_plant(kmpc_handle* h, const double* delta_gram_dev, const void* ref_dev, void* U0_dev, void* Useq_dev,
                             int32_t* status_dev, int32_t* iters_dev, int plant, void* X_dev, int switched, double hstep,
                             void* stream);
+/* The shared-model loop itself (Tank_System.m:170-291 with one model for every trajectory of every rank; the loop bench.py
+ * times for BASELINE cfg4), `steps` iterations enqueued from C++ on ONE stream with the collective inside:
+ *   lift + local Gram sums (one launch) -> ncclAllReduce(sum, float64) of the (2L + n + 1)(L + 1)-element block over
+ *   nccl_comm (RCCL; resolved at run time as in kmpc_allreduce_gram; NULL: single rank, no collective) -> model, condensed QP,
+ *   T0 -> interior trajectories on the matrix cores / box QPs, plant inside (X_dev <- f(X_dev, u_k), parameters switched from
+ *   global iteration switch_step on, -1: never).
+ * No host round trip and no Python between the stages.  U_log_dev (steps x B) / X_log_dev (steps x n x B) optional;
+ * status_dev / iters_dev receive every trajectory's worst QP status and total Newton solves; U0_dev (B, optional) the last
+ * step's inputs, Useq_dev (N x B, optional) its sequences.  Same results as the loop of kmpc_shared_local_gram -> [all-reduce] -> kmpc_shared_solve_plant.      */
+int kmpc_shared_rollout(kmpc_handle* h, int plant, void* X_dev, const void* ref_dev, int steps, int step0, int switch_step, double hstep,
+                        void* nccl_comm, void* U_log_dev, void* X_log_dev, void* U0_dev, void* Useq_dev, int32_t* status_dev,
+                        int32_t* iters_dev, void* stream);
 /* the shared model: A_dev (L x L), B_dev (L), C_dev (n x L) in the handle dtype                           */
 int kmpc_shared_get_model(kmpc_handle* h, void* A_dev, void* B_dev, void* C_dev, void* stream);
 

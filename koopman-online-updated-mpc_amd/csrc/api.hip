@@ -58,6 +58,8 @@ struct kmpc_handle {
   virtual int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
                            hipStream_t s) = 0;
   virtual int shared_get_model(void* A, void* B, void* C, hipStream_t s) = 0;
+  virtual int shared_rollout(int plant, void* X, const void* ref, int steps, int step0, int switch_step, double hstep, void* comm,
+                             void* Ulog, void* Xlog, void* U0out, void* Useq, int32_t* st, int32_t* it, hipStream_t s) = 0;
   virtual int64_t state_bytes() const = 0;
   virtual int state_export(void* blob, int64_t bytes) = 0;
   virtual int state_import(const void* blob, int64_t bytes) = 0;
@@ -65,6 +67,21 @@ struct kmpc_handle {
   virtual int profile_read(double* ms2, int64_t* count, int reset) = 0;
   virtual int64_t algorithmic_bytes() const = 0;
 };
+
+// ncclAllReduce of the RCCL that lives in this process (under PyTorch: torch's own copy), else of the system library; null: none.
+// The library itself does not link against RCCL.
+static void* resolve_nccl_allreduce() {
+  static void* fn = nullptr;
+  if (!fn) {
+    fn = dlsym(RTLD_DEFAULT, "ncclAllReduce");
+    if (!fn) {
+      void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (lib) fn = dlsym(lib, "ncclAllReduce");
+    }
+  }
+  return fn;
+}
 
 #define HIPCHK(expr)                                                                  \
   do {                                                                                \
@@ -220,7 +237,7 @@ struct Impl : kmpc_handle {
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
                       (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
-                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet})
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet, (void*)dDelta, (void*)dQpList})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -882,6 +899,8 @@ struct Impl : kmpc_handle {
   double *dGram = nullptr, *dPartial = nullptr;
   T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr, *dTs = nullptr;
   int32_t* dNeed = nullptr;  // [B] flags of shared_fast_kernel
+  int32_t* dQpList = nullptr;  // two alternating counters, then the list of the trajectories shared_fast_kernel left to the solve-only kernel
+  int qp_list_parity = 0;
   T* dWt = nullptr;  // PN - Qw I (terminal block of Q_bar)
   std::vector<double> hostPN;  // P_N as given to kmpc_set_terminal_weight
   bool have_wterm = false;
@@ -890,7 +909,7 @@ struct Impl : kmpc_handle {
   int dare_cap = 0;
   bool wterm_from_dare = false, wterm_per_traj = false;
   bool shared_has_samples = false;
-  static constexpr int GRAM_BLOCKS = 256;
+  static constexpr int GRAM_BLOCKS = 256;  // partial blocks of the Gram kernels (512 measured slower: lift + Gram 21.8 vs 17.2 us, reduce 7.6 vs 4.8 us)
   int64_t gram_elems() const override { return (int64_t)(p + L + n) * p; }
   int shared_alloc() {
     if (dGram) return 0;
@@ -916,17 +935,37 @@ struct Impl : kmpc_handle {
     if (rc) return rc;
     T* psi_now = dPsi[cur];
     T* psi_prev = dPsi[cur ^ 1];
+    GramArgs<T> g{};
+    g.B = B; g.n = n; g.L = L; g.max_blocks = GRAM_BLOCKS;
+    g.psi_prev = psi_prev; g.pp_sl = 1; g.pp_sb = L;
+    g.psi_now = psi_now; g.pn_sl = 1; g.pn_sb = L;
+    g.u_prev = dUprev; g.x_now = (const T*)X; g.partial = dPartial;
+    if constexpr (sizeof(T) == 8) {
+      // float64 MLP lift: the lift and the Gram sums of the transitions in ONE launch (lift_coop_kernel<.., GRAM>), then the reduce
+      const bool two = getenv("KMPC_SHARED_LIFT_GRAM_2") != nullptr;  // measurement / test aid (read per call): the two round-3 launches
+      if (have_prev && !two && cfg.lift_kind == KMPC_LIFT_MLP) {
+        if ((rc = check_lift_ready())) return rc;
+        LiftArgs<T> a{};
+        a.B = B; a.n = n; a.L = L; a.hidden = hid; a.nlayers = cfg.layers;
+        a.X = (const T*)X; a.Psi = psi_now; a.ps_l = 1; a.ps_b = L;
+        a.W1 = dW1; a.b1 = db1; a.Wh[0] = dWh[0]; a.Wh[1] = dWh[1]; a.bh[0] = dbh[0]; a.bh[1] = dbh[1];
+        a.Wo = dWo; a.bo = dbo; a.Hp = Hp; a.Lp = Lp;
+        if ((rc = pack_encoder(s))) return rc;
+        a.Whp[0] = dWhp[0]; a.Whp[1] = dWhp[1] ? dWhp[1] : dWhp[0]; a.Wop = dWop; a.KSp = (hid + 3) / 4;
+        if (lift_gram_available(a)) {
+          int nb = 0;
+          HIPCHK(launch_lift_gram(a, g, &nb, s));
+          HIPCHK(launch_gram_reduce(dPartial, nb, L, n, 0.0, delta, s));  // (forget = 0 overwrites delta)
+          return 0;
+        }
+      }
+    }
     rc = lift_to((const T*)X, psi_now, 1, L, B, s);
     if (rc) return rc;
     if (!have_prev) {
       HIPCHK(hipMemsetAsync(delta, 0, sizeof(double) * (size_t)gram_elems(), s));
       return 0;
     }
-    GramArgs<T> g{};
-    g.B = B; g.n = n; g.L = L; g.max_blocks = GRAM_BLOCKS;
-    g.psi_prev = psi_prev; g.pp_sl = 1; g.pp_sb = L;
-    g.psi_now = psi_now; g.pn_sl = 1; g.pn_sb = L;
-    g.u_prev = dUprev; g.x_now = (const T*)X; g.partial = dPartial;
     HIPCHK(launch_gram<T>(g, 0.0, delta, s));  // (forget = 0 overwrites delta)
     return 0;
   }
@@ -939,6 +978,43 @@ struct Impl : kmpc_handle {
     const int rc = shared_solve(delta, ref, U0, Useq, st, it, s);
     fuse_plant = -1; fuse_X = nullptr;
     return rc;
+  }
+  // kmpc_shared_rollout: the stages of the shared-model step, `steps` times, on one stream, the collective between them
+  double* dDelta = nullptr;  // this rank's Gram sums of a step (all-reduced in place)
+  int shared_rollout(int plant, void* X, const void* ref, int steps, int step0, int switch_step, double hstep, void* comm, void* Ulog,
+                     void* Xlog, void* U0out, void* Useq, int32_t* st, int32_t* it, hipStream_t s) override {
+    if (!X || !ref || steps < 0) FAIL(-3, "kmpc_shared_rollout: bad arguments");
+    if (n != 2) FAIL(-3, "plants are two-state systems");
+    if (!plant_id_ok(plant)) FAIL(-3, "unknown plant");
+    int rc = shared_alloc();
+    if (rc) return rc;
+    if (!dDelta) HIPCHK(hipMalloc(&dDelta, sizeof(double) * (size_t)gram_elems()));
+    if (!dU0) HIPCHK(hipMalloc(&dU0, sizeof(T) * (size_t)B));
+    typedef ncclResult_t (*allreduce_fn)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
+    allreduce_fn ar = nullptr;
+    if (comm) {
+      ar = (allreduce_fn)resolve_nccl_allreduce();
+      if (!ar) FAIL(-4, "kmpc_shared_rollout: no RCCL in this process (ncclAllReduce not found)");
+    }
+    if (st) HIPCHK(hipMemsetAsync(st, 0, sizeof(int32_t) * (size_t)B, s));
+    if (it) HIPCHK(hipMemsetAsync(it, 0, sizeof(int32_t) * (size_t)B, s));
+    for (int i = 0; i < steps; ++i) {
+      const int gi = step0 + i;
+      if ((rc = shared_local_gram(X, dDelta, s))) return rc;
+      if (ar && have_prev) {  // (before the first transition every rank's block is zero: nothing to sum)
+        const ncclResult_t nr = ar(dDelta, dDelta, (size_t)gram_elems(), ncclDouble, ncclSum, (ncclComm_t)comm, s);
+        if (nr != ncclSuccess) FAIL(-(2000 + (int)nr), "kmpc_shared_rollout: ncclAllReduce failed");
+      }
+      T* const u = Ulog ? (T*)Ulog + (size_t)i * B : (U0out ? (T*)U0out : dU0);
+      accumulate = true;
+      rc = shared_solve_plant(dDelta, ref, u, Useq, st, it, plant, X, (switch_step >= 0 && gi >= switch_step) ? 1 : 0, hstep, s);
+      accumulate = false;
+      if (rc) return rc;
+      if (Xlog) HIPCHK(hipMemcpyAsync((T*)Xlog + (size_t)i * n * B, X, sizeof(T) * (size_t)n * B, hipMemcpyDeviceToDevice, s));
+    }
+    if (Ulog && U0out && steps > 0)
+      HIPCHK(hipMemcpyAsync(U0out, (T*)Ulog + (size_t)(steps - 1) * B, sizeof(T) * (size_t)B, hipMemcpyDeviceToDevice, s));
+    return 0;
   }
   int shared_solve(const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
                    hipStream_t s) override {
@@ -956,8 +1032,24 @@ struct Impl : kmpc_handle {
     if (one_launch) {
       // model solve + condensed QP + the tableau the box QPs start from, one launch (shared_model_kernel)
       if (!dTs) HIPCHK(hipMalloc(&dTs, sizeof(T) * (size_t)N * N));
-      HIPCHK(launch_shared_model<T>(dGram, have_prev ? delta : nullptr, cfg.lambda, (const T*)ref, L, n, q, N, 1.0 / cfg.P0, 1.0 / cfg.barQ0, 1, have_prev ? 1 : 0, cfg.Qw,
-                                    cfg.Rw, dKs, dCs, dHs, dFs, df0s, dTs, wt, cfg.delta_u ? 1 : 0, cy0, s));
+      const bool old_kernel = getenv("KMPC_SHARED_MODEL_R3") != nullptr;  // measurement / test aid (read per call): the round-3 model kernel
+      bool on16 = false;
+      if constexpr (sizeof(T) == 8) {
+        if (!old_kernel && shared_model2_available(L, n, q, N, cfg.delta_u ? 1 : 0)) {
+          SharedModel2Args m{};
+          m.gram = dGram; m.delta = have_prev ? delta : nullptr; m.forget = cfg.lambda; m.ref = (const double*)ref;
+          m.Lm = L; m.n = n; m.q = q; m.N = N; m.dP = 1.0 / cfg.P0; m.dQ = 1.0 / cfg.barQ0; m.have_samples = have_prev ? 1 : 0;
+          m.Qw = cfg.Qw; m.Rw = cfg.Rw;
+          m.Kio = (double*)dKs; m.Cio = (double*)dCs; m.Hout = (double*)dHs; m.Fout = (double*)dFs; m.f0out = (double*)df0s; m.Tout = (double*)dTs;
+          m.Wt = (const double*)wt; m.du_mode = cfg.delta_u ? 1 : 0; m.cy0 = cy0;
+          HIPCHK(launch_shared_model2(m, s));
+          on16 = true;
+        }
+      }
+      if (!on16) {
+        HIPCHK(launch_shared_model<T>(dGram, have_prev ? delta : nullptr, cfg.lambda, (const T*)ref, L, n, q, N, 1.0 / cfg.P0, 1.0 / cfg.barQ0, 1, have_prev ? 1 : 0, cfg.Qw,
+                                      cfg.Rw, dKs, dCs, dHs, dFs, df0s, dTs, wt, cfg.delta_u ? 1 : 0, cy0, s));
+      }
       if (have_prev) shared_has_samples = true;
     } else {
       if (have_prev) {
@@ -975,6 +1067,7 @@ struct Impl : kmpc_handle {
     a.psi_now = dPsi[cur]; a.pn_sl = 1; a.pn_sb = L;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
     a.x_warm = cfg.cold_start ? nullptr : dWarm;
+    a.accumulate = accumulate ? 1 : 0;  // (kmpc_shared_rollout: worst status / total Newton solves over the steps)
     // (kmpc_shared_solve_plant: the solve also advances every trajectory's plant with its u_k, as the roll-outs do)
     if (fuse_plant >= 0) { a.plant = fuse_plant; a.plant_switched = fuse_switched; a.plant_h = (T)fuse_h; a.X_rw = (T*)fuse_X; }
     const bool rec = prof && ev_used + 3 <= EV_CAP;  // (profiling: the QP launch of the shared-model step)
@@ -992,6 +1085,17 @@ struct Impl : kmpc_handle {
     const bool no_fast = getenv("KMPC_SHARED_NO_FAST") != nullptr;  // measurement / test aid (read per call): every trajectory through the QP kernel
     if (one_launch && sizeof(T) == 8 && N <= 64 && !no_fast) {
       if (!dNeed) HIPCHK(hipMalloc(&dNeed, sizeof(int32_t) * (size_t)B));
+      // (the flagged trajectories also go into a list that a fixed grid of the solve-only kernel walks; two counters alternate)
+      if (!dQpList) {
+        HIPCHK(hipMalloc(&dQpList, sizeof(int32_t) * (size_t)(B + 2)));
+        HIPCHK(hipMemsetAsync(dQpList, 0, sizeof(int32_t) * (size_t)(B + 2), s));
+      }
+      if (!getenv("KMPC_SHARED_NO_LIST")) {  // (measurement / test aid, read per call: one workgroup per trajectory, flags only)
+        a.qp_list = dQpList + 2;
+        a.qp_count = dQpList + qp_list_parity;
+        a.qp_count_next = dQpList + (qp_list_parity ^ 1);
+        qp_list_parity ^= 1;
+      }
       HIPCHK(launch_shared_fast<T>(a, dNeed, s));
       a.qp_need = dNeed;
     }
@@ -1309,16 +1413,8 @@ int kmpc_allreduce_gram(kmpc_handle* h, double* delta, void* nccl_comm, void* s)
   NN(h);
   if (!delta || !nccl_comm) return -3;
   typedef ncclResult_t (*allreduce_fn)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
-  static allreduce_fn fn = nullptr;
-  if (!fn) {
-    fn = (allreduce_fn)dlsym(RTLD_DEFAULT, "ncclAllReduce");
-    if (!fn) {
-      void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
-      if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
-      if (lib) fn = (allreduce_fn)dlsym(lib, "ncclAllReduce");
-    }
-    if (!fn) return -4;  // no RCCL in this process
-  }
+  const allreduce_fn fn = (allreduce_fn)resolve_nccl_allreduce();
+  if (!fn) return -4;  // no RCCL in this process
   const ncclResult_t rc = fn(delta, delta, (size_t)h->gram_elems(), ncclDouble, ncclSum, (ncclComm_t)nccl_comm, (hipStream_t)s);
   return rc == ncclSuccess ? 0 : -(2000 + (int)rc);
 }
@@ -1331,6 +1427,11 @@ int kmpc_shared_solve_plant(kmpc_handle* h, const double* delta, const void* ref
   return h->shared_solve_plant(delta, ref, U0, Useq, st, it, plant, X, switched, hstep, (hipStream_t)s);
 }
 int kmpc_shared_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->shared_get_model(A, B, C, (hipStream_t)s); }
+int kmpc_shared_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int steps, int step0, int switch_step, double hstep, void* comm,
+                        void* Ulog, void* Xlog, void* U0out, void* Useq, int32_t* st, int32_t* it, void* s) {
+  NN(h);
+  return h->shared_rollout(plant, X, ref, steps, step0, switch_step, hstep, comm, Ulog, Xlog, U0out, Useq, st, it, (hipStream_t)s);
+}
 int64_t kmpc_state_bytes(const kmpc_handle* h) { return h ? h->state_bytes() : -1; }
 int kmpc_state_export(kmpc_handle* h, void* blob, int64_t bytes) { NN(h); return h->state_export(blob, bytes); }
 int kmpc_state_import(kmpc_handle* h, const void* blob, int64_t bytes) { NN(h); return h->state_import(blob, bytes); }

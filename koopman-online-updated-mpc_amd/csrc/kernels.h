@@ -49,6 +49,12 @@ struct StepArgs {
   const T* F_in; const T* f0_in; // shared-model mode: f_b = F psi_b + f0 (F: N x L), psi from psi_now
   const int32_t* qp_need;        // shared-model mode: [B] flags written by shared_fast_kernel -- 0: that kernel has already written this
                                  // trajectory's result (its unconstrained minimiser lies inside the box), the solve-only kernel skips it
+  // ... and the flagged trajectories as a list (round 4): shared_fast_kernel appends them to qp_list with one atomic per trajectory
+  // (*qp_count); the solve-only kernel is then launched with a FIXED small grid whose workgroups walk the list -- 8192 workgroups
+  // that read one flag and exit were 18.7 us of the step.  Two counters alternate from step to step: shared_fast_kernel zeroes the
+  // next step's (*qp_count_next) while it fills this step's, so that no launch is spent on it.  The order of the list is whatever
+  // the atomics make it; every trajectory's solve is independent of it.  Kernels without a list mode ignore it (qp_need still holds).
+  int32_t* qp_list; int32_t* qp_count; int32_t* qp_count_next;
   // QP
   T* Useq;           // (N x B) or null
   T* U0;             // [B] or null
@@ -162,6 +168,10 @@ hipError_t launch_state_to_image(const double* P, long sP, const double* K, long
 hipError_t launch_image_to_state(const double* img, long stride, int n, int L, int B, double* P, long sP, double* K, long sK,
                                  double* Q, long sQ, double* C, long sC, hipStream_t s);
 template <typename T> hipError_t launch_pack_afrag(const T* src, int Mp, int Hp, int KS, T* dst, hipStream_t s);
+// lift + Gram sums of the transitions in ONE launch (float64, cooperative MLP encoder; round 4), then the fixed-order sum of the partials
+bool lift_gram_available(const LiftArgs<double>& a);
+hipError_t launch_lift_gram(const LiftArgs<double>& a, const GramArgs<double>& g, int* nblocks, hipStream_t s);
+hipError_t launch_gram_reduce(const double* partial, int nblocks, int L, int n, double forget, double* gram, hipStream_t s);
 template <typename T> hipError_t launch_lift_mlp(const LiftArgs<T>& a, hipStream_t s);
 template <typename T> hipError_t launch_lift_rbf(const LiftArgs<T>& a, hipStream_t s);
 template <typename T> hipError_t launch_plant(const PlantArgs<T>& a, hipStream_t s);
@@ -188,6 +198,16 @@ hipError_t launch_shared_model(double* gram, const double* delta, double forget,
 template <typename T>
 hipError_t launch_shared_fast(const StepArgs<T>& a, int32_t* need, hipStream_t s);
 bool shared_model_available(int Lm, int n, int q, int N, int du_mode);
+// shared_model2_kernel (round 4): shared_model_kernel on sixteen waves (float64, q <= 2, N >= 12, L~ <= 33)
+struct SharedModel2Args {
+  double* gram; const double* delta; double forget; const double* ref;
+  int Lm, n, q, N;
+  double dP, dQ; int have_samples; double Qw, Rw;
+  double *Kio, *Cio, *Hout, *Fout, *f0out, *Tout;
+  const double* Wt; int du_mode, cy0;
+};
+bool shared_model2_available(int Lm, int n, int q, int N, int du_mode);
+hipError_t launch_shared_model2(const SharedModel2Args& a, hipStream_t s);
 template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s);
 // [A B] and C given as dense per-trajectory blocks (A [B][L][L], Bv [B][L], C [B][n][L]; stride 0 = one model for all)
 // into the step kernel's state layout K [B][L(L+1)], Cs [B][nL]

@@ -186,24 +186,49 @@ __device__ __forceinline__ void lc_load_afrags(const double* Wp, int KS, int til
     af[i] = ks < KS ? Wp[((size_t)tile * KS + ks) * 64 + lane] : 0.0;
   }
 }
-template <int KS_>
-__global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> a) {
+// GRAM (round 4): the Gram sums of the step's transitions (gram_kernel: rows [psi_prev; u_prev; psi_now; x_now] against [psi_prev;
+// u_prev], Koopman_update.m:94-98) in the same launch -- the sixteen trajectories a workgroup has just lifted are four k-steps of the
+// Gram tiles, wave t keeps output tile t in its accumulator across the workgroup's trajectory tiles and writes it as the workgroup's
+// partial when the kernel ends (summed in a fixed order by gram_reduce_kernel, as before).  One launch and one round trip of psi through
+// memory less per shared-model step (lift 12.2 + Gram 10.4 us -> one kernel).
+constexpr int LC_GLD = 17;  // leading dimension of the Gram panel [rows][16 trajectories]
+template <int KS_, bool GRAM>
+__global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> a, const GramArgs<double> g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* const sAct0 = reinterpret_cast<double*>(smem_raw);
   double* const sAct1 = sAct0 + LC_ACT;
   double* const sXn = sAct1 + LC_ACT;  // 16 x 4
+  double* const sR = sXn + 64;         // GRAM: [Rp][LC_GLD] panel of the sixteen transitions
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = a.B, n = a.n, L = a.L;
   const int KS = KS_ > 0 ? KS_ : a.KSp, Hp = a.Hp, MTH = Hp >> 4, MTO = a.Lp >> 4;
   const int nhh = a.nlayers - 1;
   const bool hid = wv < MTH, out = wv < MTO;
+  // GRAM: p = L + 1 regressor rows, R = p + L + n rows in all; tile wv = (mt, nt) of the (R x p) block
+  const int gp = L + 1, gR = gp + L + n, gMT = (gR + 15) >> 4, gNT = (gp + 15) >> 4;
+  const int gmt = wv / gNT, gnt = wv - gmt * gNT;
+  const bool gmine = GRAM && wv < gMT * gNT;
+  d4 gacc = {0.0, 0.0, 0.0, 0.0};
   for (int bt = blockIdx.x; bt * 16 < B; bt += gridDim.x) {
     const int b0 = bt * 16;
     __syncthreads();  // (the previous tile's activations have been consumed)
     if (tid < 64) {
       const int c = tid >> 2, i = tid & 3, b = b0 + c;
       sXn[tid] = (b < B && i < n) ? a.X[(size_t)i * B + b] : 0.0;
+    }
+    if constexpr (GRAM) {
+      // rows 0 .. L-1: psi_prev, row L: u_prev, rows p + L ..: x_now (psi_now is written by the output layer below); zeros beyond B / R
+      for (int e = tid; e < gMT * 16 * 16; e += 1024) {
+        const int r = e >> 4, c = e & 15, b = b0 + c;
+        double v = 0.0;
+        if (b < B) {
+          if (r < L) v = g.psi_prev[(size_t)r * g.pp_sl + (size_t)b * g.pp_sb];
+          else if (r == L) v = g.u_prev[b];
+          else if (r >= gp + L && r < gR) v = a.X[(size_t)(r - gp - L) * B + b];
+        }
+        if (r < gp || r >= gp + L) sR[r * LC_GLD + c] = v;
+      }
     }
     double af[2][LC_KB];
     if (nhh > 0) { if (hid) lc_load_afrags(a.Whp[0], KS, wv, 0, lane, af[0]); }
@@ -252,8 +277,10 @@ __global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> 
         for (int r = 0; r < 4; ++r) {
           const int row = 16 * wv + (lane >> 4) + 4 * r;
           const double v = acc0[r] + acc1[r];
-          if (last) { if (row < L && b0 + col < B) a.Psi[(size_t)row * a.ps_l + (size_t)(b0 + col) * a.ps_b] = v; }
-          else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+          if (last) {
+            if (row < L && b0 + col < B) a.Psi[(size_t)row * a.ps_l + (size_t)(b0 + col) * a.ps_b] = v;
+            if constexpr (GRAM) { if (row < L) sR[(gp + row) * LC_GLD + col] = b0 + col < B ? v : 0.0; }
+          } else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
         }
       }
       if (!last) {  // the next layer's first fragments travel across the barrier
@@ -262,14 +289,51 @@ __global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> 
         __syncthreads();
       }
     }
+    if constexpr (GRAM) {
+      __syncthreads();  // (psi_now of the sixteen trajectories is in the panel)
+      if (gmine) {
+        // out[i][j] += sum_k R[i][k] Z[j][k]: A lane l: R[16 mt + (l & 15)][4 ks + (l >> 4)], B lane l: Z[16 nt + (l & 15)][4 ks + (l >> 4)]
+        const double* const pa = sR + (16 * gmt + (lane & 15)) * LC_GLD + (lane >> 4);
+        const double* const pb = sR + (16 * gnt + (lane & 15)) * LC_GLD + (lane >> 4);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], gacc, 0, 0, 0);
+      }
+    }
+  }
+  if constexpr (GRAM) {
+    if (gmine) {  // this workgroup's partial tile -> [block][Rp][16 NT] (gram_reduce_kernel)
+      double* const outp = g.partial + (size_t)blockIdx.x * (gMT * 16) * (16 * gNT);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) outp[(16 * gmt + (lane >> 4) + 4 * r) * (16 * gNT) + 16 * gnt + (lane & 15)] = gacc[r];
+    }
   }
 }
 static hipError_t launch_lift_coop(const LiftArgs<double>& a, hipStream_t s) {
   const size_t lds = (size_t)(2 * LC_ACT + 64) * sizeof(double);
   const int ntiles = (a.B + 15) / 16;
   const int grid = ntiles < 2048 ? ntiles : 2048;
-  if (a.KSp == 25 && a.Hp == 112) hipLaunchKernelGGL((lift_coop_kernel<25>), dim3(grid), dim3(1024), lds, s, a);
-  else hipLaunchKernelGGL((lift_coop_kernel<0>), dim3(grid), dim3(1024), lds, s, a);
+  const GramArgs<double> g{};
+  if (a.KSp == 25 && a.Hp == 112) hipLaunchKernelGGL((lift_coop_kernel<25, false>), dim3(grid), dim3(1024), lds, s, a, g);
+  else hipLaunchKernelGGL((lift_coop_kernel<0, false>), dim3(grid), dim3(1024), lds, s, a, g);
+  return hipGetLastError();
+}
+// lift + Gram sums of the step's transitions in one launch (float64 MLP lift, the cooperative encoder): g.partial receives one partial
+// block per workgroup ([*nblocks][Rp][Cp]); the caller reduces them (launch_gram_reduce)
+bool lift_gram_available(const LiftArgs<double>& a) {
+  const int p = a.L + 1, R = p + a.L + a.n;
+  return a.n <= 4 && a.Lp <= 64 && a.Hp <= 128 && (a.Hp & 15) == 0 && a.KSp <= 32 && (a.nlayers == 2 || a.nlayers == 3) &&
+         ((R + 15) / 16) * ((p + 15) / 16) <= 16;
+}
+hipError_t launch_lift_gram(const LiftArgs<double>& a, const GramArgs<double>& g, int* nblocks, hipStream_t s) {
+  if (a.B <= 0 || !lift_gram_available(a)) return hipErrorInvalidValue;
+  const int p = a.L + 1, R = p + a.L + a.n, MT = (R + 15) / 16;
+  const size_t lds = (size_t)(2 * LC_ACT + 64 + MT * 16 * LC_GLD) * sizeof(double);
+  const int ntiles = (a.B + 15) / 16;
+  int grid = ntiles < g.max_blocks ? ntiles : g.max_blocks;
+  if (grid < 1) grid = 1;
+  *nblocks = grid;
+  if (a.KSp == 25 && a.Hp == 112) hipLaunchKernelGGL((lift_coop_kernel<25, true>), dim3(grid), dim3(1024), lds, s, a, g);
+  else hipLaunchKernelGGL((lift_coop_kernel<0, true>), dim3(grid), dim3(1024), lds, s, a, g);
   return hipGetLastError();
 }
 

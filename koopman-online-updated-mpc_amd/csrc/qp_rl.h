@@ -167,6 +167,11 @@ struct QpCarry {  // what a solve leaves for the next one (registers of the step
   unsigned smask;   // variables swept into the carried tableau
   int valid;        // 0: no tableau (rebuild), 1: carried
   unsigned umask;   // of the others (held at a bound by that solve): those at the UPPER bound
+  // how the carried tableaux of this trajectory have fared: bits 0-7 consecutive solves whose carried tableau did not contract
+  // (stale), bits 8-15 solves since the last one that was given the full pass budget.  A trajectory whose model still moves a lot
+  // from step to step (2 stale solves in a row) gets 2 refinement passes instead of 6 before the tableau is given up -- it paid 6
+  // passes AND the N sweeps at every step --, and the full budget again every fourth solve (so that it finds its way back)
+  int trust;
 };
 
 // M: on entry lanes t < N of half 0 hold the carried tableau rows (cs.valid) -- loaded by the caller BEFORE H was written into
@@ -207,6 +212,11 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     }
   };
   bool carried = cs.valid != 0;  // the tableau in lanes 0-31 is last step's
+  const int nstale0 = cs.trust & 0xff, probe_age = (cs.trust >> 8) & 0xff;
+  const bool full_budget = nstale0 < 2 || probe_age >= 3;
+  const int kr_max = full_budget ? 6 : 2;
+  bool went_stale = false;
+  const bool carried_at_start = carried;
   unsigned Smask = carried ? cs.smask : 0u;
   if (half || !carried) load_h_rows();  // H rows; without a carried tableau also in lanes 0-31 (T = 2H below)
   if (!carried) {
@@ -245,6 +255,13 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   bool Jok = false;
   int it = 0, status = 1, refresh = 0, polish = 0, rtot = 0, ncrawl = 0, nref = 0;
   bool nopredict = false, rebuild = false;
+#ifdef KMPC_TRACE
+  int tc_sweeps = 0, tc_rebuild = 0, tc_pass = 0, tc_ls = 0, tc_mv = 1;  // (work counters of the trace build: slots 22-27, summed over the launch)
+  const bool tc_carried0 = carried;
+#define KCOUNT(x) (x)
+#else
+#define KCOUNT(x)
+#endif
   KTRACE(8);
 
   while (true) {
@@ -283,6 +300,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
       broke = false;
       for (int pass = 0; pass < 2; ++pass) {
         if (rebuild) {  // T = 2H, nothing swept in
+          KCOUNT(++tc_rebuild);
           if (!half) {
             load_h_rows();
 #pragma unroll
@@ -297,6 +315,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
           // more variables change sides than F has members: sweeping F into a fresh 2H is the shorter way
           // (a saturated solution met from the all-free tableau, or the other way round)
           if (__builtin_popcount(Smask ^ Fmask) > __builtin_popcount(Fmask) + 2) {
+            KCOUNT(++tc_rebuild);
             if (!half) {
               load_h_rows();
 #pragma unroll
@@ -306,6 +325,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
             Smask = 0u;
             carried = false;
           }
+          KCOUNT(tc_sweeps += __builtin_popcount(Smask ^ Fmask));
           rl_sweep_set<N_>(M, rs, rsi, Smask ^ Fmask, Smask, Fmask, broke, pass == 1, t, half);
         }
         if (!broke || pass == 1) break;
@@ -330,12 +350,14 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
           hp = hi;  // (H p)_i
           const double r = isF ? g + 2.0 * hp : 0.0;
           if ((unsigned)__ballot(!(tabs(r) <= 1e-13 * gs)) == 0u) { exact = true; break; }
-          if (kr >= 6 || !carried) { stale = carried; break; }  // (a fresh tableau is not refined: rounding in T costs an iteration, as before)
+          if (kr >= kr_max || !carried) { stale = carried; break; }  // (a fresh tableau is not refined: rounding in T costs an iteration, as before)
           halves_both_q(rs * rl_matvec<N_>(M, r), lo, hi);
           pdir += lo;
+          KCOUNT(++tc_pass);
           nref = kr + 1 > nref ? kr + 1 : nref;  // (the most passes one direction of this solve needed)
         }
         if (stale) {  // the carried tableau does not contract: this direction again from 2H
+          went_stale = true;
           rebuild = true;
           continue;
         }
@@ -401,6 +423,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
       if ((J0 - Ja >= 1e-4 * sD - Tol<double>::slack() * mag) || alpha < 1e-10) break;
       if (carried) { redo = true; break; }  // a stale tableau gave a poor direction: this iteration again with a fresh one
       alpha *= 0.25;
+      KCOUNT(++tc_ls);
       ++ncrawl;
     }
     if (redo) {
@@ -419,7 +442,16 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   }
   KTRACE(13);
 #ifdef KMPC_TRACE
-  if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + 15] = (unsigned long long)(it + rtot);
+  if (tid == 0 && b < 8192) {
+    kmpc_trace_buf[b * 32 + 15] = (unsigned long long)(it + rtot);
+    kmpc_trace_buf[b * 32 + 22] += (unsigned long long)tc_sweeps;
+    kmpc_trace_buf[b * 32 + 23] += (unsigned long long)tc_rebuild;
+    kmpc_trace_buf[b * 32 + 24] += (unsigned long long)tc_pass;
+    kmpc_trace_buf[b * 32 + 25] += (unsigned long long)it;
+    kmpc_trace_buf[b * 32 + 26] += (unsigned long long)(tc_ls + rtot * 1000);
+    kmpc_trace_buf[b * 32 + 27] += (unsigned long long)((tc_carried0 ? 1 : 0) + ((it == 1 && tc_sweeps == 0 && tc_rebuild == 0 && rtot == 0) ? 1000 : 0));
+    (void)tc_mv;
+  }
 #endif
   if (status == 2) x = own ? c0 : 0.0;
   if (status == 3) {
@@ -468,6 +500,11 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     }
   }
   cs.valid = keep ? 1 : 0;
+  if (carried_at_start) {
+    const int ns = went_stale ? (nstale0 < 255 ? nstale0 + 1 : 255) : 0;
+    const int age = full_budget ? 0 : probe_age + 1;
+    cs.trust = ns | (age << 8);
+  }
   cs.smask = Smask;
   cs.umask = (unsigned)__ballot(own && x >= ub - eact);
   KTRACE(14);

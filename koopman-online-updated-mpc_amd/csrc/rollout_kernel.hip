@@ -20,6 +20,21 @@ namespace kmpc {
 // RBF lift: every wave lifts its own state, the waves of a workgroup never meet.
 // ---------------------------------------------------------------------------------------
 typedef double d4_t __attribute__((ext_vector_type(4)));
+#ifdef KMPC_TRACE
+// lift timeline of the trace build: wave 0 of a workgroup adds (now - barrier-0 release) into slot 32 * (b0 + 1 + i) + 31 ... kept simple:
+// stamps 0..8 of the LAST step are written to the slots 22..30 of trajectory b0 + 1 (whose wave does not stamp these slots itself when
+// the work counters of qp_rl are off); read with tools/dbg/lift_timeline.py
+#define LSTAMP(i)                                                                                      \
+  do {                                                                                                 \
+    if (wv == 0 && lane == 0 && b0 < 8192) kmpc_lift_buf[(b0 >> 4) * 16 + (i)] = wall_clock64();      \
+  } while (0)
+__device__ unsigned long long kmpc_lift_buf[512 * 16];
+extern "C" int kmpc_lift_trace_read(void* host, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kmpc_lift_buf), bytes, 0, hipMemcpyDeviceToHost);
+}
+#else
+#define LSTAMP(i)
+#endif
 // NW = waves (= trajectories) per workgroup: 16 (one workgroup per CU) or 8 (two per CU, MFMA tiles half empty:
 // used when the batch would otherwise leave CUs without a workgroup).
 constexpr int RO_ACT = 32 * 64;                     // B-fragments of one activation vector set (Hp <= 128)
@@ -294,6 +309,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
         for (int r = 0; r < 4; ++r) c1[r] = R.b1[16 * wv + (lane >> 4) + 4 * r];
       }
       __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all trajectories is in sXn
+      LSTAMP(0);
       if (hid) {
         c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sXn[4 * (lane & 15) + (lane >> 4)], c1, 0, 0, 0);
 #pragma unroll
@@ -302,7 +318,9 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
           if (NW != 8 || (lane & 15) < 8) sAct0[(row >> 2) * AR + (row & 3) * (AR / 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
         }
       }
+      LSTAMP(1);
       __syncthreads();
+      LSTAMP(2);
       // ---- hidden -> hidden layers, then the output layer, all as: tile = wave, full K
       for (int h = 0; h <= R.nhh; ++h) {
         const bool last = h == R.nhh;
@@ -345,7 +363,9 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
           if (h + 1 < R.nhh) { if (hid) ro_load_afrags(R.Whp[h + 1], KS, wv, 0, lane, af[0]); }
           else if (out) ro_load_afrags(R.Wop, KS, wv, 0, lane, af[0]);
         }
+        LSTAMP(3 + 2 * h);
         __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
+        LSTAMP(4 + 2 * h);
       }
       }
       if ((lane & PSI_MASK) < L) psi_i = sPsi[(lane & PSI_MASK) * 16 + wv];
@@ -353,7 +373,10 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
 
 #ifdef KMPC_TRACE
     if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 17] = wall_clock64();  // lift done
-    if (lane == 0 && b < 8192 && k == 0) kmpc_trace_buf[b * 32 + 19] = wall_clock64();
+    if (lane == 0 && b < 8192 && k == 0) {
+      kmpc_trace_buf[b * 32 + 19] = wall_clock64();
+      for (int sl = 22; sl < 28; ++sl) kmpc_trace_buf[b * 32 + sl] = 0ull;  // (qp_rl's work counters: summed over the launch)
+    }
 #endif
     if (live) {
       int woff = R.wbase + wv * R.wstride, bk = b;

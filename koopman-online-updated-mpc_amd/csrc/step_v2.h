@@ -361,6 +361,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     cs.smask = (unsigned)__builtin_amdgcn_readfirstlane(ci[0]);  // (wave-uniform: the solve branches on them)
     cs.valid = __builtin_amdgcn_readfirstlane(ci[1]);
     cs.umask = (unsigned)__builtin_amdgcn_readfirstlane(ci[2]);
+    cs.trust = __builtin_amdgcn_readfirstlane(ci[3]);
     if (cs.valid) {
       const double* const trow = sR + (t < N_ ? t : N_ - 1) * rl_stride(N_);
       if constexpr ((N_ & 1) == 0) {
@@ -458,6 +459,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       ci[0] = (int)cs.smask;
       ci[1] = cs.valid;
       ci[2] = (int)cs.umask;
+      ci[3] = cs.trust;
     }
     block_sync<64>();
     if (sv.cov_ahead) {
@@ -479,6 +481,7 @@ template <int L_, int N_, int Q_> __device__ __forceinline__ void step_v2_init(d
     ci[0] = 0;
     ci[1] = 0;
     ci[2] = 0;
+    ci[3] = 0;
   }
   for (int e = tid; e < N_ * Q_; e += 64) sEr[N_ * Q_ + e] = 0.0;
 }

@@ -70,6 +70,7 @@ SIGNATURES = {
     "kmpc_gram_accumulate": (_I, [_VP, _VP, _VP, _VP]),
     "kmpc_shared_solve": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_shared_solve_plant": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP, _I, _VP, _I, _D, _VP]),
+    "kmpc_shared_rollout": (_I, [_VP, _I, _VP, _VP, _I, _I, _I, _D, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "kmpc_shared_get_model": (_I, [_VP, _VP, _VP, _VP, _VP]),
     "kmpc_set_applied_input": (_I, [_VP, _VP, _I, _VP]),
     "kmpc_set_online_update": (_I, [_VP, _I]),

@@ -430,6 +430,26 @@ class KoopmanMPC:
                 dist.all_reduce(delta, op=dist.ReduceOp.SUM)  # RCCL over xGMI: the one collective of the path
         return self.shared_solve(delta, r, plant=plant, X=x if plant is not None else None, switched=switched, h=h)
 
+    def shared_rollout(self, kind, X, r, steps, step0=0, switch_step=101, h=0.05, comm=None, log=False):
+        """`steps` iterations of the shared-model loop (Tank_System.m:170-291 with one model for all trajectories of all ranks)
+        enqueued from C++ on the current stream: lift + local Gram sums -> ncclAllReduce over `comm` (an RCCL communicator handle,
+        koopmpc.sharding.NcclCommunicator; None: single rank) -> model, condensed QP -> box QPs with the plant inside
+        (kmpc_shared_rollout).  X (n, B) is advanced in place; self.status / self.iters receive the worst status / total Newton
+        solves, self.U0 / self.Useq the last step's inputs / sequences.  Returns (U_log, X_log) with log=True."""
+        plant = self._plant_id(kind)
+        assert X.is_cuda and X.dtype == self.dtype and X.is_contiguous() and tuple(X.shape) == (self.n, self.B)
+        rr, per = self._ref(r)
+        if per:
+            raise ValueError("shared-model mode takes one reference (q, N) for the whole batch")
+        Ul = torch.empty(steps, self.B, dtype=self.dtype, device=self.device) if log else None
+        Xl = torch.empty(steps, self.n, self.B, dtype=self.dtype, device=self.device) if log else None
+        cptr = None if comm is None else (comm.handle if hasattr(comm, "handle") else comm)
+        self._chk(self.lib.kmpc_shared_rollout(self.h, plant, self._p(X), self._p(rr), int(steps), int(step0), int(switch_step), float(h),
+                                               cptr, self._p(Ul) if log else None, self._p(Xl) if log else None, self._p(self.U0), self._p(self.Useq),
+                                               self._p(self.status), self._p(self.iters), self._stream()), "kmpc_shared_rollout")
+        self._keep = (rr,)
+        return (Ul, Xl) if log else None
+
     def shared_model(self):
         A = torch.empty(self.L, self.L, dtype=self.dtype, device=self.device)
         Bm = torch.empty(self.L, 1, dtype=self.dtype, device=self.device)

@@ -35,3 +35,57 @@ def max_over_ranks(value, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device if device is not None else "cpu")
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+class NcclCommunicator:
+    """An RCCL communicator of this process's own for the native shared-model loop (kmpc_shared_rollout): rank 0 draws the unique id,
+    torch.distributed's default process group carries it to the other ranks (any backend: it is 128 bytes), every rank joins with
+    ncclCommInitRank.  Without a process group: a one-rank communicator.  The RCCL is the one that lives in the process (torch's own
+    copy when it exports the symbols, else the system librccl) -- the one kmpc_shared_rollout resolves ncclAllReduce from."""
+
+    def __init__(self, device=None):
+        import ctypes as C
+
+        import torch
+        import torch.distributed as dist
+
+        proc = C.CDLL(None)
+        try:
+            proc.ncclCommInitRank
+            self.rccl = proc
+        except AttributeError:
+            self.rccl = C.CDLL("librccl.so", mode=C.RTLD_GLOBAL)
+
+        class UID(C.Structure):
+            _fields_ = [("b", C.c_char * 128)]
+
+        world, rank = 1, 0
+        if dist.is_available() and dist.is_initialized():
+            world, rank = dist.get_world_size(), dist.get_rank()
+        uid = UID()
+        if rank == 0:
+            rc = self.rccl.ncclGetUniqueId(C.byref(uid))
+            if rc != 0:
+                raise RuntimeError("ncclGetUniqueId failed with code %d" % rc)
+        if world > 1:
+            raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
+            if dist.get_backend() != "gloo":
+                raw = raw.to(device if device is not None else "cuda")
+            dist.broadcast(raw, src=0)
+            C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+        if device is not None:
+            torch.cuda.set_device(device)
+        comm = C.c_void_p()
+        self.rccl.ncclCommInitRank.argtypes = [C.POINTER(C.c_void_p), C.c_int, UID, C.c_int]
+        rc = self.rccl.ncclCommInitRank(C.byref(comm), world, uid, rank)
+        if rc != 0:
+            raise RuntimeError("ncclCommInitRank failed with code %d" % rc)
+        self.handle, self.world, self.rank = comm, world, rank
+
+    def destroy(self):
+        import ctypes as C
+
+        if getattr(self, "handle", None):
+            self.rccl.ncclCommDestroy.argtypes = [C.c_void_p]
+            self.rccl.ncclCommDestroy(self.handle)
+            self.handle = None
