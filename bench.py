@@ -699,7 +699,7 @@ def main():
                 others[label or oname] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
 
-        for oname in ("cfg3", "cfg3-L20", "cfg4", "cfg5"):
+        for oname in ("cfg4", "cfg3", "cfg3-L20", "cfg5"):
             leg(oname, args)
         # BASELINE's configs[1] names fp32: the same workload with float32 arithmetic -- reported beside the float64 headline, never in
         # place of it (the 1e-6 bar on u needs float64)

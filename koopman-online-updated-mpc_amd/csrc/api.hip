@@ -186,7 +186,7 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMemset(dPsi[1], 0, sizeof(T) * (size_t)L * B));
     HIPCHK(hipMemset(dUprev, 0, sizeof(T) * (size_t)B));
     HIPCHK(hipMemset(dWarm, 0, sizeof(T) * (size_t)N * B));
-    if (sizeof(T) == 8 && threads == 256 && !getenv("KMPC_QP_NO_CARRY")) {  // (the variable is a measurement aid)
+    if (sizeof(T) == 8 && threads == 256 && !dbg_env("KMPC_QP_NO_CARRY")) {  // (the variable is a measurement aid)
       HIPCHK(hipMalloc(&dQpCarry, sizeof(T) * (size_t)B * N * N));
       HIPCHK(hipMalloc(&dQpCarrySet, sizeof(int32_t) * (size_t)B * 4));
       HIPCHK(hipMemset(dQpCarrySet, 0, sizeof(int32_t) * (size_t)B * 4));
@@ -575,7 +575,7 @@ struct Impl : kmpc_handle {
     a.umin = (T)cfg.umin; a.umax = (T)cfg.umax;
     a.u_prev = dUprev;  // delta-u reads the absolute previous input in every phase
     a.qp_scratch = dQpScr;
-    static const int predict = getenv("KMPC_QP_PREDICT") ? atoi(getenv("KMPC_QP_PREDICT")) : 1;  // measurement aid: 0 = plain projected Newton
+    static const int predict = dbg_env("KMPC_QP_PREDICT") ? atoi(dbg_env("KMPC_QP_PREDICT")) : 1;  // measurement aid: 0 = plain projected Newton
     a.qp_predict = predict;
     a.plant = -1;
     return a;
@@ -713,7 +713,7 @@ struct Impl : kmpc_handle {
     // roll-out kernel with a single step and no plant (encoder inside on MFMA, no separate lift kernel, psi handed
     // over in registers).  Same results up to the summation order of the encoder.
     if (fuse_plant < 0 && !accumulate && cfg.lift_kind == KMPC_LIFT_MLP && fused_rollout_ok()) {
-      static const bool two = getenv("KMPC_STEP_TWO_KERNELS") != nullptr;  // measurement aid
+      static const bool two = dbg_env("KMPC_STEP_TWO_KERNELS") != nullptr;  // measurement aid
       if (!two)
         return rollout_fused(-1, const_cast<void*>(X), ref, rpt, 1, 0, -1, 0.05, nullptr, nullptr, st, it, s, U0, Useq);
     }
@@ -798,7 +798,7 @@ struct Impl : kmpc_handle {
   }
   int rollout_is_fused() const override { return fused_rollout_ok() ? 1 : 0; }
   bool fused_rollout_ok() const {
-    static const bool off = getenv("KMPC_NO_FUSED_ROLLOUT") != nullptr;  // measurement aid: per-step launches
+    static const bool off = dbg_env("KMPC_NO_FUSED_ROLLOUT") != nullptr;  // measurement aid: per-step launches
     return !off && n == 2 && rollout_fused_available<T>(n, L, N, q, threads, cfg.lift_kind != KMPC_LIFT_MLP);
   }
   int rollout_fused(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
@@ -942,7 +942,7 @@ struct Impl : kmpc_handle {
     g.u_prev = dUprev; g.x_now = (const T*)X; g.partial = dPartial;
     if constexpr (sizeof(T) == 8) {
       // float64 MLP lift: the lift and the Gram sums of the transitions in ONE launch (lift_coop_kernel<.., GRAM>), then the reduce
-      const bool two = getenv("KMPC_SHARED_LIFT_GRAM_2") != nullptr;  // measurement / test aid (read per call): the two round-3 launches
+      const bool two = dbg_env("KMPC_SHARED_LIFT_GRAM_2") != nullptr;  // measurement / test aid (read per call): the two round-3 launches
       if (have_prev && !two && cfg.lift_kind == KMPC_LIFT_MLP) {
         if ((rc = check_lift_ready())) return rc;
         LiftArgs<T> a{};
@@ -1026,13 +1026,13 @@ struct Impl : kmpc_handle {
     const T* wt = !have_wterm ? nullptr : (wterm_from_dare ? (const T*)dWtB : dWt);
     const int okind = cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX;
     const int cy0 = cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0;
-    static const bool two_kernels = getenv("KMPC_SHARED_TWO_KERNELS") != nullptr;  // measurement aid: the round-1 launches
+    static const bool two_kernels = dbg_env("KMPC_SHARED_TWO_KERNELS") != nullptr;  // measurement aid: the round-1 launches
     const bool one_launch = !two_kernels && cfg.output_kind == KMPC_OUT_CX && shared_model_available(L, n, q, N, cfg.delta_u ? 1 : 0);
     if (have_prev && !one_launch) HIPCHK(launch_axpby(dGram, delta, cfg.lambda, (int)gram_elems(), s));
     if (one_launch) {
       // model solve + condensed QP + the tableau the box QPs start from, one launch (shared_model_kernel)
       if (!dTs) HIPCHK(hipMalloc(&dTs, sizeof(T) * (size_t)N * N));
-      const bool old_kernel = getenv("KMPC_SHARED_MODEL_R3") != nullptr;  // measurement / test aid (read per call): the round-3 model kernel
+      const bool old_kernel = dbg_env("KMPC_SHARED_MODEL_R3") != nullptr;  // measurement / test aid (read per call): the round-3 model kernel
       bool on16 = false;
       if constexpr (sizeof(T) == 8) {
         if (!old_kernel && shared_model2_available(L, n, q, N, cfg.delta_u ? 1 : 0)) {
@@ -1082,7 +1082,7 @@ struct Impl : kmpc_handle {
     }
     // the trajectories whose unconstrained minimiser lies inside the box are finished 16 per wave on the matrix cores
     // (shared_fast_kernel); the solve-only kernel then only runs for the flagged rest
-    const bool no_fast = getenv("KMPC_SHARED_NO_FAST") != nullptr;  // measurement / test aid (read per call): every trajectory through the QP kernel
+    const bool no_fast = dbg_env("KMPC_SHARED_NO_FAST") != nullptr;  // measurement / test aid (read per call): every trajectory through the QP kernel
     if (one_launch && sizeof(T) == 8 && N <= 64 && !no_fast) {
       if (!dNeed) HIPCHK(hipMalloc(&dNeed, sizeof(int32_t) * (size_t)B));
       // (the flagged trajectories also go into a list that a fixed grid of the solve-only kernel walks; two counters alternate)
@@ -1090,7 +1090,7 @@ struct Impl : kmpc_handle {
         HIPCHK(hipMalloc(&dQpList, sizeof(int32_t) * (size_t)(B + 2)));
         HIPCHK(hipMemsetAsync(dQpList, 0, sizeof(int32_t) * (size_t)(B + 2), s));
       }
-      if (!getenv("KMPC_SHARED_NO_LIST")) {  // (measurement / test aid, read per call: one workgroup per trajectory, flags only)
+      if (!dbg_env("KMPC_SHARED_NO_LIST")) {  // (measurement / test aid, read per call: one workgroup per trajectory, flags only)
         a.qp_list = dQpList + 2;
         a.qp_count = dQpList + qp_list_parity;
         a.qp_count_next = dQpList + (qp_list_parity ^ 1);

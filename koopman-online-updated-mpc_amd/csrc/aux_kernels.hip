@@ -6,9 +6,16 @@
 //             after step 100: x1' = x2, x2' = -3 x2 - 10 x1^2 x2 - 3 x1 + u  vanderpol.py:923-931
 //   RK4, h = 0.05                                                duffing.py:256-261
 #include "kernels.h"
+#include <cstdlib>
 #include "plant_device.h"
 
 namespace kmpc {
+
+const char* dbg_env(const char* name) {
+  static const bool on = getenv("KMPC_DEBUG") != nullptr;
+  return on ? getenv(name) : nullptr;
+}
+
 
 template <typename T> __global__ __launch_bounds__(256) void plant_kernel(const PlantArgs<T> a) {
   const int B = a.B;

@@ -8,6 +8,17 @@
 
 namespace kmpc {
 
+// Measurement / test switches of the library.  They are read from the environment ONLY when KMPC_DEBUG is set (tests/conftest.py and
+// the tools under tools/ set it); a production process never looks at them.  The table:
+//   KMPC_NO_FUSED_ROLLOUT     kmpc_rollout as per-step launches          KMPC_STEP_TWO_KERNELS    kmpc_step as lift kernel + step kernel
+//   KMPC_ROLLOUT_WAVES=4|8|16 trajectories per roll-out workgroup        KMPC_LIFT_STATIONARY     the round-1 weights-stationary lift kernel
+//   KMPC_QP_PREDICT=0         plain projected Newton (no prediction)     KMPC_QP_NO_CARRY         four-wave solver without its carried tableau
+//   KMPC_QP_NO_HGLOBAL        shared-model solve stages H into LDS        KMPC_SHARED_TWO_KERNELS  round-1 shared_solve + shared_condense
+//   KMPC_SHARED_MODEL_R3      round-3 model kernel (eight waves)          KMPC_SHARED_LIFT_GRAM_2  lift and Gram sums as two launches
+//   KMPC_SHARED_NO_FAST       every trajectory through the QP kernel      KMPC_SHARED_NO_LIST      solve-only kernel: one workgroup per trajectory
+const char* dbg_env(const char* name);
+
+
 enum { PH_RLS = 1, PH_CONDENSE = 2, PH_QP = 4 };
 enum { OUT_CX = 0, OUT_LIFT = 1 };
 

@@ -394,7 +394,7 @@ template <typename T> hipError_t launch_lift_mlp(const LiftArgs<T>& a, hipStream
   if (a.B <= 0) return hipSuccess;
   if (a.n > 4 || a.Lp > 64 || a.Hp > 128 || (a.nlayers != 2 && a.nlayers != 3)) return hipErrorInvalidValue;
   if constexpr (sizeof(T) == 8) {
-    static const bool stationary = getenv("KMPC_LIFT_STATIONARY") != nullptr;  // measurement aid: the weights-stationary kernel
+    static const bool stationary = dbg_env("KMPC_LIFT_STATIONARY") != nullptr;  // measurement aid: the weights-stationary kernel
     if (!stationary && a.KSp <= 32 && (a.Hp & 15) == 0) return launch_lift_coop(reinterpret_cast<const LiftArgs<double>&>(a), s);
   }
   const int nhh = a.nlayers - 1;

@@ -461,7 +461,7 @@ void set_rollout_workgroup(int trajectories) { g_rollout_workgroup = trajectorie
 static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
   const size_t cap = 160 * 1024 / sizeof(double);
   if (!rbf) {
-    static const char* env = getenv("KMPC_ROLLOUT_WAVES");  // measurement aid: force 4, 8 or 16
+    static const char* env = dbg_env("KMPC_ROLLOUT_WAVES");  // measurement aid: force 4, 8 or 16
     // workgroups of w trajectories that fit on one CU (LDS is handed out in 512-byte granules; 16 waves per CU)
     auto wgs = [&](int w) -> int {
       const size_t e = (rollout_lds_elems(n, L, q, N, false, w, Lp, nullptr) + 63) & ~(size_t)63;

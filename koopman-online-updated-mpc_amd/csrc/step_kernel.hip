@@ -98,7 +98,7 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
   if constexpr (QPK) {
     if (qp_only && a.phases == PH_QP) {
       // (shared H and the register safeguard compiled in and not switched off: the solve never leaves for the LDS tableau)
-      static const bool no_hg = getenv("KMPC_QP_NO_HGLOBAL") != nullptr;
+      static const bool no_hg = dbg_env("KMPC_QP_NO_HGLOBAL") != nullptr;
       if (a.h_shared && a.H_in && a.T_in && (a.qp_predict & 2) == 0 && !no_hg) {
         const int p = a.L + 1, setq = 3 * a.N > 2 * p + a.L ? 3 * a.N : 2 * p + a.L;
         k.r1 = 0;

@@ -10,6 +10,7 @@ for p in (ROOT, PKG):
         sys.path.insert(0, p)
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
+os.environ.setdefault("KMPC_DEBUG", "1")  # (the library reads its measurement / test switches only with this set: csrc/kernels.h)
 
 
 def pytest_configure(config):

@@ -2,6 +2,7 @@
 # Dev tool (GPU box): A/B/... of builds of the library on ONE box, alternating; cfg2 on the driver's window (K = 20) and the default one
 #   REPS=2 ARGS="--no-extras" tools/dbg/ab2.sh <libA.so> <libB.so> ...
 root=${GRAFT_REPO_ROOT:-/root/repo}
+export KMPC_DEBUG=1  # (the library reads its measurement switches only with this set)
 for rep in $(seq 1 ${REPS:-2}); do
 for lib in "$@"; do
 for w in "--steps 20 --warmup 5" "--steps 200 --warmup 20"; do

@@ -1,6 +1,7 @@
 """Dev tool (GPU box, trace build): where the cooperative lift of the cfg2 roll-out spends its time -- wave 0 of every workgroup stamps
 the wall clock after each barrier and after each layer's products (LAST step of the launch).
     KMPC_TRACE_LIB=libkoopmpc_devtrace.so python tools/dbg/lift_timeline.py [steps]"""
+import os as _os; _os.environ.setdefault("KMPC_DEBUG", "1")
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "koopman-online-updated-mpc_amd"))

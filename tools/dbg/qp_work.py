@@ -1,6 +1,7 @@
 """Dev tool (GPU box, trace build): what the box QPs of a fused cfg2 roll-out do, per trajectory and launch -- sweeps, rebuilds of
 the tableau, refinement passes, iterations -- and how the workgroups' finish times follow them.
     KMPC_TRACE_LIB=libkoopmpc_devtrace.so python tools/dbg/qp_work.py [steps] [cold]"""
+import os as _os; _os.environ.setdefault("KMPC_DEBUG", "1")
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "koopman-online-updated-mpc_amd"))

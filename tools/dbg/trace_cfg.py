@@ -1,5 +1,6 @@
 """Dev tool (GPU box, trace build): per-wave phase times of the fused roll-out of a bench configuration (RBF sets: the waves never
 meet, a wave's phase times are its own).   KMPC_TRACE_LIB=libkoopmpc_devtrace.so python tools/dbg/trace_cfg.py cfg3 [steps]"""
+import os as _os; _os.environ.setdefault("KMPC_DEBUG", "1")
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "koopman-online-updated-mpc_amd"))

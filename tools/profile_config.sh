@@ -7,8 +7,8 @@ cfg=${1:-cfg2}; tag=${2:-r2}; shift 2
 root=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
-cd /tmp && export TMPDIR=/tmp
-args="--config $cfg --cpu-seconds 0 --no-extras $*"
+cd /tmp && export TMPDIR=/tmp && export KMPC_DEBUG=1
+args="--config $cfg --cpu-seconds 0 --no-extras --no-probe $*"
 rocprofv3 --kernel-trace --stats -d "$out/trace" -o bench --output-format csv -- python3 "$root/bench.py" $args > "$out/bench_trace.json" 2> "$out/trace.log"
 rocprofv3 --pmc FETCH_SIZE -d "$out/fetch" -o bench --output-format csv -- python3 "$root/bench.py" $args > "$out/bench_fetch.json" 2> "$out/fetch.log"
 rocprofv3 --pmc WRITE_SIZE -d "$out/write" -o bench --output-format csv -- python3 "$root/bench.py" $args > "$out/bench_write.json" 2> "$out/write.log"

@@ -1,4 +1,5 @@
 """Dev tool (GPU box, trace build): phase stamps of shared_model_kernel for the cfg4 dimensions."""
+import os as _os; _os.environ.setdefault("KMPC_DEBUG", "1")
 import os, sys, ctypes as C
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "koopman-online-updated-mpc_amd"))

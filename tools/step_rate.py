@@ -1,4 +1,5 @@
 """Dev tool: a Python loop of kmpc_step + kmpc_plant_step at the bench batch (cfg2): microseconds per step; KMPC_STEP_TWO_KERNELS=1\nforces the lift kernel + step kernel route."""
+import os as _os; _os.environ.setdefault("KMPC_DEBUG", "1")
 import os, sys, time
 sys.path.insert(0, "/root/repo/koopman-online-updated-mpc_amd")
 import numpy as np, torch

@@ -2,6 +2,7 @@
 Lane 0 of every workgroup stamps the 100 MHz wall clock at the phase boundaries; this prints, per segment,
 the median / p90 / max duration over the 4096 trajectories of one launch at a late closed-loop step.
     python tools/trace_phases.py [B] [steps] [cold]"""
+import os as _os; _os.environ.setdefault("KMPC_DEBUG", "1")
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "koopman-online-updated-mpc_amd"))
 import numpy as np, torch
