@@ -46,17 +46,18 @@ template <typename T, int TPB, int L_, int N_, int Q_, bool HG>
 __global__ __launch_bounds__(TPB, (HG ? KMPC_QP_HG_WAVES : 3)) void step_qp_kernel(const StepArgs<T> a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const StepVar<T> sv{PH_QP, 0, a.plant_switched, a.psi_prev, a.psi_now, a.U0, nullptr, 0, T(0), T(0), HG};
-  if (a.qp_list) {
-    // the trajectories shared_fast_kernel left over, as a list: a fixed grid walks it (StepArgs::qp_list)
-    const int cnt = a.qp_count[0] < a.B ? a.qp_count[0] : a.B;
-    for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
-      step_body<T, TPB, L_, N_, Q_, true>(a, sv, a.qp_list[i], reinterpret_cast<T*>(smem_raw));
-      block_sync<TPB>();
-    }
-    return;
+  // The trajectories shared_fast_kernel left over come as a list that a fixed grid walks (StepArgs::qp_list), or -- without a list --
+  // one workgroup per trajectory reads its flag.  ONE call site of the step body serves both (two inlined copies of it cost the
+  // 168-register kernel 40 more spilled registers).
+  const bool list = a.qp_list != nullptr;
+  const int cnt = list ? (a.qp_count[0] < a.B ? a.qp_count[0] : a.B) : (int)blockIdx.x + 1;
+  for (int i = blockIdx.x; i < cnt; i += gridDim.x) {
+    const int b = list ? a.qp_list[i] : i;
+    if (!list && a.qp_need && a.qp_need[b] == 0) break;  // (finished by shared_fast_kernel)
+    step_body<T, TPB, L_, N_, Q_, true>(a, sv, b, reinterpret_cast<T*>(smem_raw));
+    if (!list) break;
+    block_sync<TPB>();
   }
-  if (a.qp_need && a.qp_need[blockIdx.x] == 0) return;  // (finished by shared_fast_kernel)
-  step_body<T, TPB, L_, N_, Q_, true>(a, sv, (int)blockIdx.x, reinterpret_cast<T*>(smem_raw));
 }
 
 // ---------------------------------------------------------------------------------------
@@ -104,12 +105,12 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
         k.r1 = 0;
         const size_t lq = (size_t)(16 + a.N + setq) * sizeof(T);
         if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&step_qp_kernel<T, TPB, L_, N_, Q_, true>), 1, lq); e != hipSuccess) return e;
-        const int gridq = a.qp_list ? (a.B < 1024 ? a.B : 1024) : a.B;  // (list mode: a fixed grid walks the flagged trajectories)
+        const int gridq = a.qp_list ? (a.B < 2048 ? a.B : 2048) : a.B;  // (list mode: a fixed grid walks the flagged trajectories)
         hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_, true>), dim3(gridq), dim3(TPB), lq, s, k);
         return hipGetLastError();
       }
       if (hipError_t e = allow_lds(reinterpret_cast<const void*>(&step_qp_kernel<T, TPB, L_, N_, Q_, false>), 2, lds); e != hipSuccess) return e;
-      const int gridq = a.qp_list ? (a.B < 1024 ? a.B : 1024) : a.B;
+      const int gridq = a.qp_list ? (a.B < 2048 ? a.B : 2048) : a.B;
       hipLaunchKernelGGL((step_qp_kernel<T, TPB, L_, N_, Q_, false>), dim3(gridq), dim3(TPB), lds, s, k);
       return hipGetLastError();
     }

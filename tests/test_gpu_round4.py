@@ -442,11 +442,11 @@ def test_lift_and_gram_in_one_launch_equal_the_two_kernels(torch_mod, KM, monkey
 
 def test_solve_only_kernel_walks_the_list_of_flagged_trajectories(torch_mod, KM, monkeypatch):
     """Round 4: the trajectories the interior kernel leaves over (box active or certificate failed) are handed to the solve-only kernel
-    as a LIST that a fixed grid of at most 1024 workgroups walks, instead of one workgroup per trajectory that reads a flag.  With
-    B = 2500 > 1024 every workgroup takes several trajectories in turn; random start states and the plant switch keep most boxes
+    as a LIST that a fixed grid of at most 2048 workgroups walks, instead of one workgroup per trajectory that reads a flag.  With
+    B = 7000 > 2048 every workgroup takes several trajectories in turn; random start states and the plant switch keep most boxes
     active.  Against the flag-only launch (KMPC_SHARED_NO_LIST, read per call) in lockstep: inputs, sequences, status bit for bit."""
     torch = torch_mod
-    L, N, B = 32, 40, 2500
+    L, N, B = 32, 40, 7000
     ma, mb = _tank_controller(KM, L, N, B), _tank_controller(KM, L, N, B)
     r = np.ones((1, N))
     X = _t(torch, 3.0 * np.abs(np.random.RandomState(2).rand(2, B)))

@@ -234,3 +234,60 @@ def test_bench_cpu_baseline_worker_makes_steps(name, solver):
     # (name, L, N, x0, budget, solver, settle steps that are set-up, first steps timed as the post-reset transient)
     done, secs, tdone, tsecs = bench._cpu_worker((name, c["L"], c["N"], x0, 1.5, solver, 3, 2))
     assert done >= 1 and secs > 0.0 and tdone >= 2 and tsecs > 0.0
+
+
+@pytest.mark.parametrize("name", ["cfg2", "cfg3", "cfg4"])
+def test_bench_parity_probe_worker_on_the_host(name, tmp_path, capsys):
+    """The oracle half of bench.py's parity probe (a child process of the cpu_baseline leg; round 4) on files made here: inputs that
+    ARE the exact minimisers' first moves for the given models and states must come back with error 0, a perturbed one with exactly
+    the perturbation -- so the number in the bench line is the device's distance from the oracle and nothing else."""
+    import json
+
+    from oracle import koopman_oracle as ko
+
+    bench = _bench()
+    c = bench.CONFIGS[name]
+    L, N = c["L"], c["N"]
+    w = bench.workload_inputs(name, L, N)
+    lift = (lambda x: ko.rbf_lift(x, w["centres"])) if c.get("lift") == "rbf" else (lambda x: ko.mlp_lift(w["weights"], x))
+    rng = np.random.RandomState(5)
+    nb = 3
+    X = np.abs(rng.rand(2, nb)) if name == "cfg4" else 4 * rng.rand(2, nb) - 2
+    A = rng.randn(nb, L, L) * 0.2 / np.sqrt(L)
+    Bm = rng.randn(nb, L, 1) * 0.1
+    Cm = rng.randn(nb, 2, L) * 0.3
+    uprev = rng.randn(nb) * 0.2 if name == "cfg4" else np.zeros(nb)
+    u = np.zeros(nb)
+    for i in range(nb):
+        psi = lift(X[:, i:i + 1]).reshape(-1)
+        if name == "cfg4":
+            ctl = ko.OracleDeltaUController(lift, L, 2, N, A[i], Bm[i], Cm[i])
+            ctl.u = float(uprev[i])
+            At, Bt, Co, xt = ctl.qp(psi)
+            _, _, H, f, _ = ko.condense(At, Bt, Co, xt, w["ref"], N, ctl.Qw, ctl.Rw)
+            lbv = np.full(N, ctl.lb); ubv = np.full(N, ctl.ub)
+            lbv[0] = max(ctl.lb, ctl.umin - ctl.u); ubv[0] = min(ctl.ub, ctl.umax - ctl.u)
+            u[i] = ctl.u + float(ko.qp_exact(H, f, lbv, ubv)[0][0])
+        else:
+            _, _, H, f, _ = ko.condense(A[i], Bm[i], Cm[i], psi, w["ref"], N, 100.0, 1e-4)
+            u[i] = float(ko.qp_exact(H, f, c["lb"], c["ub"])[0][0])
+    for delta in (0.0, 3e-5):
+        path = str(tmp_path / ("probe_%s_%g.npz" % (name, delta)))
+        ug = u.copy(); ug[1] += delta
+        np.savez(path, name=name, L=L, N=N, X=X, A=A, B=Bm, C=Cm, u=ug, uprev=uprev)
+        bench._probe_worker(path)
+        out = json.loads(capsys.readouterr().out.strip().splitlines()[-1])
+        assert out["n"] == nb and abs(out["max_abs_u_err"] - delta) <= 1e-12
+
+
+def test_bench_flop_and_byte_counts():
+    """SURVEY 8d's algorithmic flop formulas as bench.py evaluates them (the table's totals at 100 Newton solves) and the executed
+    count beside them (never above the algorithmic one for the per-trajectory modes: the Toeplitz build is cheaper than the dense H)."""
+    bench = _bench()
+    # SURVEY 8d totals at iters = 100: cfg1/2 224 806, cfg5 2 527 302
+    assert bench.algorithmic_flops("cfg2", 20, 20, 2, 100) == 224806
+    assert bench.algorithmic_flops("cfg5", 64, 50, 2, 100) == 2527302
+    for name, q in (("cfg2", 2), ("cfg3", 2), ("cfg3-L20", 2), ("cfg5", 2)):
+        c = bench.CONFIGS[name]
+        ex, al = bench.executed_flops(name, c["L"], c["N"], q, 1.1), bench.algorithmic_flops(name, c["L"], c["N"], q, 1.1)
+        assert 0 < ex < al
