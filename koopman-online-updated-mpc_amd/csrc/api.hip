@@ -237,7 +237,7 @@ struct Impl : kmpc_handle {
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
                       (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
-                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet, (void*)dDelta, (void*)dQpList})
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet, (void*)dDelta, (void*)dQpList, (void*)dWork, (void*)dPerm})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
   }
@@ -829,6 +829,15 @@ struct Impl : kmpc_handle {
     r.have_prev = have_prev ? 1 : 0; r.rls_fresh = rls_fresh ? 1 : 0;
     r.no_update = update_on ? 0 : 1;
     r.U_log = (T*)Ulog; r.X_log = (T*)Xlog;
+    if (!dbg_env("KMPC_ROLLOUT_NO_PLACE")) {  // (the trajectories' solver work of the previous launch: RolloutArgs::work)
+      if (!dWork) {
+        HIPCHK(hipMalloc(&dWork, sizeof(int32_t) * (size_t)B));
+        HIPCHK(hipMemsetAsync(dWork, 0, sizeof(int32_t) * (size_t)B, s));
+      }
+      r.work = dWork;
+      // ... across the workgroups too where the batch allows the card deal (whole workgroups; the rank kernel is O(B^2 / lanes))
+      if (place_valid && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= 16384 && !dbg_env("KMPC_ROLLOUT_NO_GLOBAL_PLACE")) r.perm = dPerm;
+    }
     if constexpr (sizeof(T) == 8) {
       if (use_img) {
         if ((rc = ensure_image(s))) return rc;
@@ -846,6 +855,13 @@ struct Impl : kmpc_handle {
       HIPCHK(hipEventRecord(ev[ev_used + 1], s));  // (no separate lift kernel)
     }
     HIPCHK(launch_rollout_fused<T>(r, s));
+    if (r.work && steps >= 4 && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= 16384) {
+      if (!dPerm) HIPCHK(hipMalloc(&dPerm, sizeof(int32_t) * (size_t)B));
+      HIPCHK(launch_place(dWork, B, dPerm, s));  // (the next launch's deal: RolloutArgs::perm)
+      place_valid = true;
+    } else {
+      place_valid = false;
+    }
     if (rec) {
       HIPCHK(hipEventRecord(ev[ev_used + 2], s));
       ev_used += 3;
@@ -899,6 +915,9 @@ struct Impl : kmpc_handle {
   double *dGram = nullptr, *dPartial = nullptr;
   T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr, *dTs = nullptr;
   int32_t* dNeed = nullptr;  // [B] flags of shared_fast_kernel
+  int32_t* dWork = nullptr;  // [B] solver work of every trajectory in the last fused launch (RolloutArgs::work)
+  int32_t* dPerm = nullptr;  // [B] slot -> trajectory for the next fused launch (RolloutArgs::perm); valid after a launch that wrote dWork
+  bool place_valid = false;
   int32_t* dQpList = nullptr;  // two alternating counters, then the list of the trajectories shared_fast_kernel left to the solve-only kernel
   int qp_list_parity = 0;
   T* dWt = nullptr;  // PN - Qw I (terminal block of Q_bar)

@@ -230,6 +230,30 @@ hipError_t launch_image_to_state(const double* img, long stride, int n, int L, i
   return hipGetLastError();
 }
 
+// place_kernel: rank of every trajectory by last launch's solver work, then the card deal of RolloutArgs::perm.  Sixteen lanes share
+// the scan of one element (B / 16 comparisons each): 256 workgroups of 256 threads for B = 4096, ~3 us.
+__global__ __launch_bounds__(256) void place_kernel(const int32_t* __restrict__ work, int B, int32_t* __restrict__ perm) {
+  const int e = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
+  const int we = e < B ? work[e] : 0;
+  int r = 0;
+  for (int c = part; c < B; c += 16) {
+    const int wc = work[c];
+    r += (wc > we || (wc == we && c < e)) ? 1 : 0;
+  }
+  r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
+  if (part == 0 && e < B) {
+    const int G = B >> 4, p = r / G;
+    int g = r - p * G;
+    if (p & 1) g = G - 1 - g;
+    perm[g * 16 + p] = e;
+  }
+}
+hipError_t launch_place(const int32_t* work, int B, int32_t* perm, hipStream_t s) {
+  if (B <= 0 || (B & 15)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(place_kernel, dim3(B / 16), dim3(256), 0, s, work, B, perm);
+  return hipGetLastError();
+}
+
 // Row-major zero-padded weights (Mp x Hp) -> MFMA A-fragments [tile][k-step][lane]: lane l of tile t, k-step ks
 // holds W[16 t + (l & 15)][4 ks + (l >> 4)], so a wave reads one fragment as 64 consecutive elements.
 template <typename T> __global__ void pack_afrag_kernel(const T* src, int Mp, int Hp, int KS, T* dst) {

@@ -122,7 +122,19 @@ template <typename T> struct RolloutArgs {
   T* U_log; T* X_log;       // optional (steps x B), (steps x n x B)
   // register-state step (step_v2.h): the wave images of the trajectories' state, [B][img_stride]
   T* img; long img_stride;
+  // work [B] (in / out, handle-owned): what every trajectory's solves cost in the previous launch (sweeps, refinement passes, further
+  // Newton points: qp_rl's estimate).  The sixteen trajectories of a workgroup are dealt to its waves by it, heaviest first: the oldest
+  // waves of the SIMDs -- served first -- take the expensive solves, the youngest, whose end is the step's end, the cheap ones (the
+  // 20-step launch of cfg2: - 5 %).  Results do not depend on it (a trajectory's arithmetic is its own).  Null: wave w takes trajectory w.
+  int32_t* work;
+  // perm [B] (optional, B a multiple of 16): slot -> trajectory for the WHOLE batch, written by place_kernel from `work` after the
+  // previous launch: the trajectories sorted by work are dealt like cards -- the G heaviest to wave 0 of the G workgroups, the next G
+  // to wave 1 in reverse order (snake), ... -- so that every workgroup gets one trajectory of each of sixteen work strata (equal sums:
+  // a 20-step launch is ONE round of workgroups and lasts as long as the slowest) and the heavy ones sit on the oldest waves.
+  const int32_t* perm;
 };
+// rank every trajectory by its work (descending, ties by index: deterministic) and write the slot -> trajectory table (RolloutArgs::perm)
+hipError_t launch_place(const int32_t* work, int B, int32_t* perm, hipStream_t s);
 
 // K7: Gram sums of one step's transitions (rows [psi_prev; u_prev; psi_now; x_now] against [psi_prev; u_prev])
 template <typename T> struct GramArgs {

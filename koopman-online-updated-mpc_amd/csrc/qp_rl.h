@@ -479,6 +479,9 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
       int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
       acc[0] = acc[0] > status ? acc[0] : status;
       acc[1] += it + rtot;
+      // what this solve cost beyond the easy case, in units of ~0.08 us (the time regression of tools/dbg/qp_work.py: 0.23 us per
+      // sweep, 0.38 per refinement pass, ~0.6 per further Newton point): the roll-out deals its trajectories to the waves by it
+      acc[2] += 8 * (it + rtot - 1) + 5 * nref + (carried ? 3 * __builtin_popcount(cs.smask ^ Smask) : 3 * N_);
     } else {
       if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
       if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it + rtot : it + rtot;

@@ -97,13 +97,34 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
   const int tid0 = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid0 >> 6);  // wave-uniform: trajectory index and LDS base stay scalar
   const int B = ra.s.B, n = ra.s.n, L = L_;
-  const int b0 = blockIdx.x * (int)(blockDim.x >> 6), b = b0 + wave;  // NW waves (MLP lift); RBF: as many as fit in LDS
-  const bool live = b < B;
+  const int b0 = blockIdx.x * (int)(blockDim.x >> 6);  // NW waves (MLP lift); RBF: as many as fit in LDS
   // lift scratch (overlays the per-wave regions between two steps)
   double* const sAct0 = smem;
   double* const sAct1 = sAct0 + (NW == 8 ? ro_act8() : RO_ACT);
   double* const sPsi = smem + ra.keep_off;  // behind the per-wave regions: survives into the step
   double* const sXn = sPsi + ra.Lp * NC;
+  int slot_traj = wave;  // which of the workgroup's trajectories this wave takes
+  if constexpr (!RBF && NW == 16) {
+    if (ra.perm) {  // (RolloutArgs::perm: the whole batch dealt out by work)
+      slot_traj = b0 + wave < B ? ra.perm[b0 + wave] - b0 : wave;
+    } else if (ra.work) {  // (RolloutArgs::work: by last launch's solver work, heaviest to the oldest waves)
+      int* const sHint = reinterpret_cast<int*>(sPsi);
+      int* const sRank = sHint + 16;
+      if (tid0 < 16) sHint[tid0] = b0 + (int)tid0 < B ? ra.work[b0 + tid0] : -1;
+      __syncthreads();
+      if (tid0 < 16) {
+        const int ht = sHint[tid0];
+        int r = 0;
+        for (int v = 0; v < 16; ++v) { const int hv = sHint[v]; r += (hv > ht || (hv == ht && v < (int)tid0)) ? 1 : 0; }
+        sRank[r] = tid0;
+      }
+      __syncthreads();
+      slot_traj = __builtin_amdgcn_readfirstlane(sRank[wave]);
+      __syncthreads();
+    }
+  }
+  const int b = b0 + slot_traj;
+  const bool live = b < B;
   if (!RBF && tid0 < 4 * NC) sXn[tid0] = 0.0;  // (columns of trajectories this workgroup does not have)
   __syncthreads();
   if (!RBF && (tid0 & 63) < 4)
@@ -434,6 +455,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
     const int* const acc = reinterpret_cast<const int*>(sXn + wave * 4 + 2);
     if (ra.s.status) ra.s.status[b] = acc[0];
     if (ra.s.iters) ra.s.iters[b] = acc[1];
+    if (ra.work) ra.work[b] = acc[2];
   }
 }
 

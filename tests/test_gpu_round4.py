@@ -462,3 +462,33 @@ def test_solve_only_kernel_walks_the_list_of_flagged_trajectories(torch_mod, KM,
         flagged += int((ma.iters > 1).sum().item())
         X = ma.plant_step("tank", X.clone(), ua, switched=(k > 5))
     assert flagged > B  # (the solve-only kernel did have work)
+
+
+@pytest.mark.parametrize("B", [256, 250])
+def test_placement_by_work_does_not_change_a_single_bit(torch_mod, KM, monkeypatch, B):
+    """Round 4: the fused roll-out deals its trajectories to workgroups and waves by the solver work the previous launch counted for
+    them (RolloutArgs::work / perm; B = 256: the card deal over the whole batch, B = 250 -- not whole workgroups -- inside each
+    workgroup only).  A trajectory's arithmetic is its own wherever it runs: four consecutive launches through the RLS reset and the
+    parameter switch against the same launches without placement (KMPC_ROLLOUT_NO_PLACE, read per launch): logged inputs and states,
+    models, status and Newton-solve counts bit for bit."""
+    torch = torch_mod
+    from koopmpc.synth import initial_states, offline_data, random_mlp_weights
+
+    L, N = 20, 20
+    w = random_mlp_weights(2, 100, 3, L, seed=4)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    ms = [KM(n=2, L=L, N=N, batch=B, weights=w) for _ in range(2)]
+    for m in ms:
+        assert m.rollout_is_fused()
+        m.offline_fit(*offline_data(), ridge=1e-8)
+    Xs = [torch.tensor(initial_states(B, seed=9), dtype=torch.float64, device="cuda:0").contiguous() for _ in range(2)]
+    for i in range(4):
+        monkeypatch.delenv("KMPC_ROLLOUT_NO_PLACE", raising=False)
+        Ua, Xa = ms[0].rollout("duffing", Xs[0], r, 10, step0=10 * i, switch_step=25, log=True)
+        monkeypatch.setenv("KMPC_ROLLOUT_NO_PLACE", "1")
+        Ub, Xb = ms[1].rollout("duffing", Xs[1], r, 10, step0=10 * i, switch_step=25, log=True)
+        monkeypatch.delenv("KMPC_ROLLOUT_NO_PLACE", raising=False)
+        assert torch.equal(Ua, Ub) and torch.equal(Xa, Xb), i
+        assert torch.equal(ms[0].status, ms[1].status) and torch.equal(ms[0].iters, ms[1].iters), i
+    for ta, tb in zip(ms[0].get_model(), ms[1].get_model()):
+        assert torch.equal(ta, tb)
