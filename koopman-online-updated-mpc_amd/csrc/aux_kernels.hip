@@ -245,6 +245,8 @@ __global__ __launch_bounds__(256) void place_kernel(const int32_t* __restrict__ 
     const int G = B >> 4, p = r / G;
     int g = r - p * G;
     if (p & 1) g = G - 1 - g;
+    // (stratum p -> wave p: age order.  Measured and dropped: strata 4-7 / 12-15 in reverse order so that the four SIMDs carry equal
+    //  sums -- it undoes the gain: heavy solves on the OLDEST waves is what pays, profiles/r4_cfg2_placement_ab.txt)
     perm[g * 16 + p] = e;
   }
 }
