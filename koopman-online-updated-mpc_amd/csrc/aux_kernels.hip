@@ -233,11 +233,15 @@ hipError_t launch_image_to_state(const double* img, long stride, int n, int L, i
 // place_kernel: rank of every trajectory by last launch's solver work, then the card deal of RolloutArgs::perm.  Sixteen lanes share
 // the scan of one element (B / 16 comparisons each): 256 workgroups of 256 threads for B = 4096, ~3 us.
 __global__ __launch_bounds__(256) void place_kernel(const int32_t* __restrict__ work, int B, int32_t* __restrict__ perm) {
+  extern __shared__ int32_t sW[];  // the whole work panel (B <= 16384: 64 KB): the scan reads it 16 times per workgroup
+  for (int c = threadIdx.x; c < B; c += 256) sW[c] = work[c];
+  __syncthreads();
   const int e = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
-  const int we = e < B ? work[e] : 0;
+  const int we = e < B ? sW[e] : 0;
   int r = 0;
+#pragma unroll 8
   for (int c = part; c < B; c += 16) {
-    const int wc = work[c];
+    const int wc = sW[c];
     r += (wc > we || (wc == we && c < e)) ? 1 : 0;
   }
   r += __shfl_xor(r, 8, 64); r += __shfl_xor(r, 4, 64); r += __shfl_xor(r, 2, 64); r += __shfl_xor(r, 1, 64);
@@ -252,7 +256,12 @@ __global__ __launch_bounds__(256) void place_kernel(const int32_t* __restrict__ 
 }
 hipError_t launch_place(const int32_t* work, int B, int32_t* perm, hipStream_t s) {
   if (B <= 0 || (B & 15)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(place_kernel, dim3(B / 16), dim3(256), 0, s, work, B, perm);
+  static bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    configured = true;
+  }
+  hipLaunchKernelGGL(place_kernel, dim3(B / 16), dim3(256), (size_t)B * sizeof(int32_t), s, work, B, perm);
   return hipGetLastError();
 }
 
