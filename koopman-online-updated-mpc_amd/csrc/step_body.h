@@ -900,6 +900,9 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       carried = true;
     }
   }
+#ifdef KMPC_TRACE
+  const bool carried0 = carried;
+#endif
   const T fi = own ? sf[myvar] : T(0);
   if (tid < 64) qv[tid] = T(0);  // (entries beyond N stay zero)
   // y_i = sum_j M_ij v_j for the owner of variable i (v given by the owners)
@@ -1169,7 +1172,13 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     if (a.status) a.status[b] = a.accumulate ? (a.status[b] > status ? a.status[b] : status) : status;
     if (a.iters) a.iters[b] = a.accumulate ? a.iters[b] + it + rtot : it + rtot;
 #ifdef KMPC_TRACE
-    if (b < 8192) kmpc_trace_buf[b * 32 + 15] = (unsigned long long)(it + rtot);
+    if (b < 8192) {
+      kmpc_trace_buf[b * 32 + 15] = (unsigned long long)(it + rtot);
+      kmpc_trace_buf[b * 32 + 16] = (unsigned long long)nref;
+      kmpc_trace_buf[b * 32 + 17] = (unsigned long long)nsw;
+      kmpc_trace_buf[b * 32 + 18] = (unsigned long long)((carried0 ? 1 : 0) | (carried ? 2 : 0));
+      kmpc_trace_buf[b * 32 + 19] = (unsigned long long)it;
+    }
 #endif
   }
   KTRACE(14);
@@ -2170,6 +2179,59 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         });
       }
       if (hf && on) sf[idx] = T(2) * a.Qw * acc;
+    } else if constexpr (ONE_REGION && TPB == 256 && N_ > 0 && Q_ > 0 && (TPB / N_) >= 2 && 5 * L_ >= (TPB / N_) * N_) {
+      // Round 4 -- four-wave trajectories: a diagonal of H is a prefix sum of N - d terms g_{t+d}.g_t and an element of f a sum
+      // of N - a terms g_t.e_{t+a}; N of the 256 threads used to walk them one after the other, 2 N dependent steps (9.4 of the
+      // 85 us of a cfg5 trajectory-step).  Every sum is now cut into NCH = TPB / N chunks of CL terms, one thread each: the chunk
+      // totals meet in LDS (where the recursion's vectors were) and a thread starts its prefix at the sum of the chunks before it.
+      constexpr int NCH = TPB / N_, CL = (N_ + NCH - 1) / NCH;
+      T* const part = va;  // NCH x N   (sy | sV | sW: dead since the recursion's last barrier)
+      const int c = tid / N_, d = tid - c * N_, t0 = c * CL;
+      const bool on = c < NCH;
+      T prod[CL];
+      T tot = T(0), ftot = T(0);
+#pragma unroll
+      for (int i = 0; i < CL; ++i) {
+        const int t = t0 + i;
+        T s0 = T(0), s1 = T(0);
+        if (on && t + d < N_) {
+#pragma unroll
+          for (int r = 0; r < Q_; ++r) {
+            const T gt = sG[t * Q_ + r];
+            s0 += sG[(t + d) * Q_ + r] * gt;
+            s1 += sEr[(t + d) * Q_ + r] * gt;
+          }
+        }
+        prod[i] = s0;
+        tot += s0;
+        ftot += s1;
+      }
+      if (on) part[c * N_ + d] = tot;
+      block_sync<TPB>();
+      T acc = T(0);
+#pragma unroll
+      for (int cc = 0; cc < NCH - 1; ++cc) acc += cc < c ? part[cc * N_ + d] : T(0);
+      const T rdiag = d == 0 ? a.Rw : T(0);
+#pragma unroll
+      for (int i = 0; i < CL; ++i) {
+        const int t = t0 + i;
+        if (on && t + d < N_) {
+          acc += prod[i];
+          const int bb = N_ - 1 - t, aa = bb - d;
+          const T hv = a.Qw * acc + rdiag;
+          sH[aa * N_ + bb] = hv;
+          sH[bb * N_ + aa] = hv;
+        }
+      }
+      block_sync<TPB>();  // the chunk totals of H have been read
+      if (on) part[c * N_ + d] = ftot;
+      block_sync<TPB>();
+      if (tid < N_) {
+        T fs = T(0);
+#pragma unroll
+        for (int cc = 0; cc < NCH; ++cc) fs += part[cc * N_ + tid];
+        sf[tid] = T(2) * a.Qw * fs;
+      }
     } else {
     for (int d = tid; d < N; d += TPB) {
         T acc = T(0);
