@@ -65,6 +65,19 @@ template <int TPB> __device__ __forceinline__ void block_sync() {
     __syncthreads();
   }
 }
+// Round 4 -- a barrier for data exchanged through LDS only.  __syncthreads() also waits for every outstanding vector-memory
+// operation of the wave (s_waitcnt vmcnt(0)): in the four-wave step that made the first barrier wait for ALL of the state
+// requested up front (bar_Q, C, inv_K_G, [A B]: the loads are issued in the order of use so that each phase waits only for its
+// own block) and every phase of the update wait until its write-back had reached HBM.  Here only the LDS counter is drained;
+// registers that receive loads are waited for where they are used (the compiler's own counters), stores complete in the
+// background.  NOT for data that threads of a workgroup hand each other through global memory.
+template <int TPB> __device__ __forceinline__ void block_sync_lds() {
+  if constexpr (TPB == 64) {
+    block_sync<TPB>();
+  } else {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+}
 template <int TPB> __device__ __forceinline__ int local_tid() {
   // (single wave: the lane index from mbcnt, so that no register has to keep threadIdx alive)
   int t = TPB == 64 ? (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) : (int)threadIdx.x;
@@ -149,6 +162,10 @@ __device__ __forceinline__ float tfma(float a, float b, float c) { return __buil
 //  where none is needed -- were a twentieth of the cfg3 step)
 __device__ __forceinline__ double tabs(double v) { return __builtin_fabs(v); }
 __device__ __forceinline__ float tabs(float v) { return __builtin_fabsf(v); }
+__device__ __forceinline__ double uniform_value(double v) {  // a value every lane holds alike, moved to scalar registers
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+__device__ __forceinline__ float uniform_value(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 template <typename T> __device__ __forceinline__ T tclip(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
 // ---- register-resident mat-vec chain (condense, static path): the current vector lives in the lanes and is
@@ -234,13 +251,13 @@ __device__ __forceinline__ double rows_sum(double v) {  // sum over the four 16-
 }
 
 // sum over the whole block; every thread gets the result.  `red` holds >= 8 elements.
-template <typename T, int TPB> __device__ __forceinline__ T block_sum(T v, T* red) {
+template <typename T, int TPB, bool LDS_ONLY = false> __device__ __forceinline__ T block_sum(T v, T* red) {
   v = wave_sum(v);
   if (TPB == 64) return v;
   const int w = threadIdx.x >> 6;
-  block_sync<TPB>();  // protect red[] from the previous use
+  if constexpr (LDS_ONLY) block_sync_lds<TPB>(); else block_sync<TPB>();  // protect red[] from the previous use
   if ((threadIdx.x & 63) == 0) red[w] = v;
-  block_sync<TPB>();
+  if constexpr (LDS_ONLY) block_sync_lds<TPB>(); else block_sync<TPB>();
   T s = T(0);
 #pragma unroll
   for (int i = 0; i < TPB / 64; ++i) s += red[i];
@@ -1482,7 +1499,12 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   // requested before anything waits: the previous input (RLS regressor, delta-u form) and -- static sizes -- the
   // reference, which the condense phase needs only after the state has been written back (requested there, the
   // load sat behind the round trip of those stores)
-  const T up = a.u_prev[b];
+  // (four-wave kernel, round 4: u_{k-1} is the same for the whole workgroup -- held in scalar registers: as a vector register that
+  //  lives until the solve it was the first thing the compiler spilled, and its reload made wave 0 wait for every outstanding
+  //  load and store in the middle of the update)
+  constexpr bool UP_SCALAR = step_one_region<TPB, L_, N_, Q_>();
+  T up = a.u_prev[b];
+  if constexpr (UP_SCALAR) up = uniform_value(up);
   T xw_pre = T(0);
   constexpr int REFN = (Q_ > 0 && N_ > 0 && Q_ * N_ <= 4 * TPB) ? (Q_ * N_ + TPB - 1) / TPB : 0;
   T refp[REFN > 0 ? REFN : 1];
@@ -1522,8 +1544,6 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     for (int i = 0; i < 2; ++i) { const int e = tid + i * TPB; cr[i] = Cg[e < n * L ? e : 0]; }
 #pragma unroll
     for (int i = 0; i < NPR; ++i) { const int e = tid + i * TPB; pr[i] = Pg[e < PP_ ? e : PP_ - 1]; }
-#pragma unroll
-    for (int i = 0; i < NKR; ++i) { const int e = tid + i * TPB; kr[i] = Kg[e < LP_ ? e : LP_ - 1]; }
     if (tid < L) { sz[tid] = zp; sy[tid] = yp; }
     if (tid == 0) sz[L] = up;
     if (tid < n) sx[tid] = xp;
@@ -1533,7 +1553,12 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     for (int i = 0; i < NQR; ++i) { const int e = tid + i * TPB; if (e < LL_) sX[e] = qr[i]; }
 #pragma unroll
     for (int i = 0; i < 2; ++i) { const int e = tid + i * TPB; if (e < n * L) sC[e] = fu ? T(0) : cr[i]; }
-    block_sync<TPB>();
+    // (round 4: [A B] is requested only now, in the registers bar_Q has just left: with all four blocks requested up front the 104
+    //  registers they need did not exist -- the compiler waited for EVERY load to arrive, to spill 37 of them to scratch)
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int i = 0; i < NKR; ++i) { const int e = tid + i * TPB; kr[i] = Kg[e < LP_ ? e : LP_ - 1]; }
+    block_sync_lds<TPB>();
     KTRACE(1);
     for (int i = tid; i < L; i += TPB) {
       T acc = T(0);
@@ -1546,11 +1571,11 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       for (int j = 0; j < L; ++j) acc -= sC[r * L + j] * sz[j];
       sE[r] = acc;
     }
-    block_sync<TPB>();
+    block_sync_lds<TPB>();
     {
       T part2 = T(0);
       for (int i = tid; i < L; i += TPB) part2 += sz[i] * sPz[i];
-      const T dc = T(1) + block_sum<T, TPB>(part2, red);
+      const T dc = T(1) + block_sum<T, TPB, true>(part2, red);
       const T dcinv = T(1) / dc;
       T* Qw = a.Qb + (size_t)b * a.strideQ;
       for_strided<TPB, LL_>(tid, L * L, [&](int e, int) {
@@ -1564,22 +1589,22 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         Cg[e] = v;
       }
     }
-    block_sync<TPB>();  // everyone is done with bar_Q in the region and with sPz / sE
+    block_sync_lds<TPB>();  // everyone is done with bar_Q in the region and with sPz / sE
     KTRACE(2);
     // ---- inv_K_G                                                     duffing.py:931-932
 #pragma unroll
     for (int i = 0; i < NPR; ++i) { const int e = tid + i * TPB; if (e < PP_) sX[e] = pr[i]; }
-    block_sync<TPB>();
+    block_sync_lds<TPB>();
     for (int i = tid; i < p; i += TPB) {
       T acc = T(0);
 #pragma unroll
       for (int j = 0; j < p; ++j) acc += sX[j * p + i] * sz[j];
       sPz[i] = acc;
     }
-    block_sync<TPB>();
+    block_sync_lds<TPB>();
     T part = T(0);
     for (int i = tid; i < p; i += TPB) part += sz[i] * sPz[i];
-    const T d = a.lam + block_sum<T, TPB>(part, red);
+    const T d = a.lam + block_sum<T, TPB, true>(part, red);
     const T dinv = T(1) / d;
     const T linv = T(1) / a.lam;
     T* Pw = a.P + (size_t)b * a.strideP;
@@ -1587,26 +1612,26 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       const int i = e / p, j = e - i * p;
       Pw[e] = (sX[e] - (sPz[i] * sPz[j]) * dinv) * linv;
     });
-    block_sync<TPB>();  // everyone is done with inv_K_G in the region
+    block_sync_lds<TPB>();  // everyone is done with inv_K_G in the region
     KTRACE(3);
     // ---- [A B]: innovation y - K z and K <- (K - K z g') / lam + y g'   (Koopman_update.m:270-274; see the general block)
 #pragma unroll
     for (int i = 0; i < NKR; ++i) { const int e = tid + i * TPB; if (e < LP_) sK[e] = fu ? T(0) : kr[i]; }
-    block_sync<TPB>();
+    block_sync_lds<TPB>();
     for (int r = tid; r < L; r += TPB) {
       T acc = sy[r];
 #pragma unroll
       for (int j = 0; j < p; ++j) acc -= sK[r * p + j] * sz[j];
       sE[r] = acc * linv + sy[r] * (T(1) - linv);
     }
-    block_sync<TPB>();
+    block_sync_lds<TPB>();
     for_strided<TPB, LP_>(tid, L * p, [&](int e, int) {
       const int r = e / p, j = e - r * p;
       const T v = tfma(sE[r], sPz[j] * dinv, sK[e] * linv);
       sK[e] = v;
       Kg[e] = v;
     });
-    block_sync<TPB>();
+    block_sync_lds<TPB>();
     KTRACE(4);
    } else if (sv.phases & PH_CONDENSE) {
     const T* Kg = a.K + (size_t)b * a.strideK;
@@ -1806,7 +1831,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         sEr[e] = -ref[r * N + k];
       }
     }
-    block_sync<TPB>();
+    block_sync_lds<TPB>();
     KTRACE(5);
     // v_{j+1} = A v_j, w_{j+1} = A w_j;  g_j = Co v_j;  e_j = Co w_j - r_{j-1}
     if constexpr (L_ > 0 && TPB == 64 && (L_ + Q_ <= 32)) {
@@ -1949,7 +1974,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       for (int l = 0; l < 32; ++l) row[l] = sK[rr * p + hh * 32 + l];
       const double co = (ln < L && corow < q) ? sC[(a.cy0 + corow) * L + ln] : 0.0;
       const double bs = a.du_mode ? sK[rr * p + L] * (chain ? up : 1.0) : 0.0;
-      block_sync<TPB>();  // (C may sit where g is written from now on)
+      block_sync_lds<TPB>();  // (C may sit where g is written from now on)
       int cur = 0;
       for (int j0 = 0; j0 <= N; j0 += 4) {  // (the outputs of four steps are reduced together: wave_sum4)
         double pc[4] = {0.0, 0.0, 0.0, 0.0};
@@ -1967,7 +1992,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
             half_gather(part, pa, pb);  // the two 16-lane rows of a pair: this row's other half sits in the neighbouring one
             const double acc = (pa + pb) + bs;
             if (hh == 0 && j < N) (chain ? sW : sV)[(cur ^ 1) * L + rr] = acc;  // v_{j+1} / w_{j+1}
-            block_sync<TPB>();
+            block_sync_lds<TPB>();
             cur ^= 1;
           }
         }
@@ -1978,7 +2003,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
           else if (j >= 1) sEr[(j - 1) * q + corow] += g4;             // e_j = Co w_j - r_{j-1}
         }
       }
-      block_sync<TPB>();  // (the last outputs)
+      block_sync_lds<TPB>();  // (the last outputs)
     } else if constexpr (ONE_REGION) {
       // Four-wave trajectories, y = C x (cfg5 sizes, L = 64): threads 0-127 run the v-chain, 128-255 the w-chain; a PAIR of
       // threads keeps one row of A in registers for the whole recursion, half a row each (32 of the 64 columns: every
@@ -2207,7 +2232,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         ftot += s1;
       }
       if (on) part[c * N_ + d] = tot;
-      block_sync<TPB>();
+      block_sync_lds<TPB>();
       T acc = T(0);
 #pragma unroll
       for (int cc = 0; cc < NCH - 1; ++cc) acc += cc < c ? part[cc * N_ + d] : T(0);
@@ -2223,9 +2248,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
           sH[bb * N_ + aa] = hv;
         }
       }
-      block_sync<TPB>();  // the chunk totals of H have been read
+      block_sync_lds<TPB>();  // the chunk totals of H have been read
       if (on) part[c * N_ + d] = ftot;
-      block_sync<TPB>();
+      block_sync_lds<TPB>();
       if (tid < N_) {
         T fs = T(0);
 #pragma unroll
@@ -2288,7 +2313,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         sf[aa] += T(2) * acc;
       }
     }
-    block_sync<TPB>();
+    block_sync_lds<TPB>();
     KTRACE(7);
     if (a.H_out) {
       T* Hg = a.H_out + (size_t)b * N * N;
