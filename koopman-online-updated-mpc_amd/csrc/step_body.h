@@ -1560,6 +1560,34 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     for (int i = 0; i < NKR; ++i) { const int e = tid + i * TPB; kr[i] = Kg[e < LP_ ? e : LP_ - 1]; }
     block_sync_lds<TPB>();
     KTRACE(1);
+    // Round 4, four waves and L = 64: the three matrix-vector products of the update (bar_Q z, inv_K_G z, [A B] z) were ONE wave
+    // walking 64 or 65 dependent LDS round trips while three waited at the barrier (2.7 us each, a tenth of the trajectory-step).
+    // Wave w now sums a quarter of the columns for all 64 rows, the partial sums meet in LDS (where the recursion's outputs will
+    // go), wave 0 adds them and the idle waves take the odd ends (the rows of C, element 65 of inv_K_G z, the two dot products).
+    constexpr bool SPLIT4 = TPB == 256 && L_ == 64;
+    const int wv = tid >> 6, ln = tid & 63;
+    T* const pt = sG;  // 3 x (L + 1)   (region 2 holds C: the launcher never folds it into sG for this kernel)
+    T dc;
+    if constexpr (SPLIT4) {
+      T acc = T(0);
+#pragma unroll
+      for (int jj = 0; jj < L_ / 4; ++jj) { const int j = wv * (L_ / 4) + jj; acc += sX[j * L_ + ln] * sz[j]; }
+      if (wv) pt[(wv - 1) * (L_ + 1) + ln] = acc;
+      block_sync_lds<TPB>();
+      if (wv == 0) {
+        const T pz = (acc + pt[ln]) + (pt[(L_ + 1) + ln] + pt[2 * (L_ + 1) + ln]);
+        sPz[ln] = pz;
+        const T zz = wave_sum(sz[ln] * pz);
+        if (ln == 0) red[0] = zz;
+      } else {
+        for (int r = wv - 1; r < n; r += 3) {
+          const T cz = wave_sum(sC[r * L_ + ln] * sz[ln]);
+          if (ln == 0) sE[r] = sx[r] - cz;
+        }
+      }
+      block_sync_lds<TPB>();
+      dc = T(1) + red[0];
+    } else {
     for (int i = tid; i < L; i += TPB) {
       T acc = T(0);
 #pragma unroll
@@ -1572,10 +1600,11 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       sE[r] = acc;
     }
     block_sync_lds<TPB>();
-    {
       T part2 = T(0);
       for (int i = tid; i < L; i += TPB) part2 += sz[i] * sPz[i];
-      const T dc = T(1) + block_sum<T, TPB, true>(part2, red);
+      dc = T(1) + block_sum<T, TPB, true>(part2, red);
+    }
+    {
       const T dcinv = T(1) / dc;
       T* Qw = a.Qb + (size_t)b * a.strideQ;
       for_strided<TPB, LL_>(tid, L * L, [&](int e, int) {
@@ -1595,6 +1624,28 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 #pragma unroll
     for (int i = 0; i < NPR; ++i) { const int e = tid + i * TPB; if (e < PP_) sX[e] = pr[i]; }
     block_sync_lds<TPB>();
+    T d;
+    if constexpr (SPLIT4) {
+      constexpr int CH = (L_ + 4) / 4;  // 17, 17, 17, 14 columns
+      T acc = T(0);
+#pragma unroll
+      for (int jj = 0; jj < CH; ++jj) { const int j = wv * CH + jj; if (j <= L_) acc += sX[j * (L_ + 1) + ln] * sz[j]; }
+      if (wv) pt[(wv - 1) * (L_ + 1) + ln] = acc;
+      block_sync_lds<TPB>();
+      if (wv == 0) {
+        const T pz = (acc + pt[ln]) + (pt[(L_ + 1) + ln] + pt[2 * (L_ + 1) + ln]);
+        sPz[ln] = pz;
+        const T zz = wave_sum(sz[ln] * pz);
+        if (ln == 0) red[0] = zz;
+      } else if (wv == 1) {  // element L of inv_K_G z (the matrix is symmetric: its row L), and its term of z' inv_K_G z
+        T t = sX[L_ * (L_ + 1) + ln] * sz[ln];
+        if (ln == 0) t += sX[L_ * (L_ + 1) + L_] * sz[L_];
+        t = wave_sum(t);
+        if (ln == 0) { sPz[L_] = t; red[1] = sz[L_] * t; }
+      }
+      block_sync_lds<TPB>();
+      d = a.lam + (red[0] + red[1]);
+    } else {
     for (int i = tid; i < p; i += TPB) {
       T acc = T(0);
 #pragma unroll
@@ -1604,7 +1655,8 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
     block_sync_lds<TPB>();
     T part = T(0);
     for (int i = tid; i < p; i += TPB) part += sz[i] * sPz[i];
-    const T d = a.lam + block_sum<T, TPB, true>(part, red);
+    d = a.lam + block_sum<T, TPB, true>(part, red);
+    }
     const T dinv = T(1) / d;
     const T linv = T(1) / a.lam;
     T* Pw = a.P + (size_t)b * a.strideP;
@@ -1618,11 +1670,24 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
 #pragma unroll
     for (int i = 0; i < NKR; ++i) { const int e = tid + i * TPB; if (e < LP_) sK[e] = fu ? T(0) : kr[i]; }
     block_sync_lds<TPB>();
+    if constexpr (SPLIT4) {
+      constexpr int CH = (L_ + 4) / 4;
+      T acc = T(0);
+#pragma unroll
+      for (int jj = 0; jj < CH; ++jj) { const int j = wv * CH + jj; if (j <= L_) acc += sK[ln * (L_ + 1) + j] * sz[j]; }
+      if (wv) pt[(wv - 1) * (L_ + 1) + ln] = acc;
+      block_sync_lds<TPB>();
+      if (wv == 0) {
+        const T kz = (acc + pt[ln]) + (pt[(L_ + 1) + ln] + pt[2 * (L_ + 1) + ln]);
+        sE[ln] = (sy[ln] - kz) * linv + sy[ln] * (T(1) - linv);
+      }
+    } else {
     for (int r = tid; r < L; r += TPB) {
       T acc = sy[r];
 #pragma unroll
       for (int j = 0; j < p; ++j) acc -= sK[r * p + j] * sz[j];
       sE[r] = acc * linv + sy[r] * (T(1) - linv);
+    }
     }
     block_sync_lds<TPB>();
     for_strided<TPB, LP_>(tid, L * p, [&](int e, int) {

@@ -69,7 +69,8 @@ template <typename T, int TPB, int L_, int N_, int Q_> static hipError_t launch_
   if (!TAB && !a.qp_scratch && (a.phases & PH_QP)) return hipErrorInvalidValue;
   size_t lds = step_lds_bytes(a.n, a.L, a.q, a.N, sizeof(T), &k.r1, &k.r2, TAB);
   if constexpr (step_one_region<TPB, L_, N_, Q_>()) {  // region 2 is C alone ([A B] follows inv_K_G in region 1)
-    const int r2 = a.n * a.L <= a.N * a.q ? 0 : (a.n * a.L + 1) & ~1;  // (C fits where g_0 .. g_{N-1} go: no region 2 at all)
+    // (C could wait where g_0 .. g_{N-1} go when it fits there -- n = 1 --, but that place now takes the partial sums of the update)
+    const int r2 = (a.n * a.L + 1) & ~1;
     k.r2 = r2;
     lds = ((size_t)k.r1 + k.r2 + vec_elems_one_region(a.n, a.L, a.q, a.N)) * sizeof(T);
   }
