@@ -265,7 +265,7 @@ template <typename T, int TPB, bool LDS_ONLY = false> __device__ __forceinline__
 }
 
 // two sums at once (their shuffle chains interleave); results returned in place
-template <typename T, int TPB> __device__ __forceinline__ void block_sum2(T& v0, T& v1, T* red) {
+template <typename T, int TPB, bool LDS_ONLY = false> __device__ __forceinline__ void block_sum2(T& v0, T& v1, T* red) {
   v0 += dpp_shr(v0, 1); v1 += dpp_shr(v1, 1);
   v0 += dpp_shr(v0, 2); v1 += dpp_shr(v1, 2);
   v0 += dpp_shr(v0, 4); v1 += dpp_shr(v1, 4);
@@ -274,9 +274,9 @@ template <typename T, int TPB> __device__ __forceinline__ void block_sum2(T& v0,
   v1 = (lane_bcast(v1, 15) + lane_bcast(v1, 31)) + (lane_bcast(v1, 47) + lane_bcast(v1, 63));
   if (TPB == 64) return;
   const int w = threadIdx.x >> 6;
-  block_sync<TPB>();
+  if constexpr (LDS_ONLY) block_sync_lds<TPB>(); else block_sync<TPB>();
   if ((threadIdx.x & 63) == 0) { red[w] = v0; red[4 + w] = v1; }
-  block_sync<TPB>();
+  if constexpr (LDS_ONLY) block_sync_lds<TPB>(); else block_sync<TPB>();
   T s0 = T(0), s1 = T(0);
 #pragma unroll
   for (int i = 0; i < TPB / 64; ++i) { s0 += red[i]; s1 += red[4 + i]; }
@@ -862,7 +862,7 @@ __device__ __forceinline__ void sweep_regs256(T (&Tm)[(N_ + 15) / 16][(N_ + 15) 
 // stays intact for the whole solve (the one-region kernels: more workgroups per CU, fewer registers each)
 template <typename T, int N_, bool HREG = true>
 __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepArgs<T>& a, const StepVar<T>& sv, int b,
-                                           T* red, T* work, T* qx_out, T up) {
+                                           T* red, T* work, T* qx_out, T up, T xw_pre, const int32_t (&cs_pre)[3]) {
   constexpr int RM = (N_ + 15) / 16;
   const int tid = threadIdx.x, ti = tid >> 4, tj = tid & 15;
   const int myvar = ti + 16 * tj;
@@ -903,7 +903,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   bool carried = false;
   unsigned long long Smask0 = 0ull;
   if (a.qp_carry) {
-    const int32_t* const cs = a.qp_carry_set + 4 * (size_t)b;
+    const int32_t (&cs)[3] = cs_pre;  // (requested before the H / f pass)
     if (__builtin_amdgcn_readfirstlane(cs[2]) != 0) {
       const T* const Tg = a.qp_carry + (size_t)b * N_ * N_;
 #pragma unroll
@@ -924,9 +924,9 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   if (tid < 64) qv[tid] = T(0);  // (entries beyond N stay zero)
   // y_i = sum_j M_ij v_j for the owner of variable i (v given by the owners)
   auto matvec = [&](auto&& Mel, T vin) -> T {
-    __syncthreads();  // the previous vector has been read
+    block_sync_lds<256>();  // the previous vector has been read
     if (own) qv[myvar] = vin;
-    __syncthreads();
+    block_sync_lds<256>();
     T xc[RM];
 #pragma unroll
     for (int c = 0; c < RM; ++c) xc[c] = qv[tj + 16 * c];
@@ -954,9 +954,9 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     }
   }
   const T gs = tabs(fi) + T(2) * ra * xmaxb;
-  T x = own ? (a.x_warm ? tclip(a.x_warm[(size_t)myvar * a.B + b], lb, ub) : c0) : T(0);
+  T x = own ? (a.x_warm ? tclip(xw_pre, lb, ub) : c0) : T(0);
   T hx = matvec(Hel, x);
-  T J0 = block_sum<T, 256>(own ? x * (hx + fi) : T(0), red);
+  T J0 = block_sum<T, 256, true>(own ? x * (hx + fi) : T(0), red);
   unsigned long long Smask = Smask0;
   int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0, rtot = 0, nref = 0;
   bool rebuild = false;
@@ -976,15 +976,15 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       bad = !((viol <= tol * gs) || (res <= tol * xs));
       loose = viol > (T)Tol<T>::tight() * gs;
     }
-    __syncthreads();
+    block_sync_lds<256>();
     if (tid < 3) smk[tid] = 0ull;
-    __syncthreads();
+    block_sync_lds<256>();
     if (own) {
       if (bad) atomicOr(&smk[0], 1ull << myvar);
       if (loose) atomicOr(&smk[1], 1ull << myvar);
       if (inI) atomicOr(&smk[2], 1ull << myvar);
     }
-    __syncthreads();
+    block_sync_lds<256>();
     const unsigned long long Bmask = smk[0], Imask = smk[2];
     const bool refine = smk[1] != 0ull;
     constexpr unsigned long long allmask = (N_ >= 64) ? ~0ull : ((1ull << N_) - 1ull);
@@ -1032,7 +1032,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
             case 2: if constexpr (RM > 2) sweep_put256<T, N_, 2>(Tm, kt, ti, tj, col, row); break;
             default: if constexpr (RM > 3) sweep_put256<T, N_, 3>(Tm, kt, ti, tj, col, row); break;
           }
-          __syncthreads();
+          block_sync_lds<256>();
           const T d = col[k];  // T(k, k)
           if (!((rev ? -d : d) > T(0))) {  // numerical breakdown of the tableau
             broke = true;
@@ -1082,22 +1082,22 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       const T cand = x + pdir;
       const T over = isF ? (cand - ub > lb - cand ? cand - ub : lb - cand) : T(-1);
       const T wmax = wave_max_x(over);
-      __syncthreads();
+      block_sync_lds<256>();
       if ((tid & 63) == 0) red[tid >> 6] = wmax;
       if (tid == 0) smk[0] = ~0ull;
-      __syncthreads();
+      block_sync_lds<256>();
       const T w01 = red[0] > red[1] ? red[0] : red[1], w23 = red[2] > red[3] ? red[2] : red[3];
       const T worst = w01 > w23 ? w01 : w23;
       if (!(worst > T(0))) break;
       if (isF && over == worst) atomicMin(&smk[0], (unsigned long long)myvar);
-      __syncthreads();
+      block_sync_lds<256>();
       const int jv = (int)smk[0];
       if (own && myvar == jv) {
         const T bj = cand > ub ? ub : lb;
         qx_out[jv] = bj;
         red[12] = bj - x;
       }
-      __syncthreads();
+      block_sync_lds<256>();
       const T delta = red[12];
       if (own) g += T(2) * sH[myvar * N_ + jv] * delta;  // gradient at the new base point
       Fmask &= ~(1ull << jv);
@@ -1119,12 +1119,12 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       hxa = matvec(Hel, xa);
       T pJa = own ? xa * (hxa + fi) : T(0);
       if (rounds > 0) {
-        Ja = block_sum<T, 256>(pJa, red);
+        Ja = block_sum<T, 256, true>(pJa, red);
         if (!(Ja <= J0)) redo = true;
         break;
       }
       T pdec = own ? (isF ? alpha * (-g * pdir) : g * (x - xa)) : T(0);
-      block_sum2<T, 256>(pJa, pdec, red);
+      block_sum2<T, 256, true>(pJa, pdec, red);
       Ja = pJa;
       const T mag = tabs(J0) > tabs(Ja) ? tabs(J0) : tabs(Ja);
       if ((J0 - Ja >= T(1e-4) * pdec - (T)Tol<T>::slack() * mag) || alpha < T(1e-10)) break;
@@ -1147,12 +1147,15 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   KTRACE(13);
   if (status == 2) x = own ? c0 : T(0);  // (see qp_regs: non-finite data never leaves as a NaN input)
   if (status == 3) {
-    __syncthreads();
+    block_sync_lds<256>();
     if (own) qx_out[myvar] = x;
     if (a.qp_carry && tid == 0) a.qp_carry_set[4 * (size_t)b + 2] = 0;
     return true;
   }
   const int B = a.B;
+  // (the plant's state is requested before the write-back below: behind it, thread 0 sat out a memory round trip at the very end)
+  T x1p = T(0), x2p = T(0);
+  if (tid == 0 && a.plant >= 0) { x1p = a.X_rw[b]; x2p = a.X_rw[(size_t)B + b]; }
   if (own) {
     if (a.Useq) a.Useq[(size_t)myvar * B + b] = x;
     if (a.x_warm) a.x_warm[(size_t)myvar * B + b] = x;
@@ -1181,7 +1184,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     if (sv.U0) sv.U0[b] = uout;
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
-      T x1 = a.X_rw[b], x2 = a.X_rw[(size_t)B + b];
+      T x1 = x1p, x2 = x2p;
       plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
@@ -1506,6 +1509,7 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
   T up = a.u_prev[b];
   if constexpr (UP_SCALAR) up = uniform_value(up);
   T xw_pre = T(0);
+  int32_t cs_pre[3] = {0, 0, 0};  // (four-wave solver: sets and validity of the carried tableau)
   constexpr int REFN = (Q_ > 0 && N_ > 0 && Q_ * N_ <= 4 * TPB) ? (Q_ * N_ + TPB - 1) / TPB : 0;
   T refp[REFN > 0 ? REFN : 1];
   if constexpr (REFN > 0) {
@@ -2225,6 +2229,17 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
       }
     }
+    if constexpr (N_ > 0 && N_ <= 64 && TPB == 256) {
+      // (four-wave solver, round 4: likewise, and the header of the carried tableau -- two dependent round trips at its start)
+      if (sv.phases & PH_QP) {
+        const int mv = (tid >> 4) + 16 * (tid & 15);
+        if (a.x_warm) xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
+        if (a.qp_carry) {
+          const int32_t* const cs = a.qp_carry_set + 4 * (size_t)b;
+          cs_pre[0] = cs[0]; cs_pre[1] = cs[1]; cs_pre[2] = cs[2];
+        }
+      }
+    }
     if constexpr (TPB == 64 && N_ > 0 && N_ <= 32 && Q_ > 0) {
       // One pass for both: lane d < N walks diagonal d of H, lane 32 + a accumulates f[a].  Both are sums of
       // g_t . w_{t+idx} with w = g (H) or e (f), so the two halves of the wave share one instruction stream.
@@ -2458,7 +2473,15 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       // four-wave register tableau; the workspace is the vector area behind qx / qxa / qg (dead set A of the phase)
       static_assert(L_ == 0 || 2 * (L_ + 1) + 6 * L_ + 1 + 2 * N_ * Q_ >= 3 * N_ + 324, "qp_regs256 workspace");
       static_assert(!ONE_REGION || (5 * L_ + 1 + 2 * N_ * Q_ >= 3 * N_ + 324 && 2 * (L_ + 1) + L_ <= 4 * L_), "qp_regs256 workspace / update vectors (one region)");
-      if (qp_regs256<T, N_, !ONE_REGION>(sH, sf, a, sv, b, red, qg + N, qx, up)) {
+      if (!(sv.phases & PH_CONDENSE)) {  // QP-only call: nothing has requested these yet
+        const int mv = (tid >> 4) + 16 * (tid & 15);
+        if (a.x_warm) xw_pre = a.x_warm[(size_t)(mv < N_ ? mv : 0) * a.B + b];
+        if (a.qp_carry) {
+          const int32_t* const cs = a.qp_carry_set + 4 * (size_t)b;
+          cs_pre[0] = cs[0]; cs_pre[1] = cs[1]; cs_pre[2] = cs[2];
+        }
+      }
+      if (qp_regs256<T, N_, !ONE_REGION>(sH, sf, a, sv, b, red, qg + N, qx, up, xw_pre, cs_pre)) {
         block_sync<TPB>();
         if constexpr (step_tableau_in_lds<TPB, N_, L_>() && !ONE_REGION) {
           qp_lds<T, TPB>(sH, sf, sM, qx, qxa, qg, red, a, sv, b, N, true);
