@@ -584,10 +584,12 @@ template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a
     return hipErrorInvalidValue;
   if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);  // BASELINE cfg3 (RBF lift, y = Cx)
-#ifndef KMPC_DEV_CFG2_ONLY  // (development builds compile the cfg2 / cfg3 instantiations only)
-  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 2) return launch_rollout_impl<8, 10, 2>(a, s);
+#if !defined(KMPC_DEV_CFG2_ONLY) || defined(KMPC_DEV_LIFT)  // (development builds compile the cfg2 / cfg3 instantiations only)
   if (a.s.L == 8 && a.s.N == 10 && a.s.q == 8) return launch_rollout_impl<8, 10, 8>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 8) return launch_rollout_impl<8, 30, 8>(a, s);
+#endif
+#ifndef KMPC_DEV_CFG2_ONLY
+  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 2) return launch_rollout_impl<8, 10, 2>(a, s);
   if (a.s.L == 10 && a.s.N == 20 && a.s.q == 1) return launch_rollout_impl<10, 20, 1>(a, s);  // Tank_System.m dimensions
   if (a.s.L == 20 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<20, 30, 2>(a, s);  // BASELINE cfg3 sizes, y = Cx
   if (a.s.L == 32 && a.s.N == 40 && a.s.q == 2) return launch_rollout_impl<32, 40, 2>(a, s);  // BASELINE cfg4 sizes

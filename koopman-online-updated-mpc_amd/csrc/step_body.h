@@ -2255,14 +2255,20 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       const int hstep = hf ? 0 : N_ + 1;
       const T rdiag = (idx == 0 && !hf) ? a.Rw : T(0);
       auto pass = [&](auto dotq) {
-#pragma unroll
-        for (int t = 0; t < N_; ++t) {
+        auto term = [&](int t) {
           if (on && t + idx < N_) {
             acc += dotq(sG + t * Q_, wb + t * Q_);
             const T hv = a.Qw * acc + rdiag;
             h1[(N_ - 1 - t) * hstep] = hv;
             h2[(N_ - 1 - t) * hstep] = hv;
           }
+        };
+        if constexpr (Q_ * N_ > 128) {  // (y = psi with a long horizon: a loop -- unrolled, the N q loads of a lane were hoisted and spilled; L = 8, N = 30: 103 -> 55 registers, +7 ... 12 %)
+#pragma unroll 1
+          for (int t = 0; t < N_; ++t) term(t);
+        } else {
+#pragma unroll
+          for (int t = 0; t < N_; ++t) term(t);
         }
       };
       if (vec) {  // 16-byte LDS reads (the layout is even for the shipped dimension sets)
@@ -2380,7 +2386,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         const T* ga = sG + (N - 1 - aa) * q;
         const T* gb = sG + (N - 1 - bb) * q;
         T acc = T(0);
+#pragma unroll 1
         for (int r = 0; r < q; ++r)
+#pragma unroll 2
           for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * (T(0.5) * (Wt[r * q + s2] + Wt[s2 * q + r])) * gb[s2];
         sH[e] += acc;
       }
@@ -2388,7 +2396,9 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
         const T* ga = sG + (N - 1 - aa) * q;
         const T* eN = sEr + (N - 1) * q;
         T acc = T(0);
+#pragma unroll 1
         for (int r = 0; r < q; ++r)
+#pragma unroll 2
           for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * Wt[r * q + s2] * eN[s2];
         sf[aa] += T(2) * acc;
       }

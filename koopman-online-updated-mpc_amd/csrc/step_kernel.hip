@@ -134,14 +134,16 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
   // dimensions (L=8, N=10; y = Cx duffing.py, y = lifted state vanderpol.py)
   if (a.L == 20 && a.N == 20 && a.q == 2) return launch_impl<T, 64, 20, 20, 2>(a, s);
   if (a.L == 8 && a.N == 30 && a.q == 2) return launch_impl<T, 64, 8, 30, 2>(a, s);
+#if !defined(KMPC_DEV_CFG2_ONLY) || defined(KMPC_DEV_LIFT)
+  if (a.L == 8 && a.N == 10 && a.q == 8) return launch_impl<T, 64, 8, 10, 8>(a, s);
+  if (a.L == 8 && a.N == 30 && a.q == 8) return launch_impl<T, 64, 8, 30, 8>(a, s);
+#endif
 #ifndef KMPC_DEV_CFG2_ONLY
   if (a.L == 8 && a.N == 10 && a.q == 2) return launch_impl<T, 64, 8, 10, 2>(a, s);
-  if (a.L == 8 && a.N == 10 && a.q == 8) return launch_impl<T, 64, 8, 10, 8>(a, s);
   // BASELINE cfg3: Van der Pol tracking, 8 RBF / MLP observables, N = 30, y = lifted state
   if (a.L == 10 && a.N == 20 && a.q == 1) return launch_impl<T, 64, 10, 20, 1>(a, s);  // Tank_System.m dimensions
   if (a.L == 32 && a.N == 40 && a.q == 2) return launch_impl<T, 64, 32, 40, 2>(a, s);  // BASELINE cfg4 sizes
   if (a.L == 32 && a.N == 40 && a.q == 1) return launch_impl<T, 64, 32, 40, 1>(a, s);
-  if (a.L == 8 && a.N == 30 && a.q == 8) return launch_impl<T, 64, 8, 30, 8>(a, s);
   if (a.L == 20 && a.N == 30 && a.q == 2) return launch_impl<T, 64, 20, 30, 2>(a, s);
 #endif
   return launch_impl<T, 64, 0, 0, 0>(a, s);

@@ -1038,6 +1038,7 @@ def test_step_matches_separate_ops(torch_mod, KM, lift):
     ("mlp", 20, 20, "Cx", 50, 9),     # fused roll-out kernel, ragged last workgroup (50 = 3 x 16 + 2)
     ("mlp", 20, 20, "Cx", 16, 1),     # a single step: the RLS flags must come out like kmpc_step's
     ("mlp", 8, 10, "Cx", 33, 12),     # the reference's own dimensions
+    ("mlp", 8, 10, "lift", 33, 12),   # vanderpol.py's dimensions, y = psi (round 4: register-state step for q = L)
     ("rbf", 8, 30, "lift", 40, 8),    # RBF lift inside the roll-out kernel (cfg3 dimensions)
     ("mlp", 32, 40, "Cx", 20, 5),     # cfg4 sizes: 29 KB of LDS per trajectory, four trajectories per workgroup
     ("mlp", 8, 30, "Cx", 24, 6),      # cfg3 sizes with the MLP lift: 19 KB of LDS per trajectory, 8 per CU
