@@ -469,14 +469,17 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     if (sv.U0) sv.U0[b] = uout;
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
-      double x1 = sv.x_next ? sv.x_next[0] : a.X_rw[b], x2 = sv.x_next ? sv.x_next[1] : a.X_rw[(size_t)B + b];
+      double x1, x2;  // (x_next, when given, is the roll-out's LDS slot -- step_body.h lds_ld: as a select of two addresses these were
+      // flat loads, which wait for both counters: behind the step's write-back a drain of every outstanding store, K = 20 - 4 %)
+      if (sv.x_next) { x1 = lds_ld(sv.x_next); x2 = lds_ld(sv.x_next + 1); }
+      else { x1 = a.X_rw[b]; x2 = a.X_rw[(size_t)B + b]; }
       plant_apply<double>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
-      if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
+      if (sv.x_next) { lds_st(sv.x_next, x1); lds_st(sv.x_next + 1, x2); }
     }
     if (sv.x_next) {
-      int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
+      lds_i32* const acc = (lds_i32*)reinterpret_cast<int*>(sv.x_next + 2);
       acc[0] = acc[0] > status ? acc[0] : status;
       acc[1] += it + rtot;
       // what this solve cost beyond the easy case, in units of ~0.08 us (the time regression of tools/dbg/qp_work.py: 0.23 us per

@@ -162,6 +162,16 @@ __device__ __forceinline__ float tfma(float a, float b, float c) { return __buil
 //  where none is needed -- were a twentieth of the cfg3 step)
 __device__ __forceinline__ double tabs(double v) { return __builtin_fabs(v); }
 __device__ __forceinline__ float tabs(float v) { return __builtin_fabsf(v); }
+// Accesses through a generic pointer that is KNOWN to point into LDS (StepVar::x_next in the fused roll-out).  Where the other arm of
+// the choice is a global pointer the compiler selects between the two ADDRESSES and issues a flat access, which waits for both
+// counters -- behind the step's write-back that is a drain of every outstanding store.
+typedef __attribute__((address_space(3))) double lds_f64;
+typedef __attribute__((address_space(3))) int lds_i32;
+typedef __attribute__((address_space(3))) float lds_f32;
+__device__ __forceinline__ double lds_ld(const double* p) { return *(const lds_f64*)p; }
+__device__ __forceinline__ void lds_st(double* p, double v) { *(lds_f64*)p = v; }
+__device__ __forceinline__ float lds_ld(const float* p) { return *(const lds_f32*)p; }
+__device__ __forceinline__ void lds_st(float* p, float v) { *(lds_f32*)p = v; }
 __device__ __forceinline__ double uniform_value(double v) {  // a value every lane holds alike, moved to scalar registers
   return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
 }
@@ -777,14 +787,16 @@ __device__ __forceinline__ bool qp_regs(const T* sH, const T* sf, const StepArgs
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
       // fused roll-out: x_k waits in the workgroup's LDS slot (no HBM round trip at the end of the step)
-      T x1 = sv.x_next ? sv.x_next[0] : a.X_rw[b], x2 = sv.x_next ? sv.x_next[1] : a.X_rw[(size_t)B + b];
+      T x1, x2;  // (x_next, when given, is the roll-out's LDS slot: lds_ld above)
+      if (sv.x_next) { x1 = lds_ld(sv.x_next); x2 = lds_ld(sv.x_next + 1); }
+      else { x1 = a.X_rw[b]; x2 = a.X_rw[(size_t)B + b]; }
       plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
-      if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
+      if (sv.x_next) { lds_st(sv.x_next, x1); lds_st(sv.x_next + 1, x2); }
     }
     if (sv.x_next) {  // ... and the status / iteration counters are accumulated next to it, written once at the end
-      int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
+      lds_i32* const acc = (lds_i32*)reinterpret_cast<int*>(sv.x_next + 2);
       acc[0] = acc[0] > status ? acc[0] : status;
       acc[1] += it + rtot;
     } else {
@@ -1436,14 +1448,16 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
       // fused roll-out: x_k waits in the workgroup's LDS slot (no HBM round trip at the end of the step)
-      T x1 = sv.x_next ? sv.x_next[0] : a.X_rw[b], x2 = sv.x_next ? sv.x_next[1] : a.X_rw[(size_t)B + b];
+      T x1, x2;  // (x_next, when given, is the roll-out's LDS slot: lds_ld above)
+      if (sv.x_next) { x1 = lds_ld(sv.x_next); x2 = lds_ld(sv.x_next + 1); }
+      else { x1 = a.X_rw[b]; x2 = a.X_rw[(size_t)B + b]; }
       plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
       a.X_rw[b] = x1;
       a.X_rw[(size_t)B + b] = x2;
-      if (sv.x_next) { sv.x_next[0] = x1; sv.x_next[1] = x2; }
+      if (sv.x_next) { lds_st(sv.x_next, x1); lds_st(sv.x_next + 1, x2); }
     }
     if (sv.x_next) {  // ... and the status / iteration counters are accumulated next to it, written once at the end
-      int* const acc = reinterpret_cast<int*>(sv.x_next + 2);
+      lds_i32* const acc = (lds_i32*)reinterpret_cast<int*>(sv.x_next + 2);
       acc[0] = acc[0] > status ? acc[0] : status;
       acc[1] += it;
     } else {

@@ -230,7 +230,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   double* const qg = qxa + N;
 
   KTRACE(0);
-  const double up = a.u_prev[b];
+  const double up = uniform_value(a.u_prev[b]);  // (one trajectory per wave: scalar registers; K = 200 - 2 %)
   double xw_pre = 0.0;
   constexpr int REFN = (Q_ * N_ + 63) / 64;
   double refp[REFN];
@@ -268,7 +268,9 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     }
     // x_{k+1} for the rows of C (the roll-out keeps it in LDS)
     const int xr = t - L_ < 0 ? 0 : (t - L_ < NX ? t - L_ : NX - 1);
-    const double xn = sv.x_next ? sv.x_next[xr] : a.x_now[(size_t)xr * B + b];
+    double xn;  // (x_next, when given, is the roll-out's LDS slot: step_body.h lds_ld)
+    if (sv.x_next) xn = lds_ld(sv.x_next + xr);
+    else xn = a.x_now[(size_t)xr * B + b];
     // z = [psi(x_{k-1}); u_{k-1}] in the lanes of both halves
     const double z = t < L_ ? sv.psi_prev_v : (t == L_ ? up : 0.0);
     KTRACE(1);
