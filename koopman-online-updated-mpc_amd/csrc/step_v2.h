@@ -393,19 +393,32 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     double* const h1 = sR - idx * NS;
     double* const h2 = sR - idx;
     const double Qw = a.Qw, rdiag = idx == 0 ? a.Rw : 0.0;  // (read once: inside the masked regions below every use was a scalar load of its own)
-    static_for<0, N_>([&](auto TT) {
-      constexpr int tt = decltype(TT)::value;
-      if constexpr (Q_ == 2) {
-        const dq_t u = gq[tt], w = wq[tt];
-        acc = tfma(u[0], w[0], acc);
-        acc = tfma(u[1], w[1], acc);
-      } else {
+    // Round 4: HCH diagonal steps at a time -- their values first, then their stores.  One step at a time, every step was a complete
+    // LDS round trip: the stores are volatile assembly (the immediate exec masks), nothing moves across them, so the two reads
+    // of a step could only be requested behind the previous step's stores and waited for in full (20 x ~230 cycles = 1.9 of the
+    // 33 us of a cfg2 step).  In a chunk the reads of all its steps are in flight together.
+    constexpr int HCH = 10;
+    static_for<0, (N_ + HCH - 1) / HCH>([&](auto CC) {
+      constexpr int c0 = decltype(CC)::value * HCH, c1 = c0 + HCH < N_ ? c0 + HCH : N_;
+      double hv[HCH];
+      static_for<c0, c1>([&](auto TT) {
+        constexpr int tt = decltype(TT)::value;
+        if constexpr (Q_ == 2) {
+          const dq_t u = gq[tt], w = wq[tt];
+          acc = tfma(u[0], w[0], acc);
+          acc = tfma(u[1], w[1], acc);
+        } else {
 #pragma unroll
-        for (int r = 0; r < Q_; ++r) acc = tfma(sG[tt * Q_ + r], ((hf ? sEr : sG) + idx * Q_)[tt * Q_ + r], acc);
-      }
+          for (int r = 0; r < Q_; ++r) acc = tfma(sG[tt * Q_ + r], ((hf ? sEr : sG) + idx * Q_)[tt * Q_ + r], acc);
+        }
+        hv[tt - c0] = Qw * acc + rdiag;
+      });
       // lanes tid < N - tt: (aa, bb) = (N-1-tt-idx, N-1-tt) is inside H.  The lane set is a compile-time constant: the two stores run
       // under an exec mask written as an immediate (a compare, a saved mask and a branch per diagonal step otherwise)
-      lds_store2_lanes<N_ - tt, (N_ - 1 - tt) * (NS + 1) * 8>(h1, h2, Qw * acc + rdiag);
+      static_for<c0, c1>([&](auto TT) {
+        constexpr int tt = decltype(TT)::value;
+        lds_store2_lanes<N_ - tt, (N_ - 1 - tt) * (NS + 1) * 8>(h1, h2, hv[tt - c0]);
+      });
     });
     if (hf && idx < N_) sf[idx] = 2.0 * Qw * acc;
   }
