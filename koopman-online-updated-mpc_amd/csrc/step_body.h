@@ -1174,7 +1174,8 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   }
   if (a.qp_carry) {  // the tableau stays for the next solve (a carried one that needed many iterations does not: 2H next time)
     const bool keep = status == 0 && !(carried && (it >= 4 || nref >= 5));
-    if (keep) {
+    // (a carried tableau that saw no sweep is what global memory already holds: half of the settled solves, 20 KB each at N = 50)
+    if (keep && !(carried && nsw == 0)) {
       T* const Tg = a.qp_carry + (size_t)b * N_ * N_;
 #pragma unroll
       for (int r = 0; r < RM; ++r)
