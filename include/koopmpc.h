@@ -267,7 +267,9 @@ int kmpc_plant_step(kmpc_handle* h, int plant, void* X_dev, const void* U_dev, d
  * For float64, single-wave configurations with a static instantiation (kmpc_rollout_is_fused) the whole
  * call is ONE kernel launch: 16 trajectories per workgroup, the encoder evaluated inside on MFMA, no
  * synchronisation between workgroups from the first step to the last.  Same results as the per-step
- * launches up to the summation order of the encoder (1e-12 on the controls).                         */
+ * launches up to the summation order of the encoder (1e-12 on the controls).
+ * steps = 0 changes nothing and brings the handle into the form the fused roll-out works on (set-up
+ * that the next call would otherwise pay after a state import or per-step calls).                  */
 int kmpc_rollout(kmpc_handle* h, int plant, void* X_dev, const void* ref_dev, int ref_per_traj,
                  int steps, int step0, int switch_step, double hstep, void* U_log_dev, void* X_log_dev,
                  int32_t* status_dev, int32_t* iters_dev, void* stream);

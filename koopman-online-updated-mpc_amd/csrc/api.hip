@@ -894,6 +894,14 @@ struct Impl : kmpc_handle {
     }
     if (steps > 0 && fused_rollout_ok())
       return rollout_fused(plant, X, ref, rpt, steps, step0, switch_step, hs, Ulog, Xlog, st, it, s);
+    if (steps == 0 && fused_rollout_ok()) {
+      // a call without steps brings the handle into the form the fused roll-out works on (the wave image of a state that was
+      // set, restored or stepped through the dense blocks): set-up that the next kmpc_rollout would otherwise pay
+      if constexpr (sizeof(T) == 8) {
+        if (use_img) return ensure_image(s);
+      }
+      return 0;
+    }
     for (int i = 0; i < steps; ++i) {
       const int gi = step0 + i;
       T* u = Ulog ? (T*)Ulog + (size_t)i * B : dU0;
