@@ -492,3 +492,31 @@ def test_placement_by_work_does_not_change_a_single_bit(torch_mod, KM, monkeypat
         assert torch.equal(ms[0].status, ms[1].status) and torch.equal(ms[0].iters, ms[1].iters), i
     for ta, tb in zip(ms[0].get_model(), ms[1].get_model()):
         assert torch.equal(ta, tb)
+
+
+def test_rollout_without_steps_only_prepares_the_handle(torch_mod, KM):
+    """kmpc_rollout(steps = 0) changes nothing -- state, model, the next roll-out -- and leaves the handle in the form the fused roll-out
+    works on (the wave image of a state that was stepped through the dense blocks): what bench.py's cold-start leg uses to keep that
+    one-off conversion out of its timed region, as it is outside the headline's."""
+    torch = torch_mod
+    from koopmpc.synth import initial_states, offline_data, random_mlp_weights
+
+    L, N, B = 20, 20, 64
+    w = random_mlp_weights(2, 100, 3, L, seed=4)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    ms = [KM(n=2, L=L, N=N, batch=B, weights=w) for _ in range(2)]
+    Xs = [torch.tensor(initial_states(B, seed=3), dtype=torch.float64, device="cuda:0").contiguous() for _ in range(2)]
+    for m, X in zip(ms, Xs):
+        m.offline_fit(*offline_data(), ridge=1e-8)
+        for k in range(3):  # per-step calls: the state lives in the dense blocks
+            u = m.step(X, r)
+            X.copy_(m.plant_step("duffing", X, u))
+    X0 = Xs[0].clone()
+    model0 = [t.clone() for t in ms[0].get_model()]
+    assert ms[0].rollout("duffing", Xs[0], r, 0, step0=3) is None
+    assert torch.equal(Xs[0], X0)
+    for ta, tb in zip(ms[0].get_model(), model0):
+        assert torch.equal(ta, tb)
+    Ua, Xa = ms[0].rollout("duffing", Xs[0], r, 6, step0=3, log=True)
+    Ub, Xb = ms[1].rollout("duffing", Xs[1], r, 6, step0=3, log=True)
+    assert torch.equal(Ua, Ub) and torch.equal(Xa, Xb)
