@@ -29,7 +29,8 @@ The default run (cfg2, one GPU) appends `other_configs`: short legs of cfg3, cfg
 same K / W.  `cpu_baseline` times the NumPy oracle run the way the reference runs (per-trajectory Python
 loop, SciPy L-BFGS-B on the shooting cost, duffing.py:857-859) on a bounded sample of the same workload IN
 THE SAME REGIME (the settle steps after the reset are set-up, the steps after them are timed): one worker
-process per host core of the box's CPU share (16), forked before the GPU is touched.
+process per host core the process may use (affinity mask, capped by the cgroup quota; the count is in the line), forked before
+the GPU is touched.
 """
 import argparse
 import json
@@ -237,15 +238,13 @@ def _probe_worker(path):
     print(json.dumps({"max_abs_u_err": worst, "n": int(X.shape[1])}))
 
 
-def parity_probe(loop, name, L, N, step_next, nprobe=8, check=True):
-    """One more closed-loop step of the timed controller (untimed), `nprobe` of its trajectories checked against the oracle in a child
-    process: max |u_gpu - u_oracle| (duffing.py:857-861: the input the loop applies).  The models are the ones the device solved with
-    (exported after the step), so the figure covers lift, condensed build and box QP of the timed state."""
-    import tempfile
+def parity_probe_step(loop, name, step_next, nprobe=8):
+    """One more closed-loop step of the timed controller (untimed) on every rank; returns what the check needs of `nprobe` of its
+    trajectories: the states before the step, the inputs the device computed, the models it solved with (exported after the step)."""
     torch = loop.torch
     B = loop.B
     idx = torch.tensor(np.unique(np.linspace(0, B - 1, nprobe).astype(np.int64)), device=loop.dev)
-    Xpre = loop.X[:, idx].cpu().numpy()
+    Xpre = loop.X[:, idx].cpu().numpy().astype(np.float64)
     if loop.shared:
         uprev = loop.m.U0[idx].cpu().numpy()
         loop.m.shared_step(loop.X, loop.r, plant="tank", switched=(step_next > 100))
@@ -257,15 +256,51 @@ def parity_probe(loop, name, L, N, step_next, nprobe=8, check=True):
         Ul, _ = loop.m.rollout(loop.c["plant"], loop.X, loop.r, 1, step0=step_next, log=True)
         u = Ul[0, idx].cpu().numpy()
         A, Bm, Cm = [t[idx].cpu().numpy() for t in loop.m.get_model()]
-    if not check:  # (the other ranks of a multi-rank run only take part in the step: cfg4's step holds a collective)
-        return None
+    return dict(X=Xpre, A=np.asarray(A, dtype=np.float64), B=np.asarray(Bm, dtype=np.float64), C=np.asarray(Cm, dtype=np.float64),
+                u=np.asarray(u, dtype=np.float64), uprev=np.asarray(uprev, dtype=np.float64))
+
+
+def parity_probe_check(sample, name, L, N):
+    """max |u_gpu - u_oracle| (duffing.py:857-861: the input the loop applies) of the sampled trajectories, oracle in a child process
+    that never touches the GPU: the figure covers lift, condensed build and box QP of the timed state."""
+    import tempfile
+
     with tempfile.TemporaryDirectory() as td:
         path = os.path.join(td, "probe.npz")
-        np.savez(path, name=name, L=L, N=N, X=Xpre, A=A, B=Bm, C=Cm, u=u, uprev=uprev)
+        np.savez(path, name=name, L=L, N=N, **sample)
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--probe-worker", path], capture_output=True, text=True, timeout=300)
     if out.returncode != 0:
         return {"error": out.stderr.strip()[-200:]}
     return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def parity_probe(loop, name, L, N, step_next, nprobe=8, check=True):
+    sample = parity_probe_step(loop, name, step_next, nprobe)
+    return parity_probe_check(sample, name, L, N) if check else None
+
+
+def host_cores():
+    """Host cores this process may use: the scheduler affinity mask, capped by the cgroup CPU quota when the box has one (a quota
+    below the mask would time-slice the workers: their settle phase alone would outlast the budget).  Returns (cores, note)."""
+    aff = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]  # cgroup v2
+        if q != "max":
+            quota = float(q) / float(per)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    cores = aff if quota is None else max(1, min(aff, int(quota + 0.999)))
+    cap = int(os.environ.get("KMPC_BENCH_CPU_CORES", "0"))  # (measurement aid: fewer workers)
+    if cap > 0:
+        cores = min(cores, cap)
+    return max(1, cores), "affinity mask %d cores, cgroup quota %s, os.cpu_count() %s" % (aff, "none" if quota is None else "%.1f" % quota, os.cpu_count())
 
 
 def cpu_baseline(name, L, N, x0s, budget_s, settle):
@@ -275,7 +310,7 @@ def cpu_baseline(name, L, N, x0s, budget_s, settle):
     import multiprocessing as mp
 
     post = 8
-    cores = max(1, min(16, os.cpu_count() or 1))  # a one-GPU box comes with 16 host cores
+    cores, cores_note = host_cores()  # every core the process may run on, stated in the line
     solver = "exact" if name == "cfg4" else "lbfgsb"
     per = max(1, min(64 if name == "cfg4" else 1 << 30, x0s.shape[1] // (cores + 2)))
     jobs = [(name, L, N, x0s[:, i * per:(i + 1) * per], budget_s, solver, settle, post) for i in range(cores)]
@@ -294,7 +329,8 @@ def cpu_baseline(name, L, N, x0s, budget_s, settle):
     exact = _cpu_worker((name, L, N, x0s[:, cores * per:(cores + 1) * per], budget_s / 2.0, "exact", min(settle, 40), post)) if solver != "exact" else None
     return {"all": (rate, done, busy, cores, wall), "transient": (trate, tdone, tbusy),
             "one": (done / busy if busy > 0 else 0.0, done, busy),
-            "exact": ((exact[0] / exact[1]) if exact and exact[1] > 0 else None), "settle": settle, "post": post, "solver": solver}
+            "exact": ((exact[0] / exact[1]) if exact and exact[1] > 0 else None), "settle": settle, "post": post, "solver": solver,
+            "cores_note": cores_note}
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -342,13 +378,15 @@ class Loop:
         self.comm, self.native = None, False
         if self.shared and os.environ.get("KMPC_BENCH_PY_SHARED_LOOP") is None:
             import torch.distributed as dist
-            from koopmpc.sharding import NcclCommunicator, force_collectives
+            from koopmpc.sharding import force_collectives
 
             pg = dist.is_available() and dist.is_initialized()
             if not pg or (dist.get_world_size() == 1 and not force_collectives()):
                 self.native = True
             elif dist.get_backend() != "gloo":
-                self.comm = NcclCommunicator(dev)
+                from koopmpc.sharding import process_communicator
+
+                self.comm = process_communicator(dev)  # ONE RCCL communicator per process, shared by every Loop
                 self.native = True
 
     def advance(self, steps, step0):
@@ -367,6 +405,7 @@ class Loop:
                 self.m.shared_step(self.X, self.r, plant="tank", switched=(k > 100))
 
 
+SWITCH_WINDOW_START = 95  # the `switch_window` leg times K steps from here (the plant switches at step 102, duffing.py:991-992)
 FP64_PEAK_TFLOPS = 78.6  # /opt/skills/guides/MI355X_MICROARCH.md: fp64 vector / matrix peak (spec)
 FP32_PEAK_TFLOPS = 157.3  # fp32 vector peak (spec, packed): the float32 legs
 
@@ -447,12 +486,26 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
 
     # ---- the workload's controller: set-up (offline fit, settle), warm-up (untimed), then EXACTLY --steps timed steps
     main_loop = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
-    main_loop.advance(settle, 0)
-    main_loop.advance(args.warmup, settle)
-    torch.cuda.synchronize(dev)
     step0 = settle + args.warmup
     can_snap = not main_loop.shared
+    # (the state before the W warm-up steps is kept: a replica of the timed region starts there and runs the warm-up as a launch of its
+    #  own, exactly as the headline's controller did -- so that its placement by solver work comes from the steps BEFORE the timed
+    #  ones, not from a replica of the steps it is about to time: ADVICE r4)
+    pre = args.warmup if can_snap else 0
+    main_loop.advance(settle, 0)
+    snap_pre = (main_loop.m.state_to(), main_loop.X.clone()) if pre else None
+    main_loop.advance(args.warmup, settle)
+    torch.cuda.synchronize(dev)
     snap = (main_loop.m.state_to(), main_loop.X.clone()) if can_snap else None
+
+    def replica_start(loop):
+        """bring `loop` to the state and the placement the headline's controller had when its timed region began"""
+        if snap_pre is not None:
+            loop.m.state_from(snap_pre[0]); loop.X.copy_(snap_pre[1])
+            loop.advance(pre, step0 - pre)
+        else:
+            loop.m.state_from(snap[0]); loop.X.copy_(snap[1])
+            loop.advance(0, step0)
     scratch = None
     if spin_seconds > 0 or extras:
         scratch = Loop(name, w, B, dtype, dev, rank, cold=args.cold_start, threads=args.threads)
@@ -521,13 +574,10 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
     if extras and scratch is not None:
         if can_snap and not args.cold_start:
             cold = Loop(name, w, B, dtype, dev, rank, cold=True, threads=args.threads)
-            # (as for the headline, whose controller has launched before: one untimed replica of the region gives the cold handle its
-            #  placement by solver work; then the state is restored and -- a call without steps -- converted to the wave image)
-            cold.m.state_from(snap[0]); cold.X.copy_(snap[1])
-            cold.advance(args.steps, step0)
-            cold.m.state_from(snap[0]); cold.X.copy_(snap[1])
-            cold.advance(0, step0)
+            # (as the headline's controller, the cold one has run the window in front of the timed one: its placement by solver work
+            #  comes from those steps, not from a replica of the steps it is about to time -- ADVICE r4)
             respin()
+            replica_start(cold)
             dtc = timed(cold, args.steps, step0, profile=True)
             fk, fw, kms = leg_fracs(cold, dtc)
             ex["cold_start"] = {"value": B * world * args.steps / dtc, "ms_per_step": dtc / args.steps * 1e3,
@@ -545,6 +595,44 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
                             "newton_solves_per_step": float(fresh.m.iters.double().mean().item()) / (max(1, args.steps) if (not fresh.shared or fresh.native) else 1),
                             "note": "the same %d steps after %d warm-up steps counted from the RLS reset (no settle steps)" % (args.steps, args.warmup)}
         del fresh
+        if can_snap and not args.cold_start:
+            # ---- the timed window again, >= 5 times on the scratch controller (each replica restored and given the preceding window
+            #      like the headline): the spread of the dominant kernel's duration, so that a reader sees which side of a line the
+            #      median sits on.  `value` stays the one timed window above.
+            reps = []
+            respin()
+            for _ in range(max(0, args.replicas)):
+                replica_start(scratch)
+                dtr = timed(scratch, args.steps, step0, profile=True)
+                fk, fw, kms = leg_fracs(scratch, dtr)
+                reps.append((fk, fw, kms, B * world * args.steps / dtr))
+            if reps:
+                fr = sorted(r[0] for r in reps)
+                ex["replicas"] = {"n": len(reps), "frac_min": fr[0], "frac_median": fr[len(fr) // 2], "frac_max": fr[-1],
+                                  "kernel_ms": [round(r[2], 5) if r[2] else None for r in reps],
+                                  "value_median": sorted(r[3] for r in reps)[len(reps) // 2]}
+            # ---- the window that CONTAINS the plant-parameter switch (duffing.py:991-992: after iteration 101): K steps from step 95
+            #      of a run that started at the RLS reset, as the reference's experiment does -- the controller while its model moves
+            sw0 = max(0, SWITCH_WINDOW_START - (0 if args.steps <= 40 else 0))
+            if sw0 + args.steps > 102 and sw0 >= args.warmup:
+                swl = Loop(name, w, B, dtype, dev, rank, cold=False, threads=args.threads)
+                swl.advance(sw0 - args.warmup, 0)
+                swl.advance(args.warmup, sw0 - args.warmup)  # (the W steps in front as a launch of their own, like the headline's warm-up)
+                respin()
+                dts = timed(swl, args.steps, sw0, profile=True)
+                fk, fw, kms = leg_fracs(swl, dts)
+                ex["switch_window"] = {"value": B * world * args.steps / dts, "ms_per_step": dts / args.steps * 1e3, "frac": fk, "wall_frac": fw,
+                                       "kernel_ms": kms, "newton_solves_per_step": float(swl.m.iters.double().mean().item()) / max(1, args.steps),
+                                       "worst_status": int(swl.m.status.max().item()), "finite": bool(torch.isfinite(swl.X).all().item()),
+                                       "steps": [sw0, sw0 + args.steps],
+                                       "note": "steps %d..%d counted from the RLS reset; the plant's parameters switch at step 102 inside the window" % (sw0, sw0 + args.steps - 1)}
+                if probe and rank == 0:
+                    try:
+                        ppz = parity_probe(swl, name, L, N, sw0 + args.steps)
+                        ex["switch_window"]["parity_probe_max_abs_u_err"] = (ppz or {}).get("max_abs_u_err")
+                    except Exception as e:
+                        ex["switch_window"]["parity_probe_max_abs_u_err"] = "%s: %s" % (type(e).__name__, e)
+                del swl
 
     if dist is not None:
         flag = torch.tensor([worst_status, 0 if x_ok else 1], device=dev if args.backend == "nccl" else "cpu")
@@ -573,12 +661,15 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
     flop_peak = FP32_PEAK_TFLOPS if args.dtype == "f32" else FP64_PEAK_TFLOPS
     flop_frac = tflops / flop_peak
     compute_bound = (c.get("lift") == "rbf" and L <= 8)
+    # (a compute-bound set is priced on the flops its kernels EXECUTE -- Toeplitz H / f by prefix sums, gain-form RLS --; SURVEY 8d's
+    #  dense-H count, 86 % of cfg3's nominal figure, is kept beside it as `nominal_flop_frac`: VERDICT r4 item 7)
     roof = {
         "bound": "fp64_valu" if compute_bound else "hbm",
-        "achieved": tflops if compute_bound else achieved,
+        "achieved": exec_tflops if compute_bound else achieved,
         "peak": flop_peak if compute_bound else HBM_PEAK_GBS,
         "unit": "TFLOP/s" if compute_bound else "GB/s",
-        "frac": flop_frac if compute_bound else hbm_frac,
+        "frac": exec_tflops / flop_peak if compute_bound else hbm_frac,
+        "nominal_flop_frac": flop_frac,
         "traffic": traffic,
         "kernel": kname,
         "avg_kernel_ms": launch_ms,
@@ -594,6 +685,8 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
     }
     if traffic_src:
         roof["traffic_source"] = traffic_src
+    if args.dtype == "f32":  # (float32 panels, float64 state: the same launch priced at the float64 formula's bytes as well)
+        roof["hbm_frac_f64_state"] = hbm_frac * 2.0
     if qp_launch_ms is not None:
         roof["qp_launches_ms"] = qp_launch_ms  # shared_fast_kernel + step_qp_kernel between HIP events
     # (frac: over the leg's kernel duration, as the headline's; wall_frac: over the wall time of its region)
@@ -605,13 +698,27 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
         roof["post_reset_frac"] = ex["post_reset"]["frac"]
         roof["post_reset_wall_frac"] = ex["post_reset"]["wall_frac"]
         roof["post_reset_value"] = ex["post_reset"]["value"]
+        roof["post_reset_newton_solves_per_step"] = ex["post_reset"]["newton_solves_per_step"]
+    if "replicas" in ex:
+        roof["replicas"] = ex["replicas"]
+    if "switch_window" in ex:
+        sw = ex["switch_window"]
+        roof["switch_window_frac"] = sw["frac"]
+        roof["switch_window_wall_frac"] = sw["wall_frac"]
+        roof["switch_window_value"] = sw["value"]
+        roof["switch_window"] = {k: sw[k] for k in ("steps", "kernel_ms", "newton_solves_per_step", "worst_status", "finite") if k in sw}
+        roof["switch_window"]["parity_probe_max_abs_u_err"] = sw.get("parity_probe_max_abs_u_err")
     pp = None
     if probe:
-        try:
-            pp = parity_probe(main_loop, name, L, N, step0 + args.steps, check=(rank == 0))
-        except Exception as e:  # (the probe must not take the measurement with it; it is reported)
-            pp = {"error": "%s: %s" % (type(e).__name__, e)}
+        # (the probe's extra control step runs on EVERY rank and, for the shared model, holds a collective: it is outside the guard --
+        #  a rank that fails there must fail the job, not leave the others waiting in an all-reduce; only rank 0's host-side check,
+        #  a child process, is guarded)
+        sample = parity_probe_step(main_loop, name, step0 + args.steps)
         if rank == 0:
+            try:
+                pp = parity_probe_check(sample, name, L, N)
+            except Exception as e:  # (the check must not take the measurement with it; it is reported)
+                pp = {"error": "%s: %s" % (type(e).__name__, e)}
             roof["parity_probe_max_abs_u_err"] = pp.get("max_abs_u_err")
     return {"dt": dt, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "roofline": roof, "extras": ex,
             "worst_status": worst_status, "x_ok": x_ok, "newton_per_step": newton_per_step, "newton_max": newton_max,
@@ -637,6 +744,7 @@ def main():
     ap.add_argument("--spin-seconds", type=float, default=1.0,
                     help="untimed GPU activity on a scratch copy of the workload before the warm-up, so that the "
                          "clocks have left their idle state when the W warm-up steps start")
+    ap.add_argument("--replicas", type=int, default=5, help="replicas of the timed window whose kernel-time spread is reported (roofline.replicas)")
     ap.add_argument("--no-extras", action="store_true", help="skip the cold-start / post-reset measurements and the other configurations' legs")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="process-group backend for --gpus N > 1: nccl (= RCCL, one GPU per rank) or gloo (rehearsal of the "
@@ -707,30 +815,44 @@ def main():
     if name == "cfg2" and world == 1 and not args.no_extras and not (args.batch or args.L or args.N or args.cold_start):
         import copy
 
-        def leg(oname, a_, label=None):
+        def leg(oname, a_, label=None, batch=0):
             oc = CONFIGS[oname]
             try:
-                o = measure_config(oname, a_, None, dev, 0, 1, oc["L"], oc["N"], oc["B"], oc["settle"], extras=False, spin_seconds=0.3,
-                                   probe=not args.no_probe)
+                o = measure_config(oname, a_, None, dev, 0, 1, oc["L"], oc["N"], batch or oc["B"], oc["settle"], extras=False, spin_seconds=0.3,
+                                   probe=not a_.no_probe)
                 ro = o["roofline"]
                 # [steps/s, frac of the governing roofline, bound, kernel ms per launch, steps per launch, worst QP status, finite,
                 #  parity probe max |u - u_oracle|, executed-flop fraction]
                 others[label or oname] = [o["value"], ro["frac"], ro["bound"], ro["avg_kernel_ms"], ro["steps_per_launch"], o["worst_status"],
                                           o["x_ok"], ro.get("parity_probe_max_abs_u_err"), ro["executed_flop_frac"]]
+                if ro["bound"] != "hbm":  # (compute-bound set: frac is over the executed flops, the nominal dense-H figure beside it)
+                    others[label or oname].append({"nominal_flop_frac": ro["nominal_flop_frac"]})
+                if a_.dtype == "f32":
+                    others[label or oname].append({"io": "float32 panels, float64 state and arithmetic inside the launch (SURVEY G6)", "fused": ro["steps_per_launch"] > 1,
+                                                   "hbm_frac_on_f64_state_bytes": ro.get("hbm_frac_f64_state")})
             except Exception as e:  # (a leg that fails must not take the headline with it; it is reported)
                 others[label or oname] = {"error": "%s: %s" % (type(e).__name__, e)}
             torch.cuda.empty_cache()
 
         for oname in ("cfg4", "cfg3", "cfg3-L20", "cfg5"):
             leg(oname, args)
-        # BASELINE's configs[1] names fp32: the same workload with float32 arithmetic -- reported beside the float64 headline, never in
-        # place of it (the 1e-6 bar on u needs float64)
-        if args.dtype == "f64" and os.environ.get("KMPC_BENCH_F32_LEG"):
+        # the headline's kernel with a state that no longer fits the 256 MB Infinity Cache (348 MB at 16384 trajectories; four rounds of
+        # workgroups): does the rate hold when the state really streams from HBM?  
+        leg("cfg2", args, "cfg2-B16384", batch=16384)
+        # BASELINE's configs[1] names fp32: the same workload behind float32 panels -- reported beside the float64 headline, never in
+        # place of it (the 1e-6 bar on u needs float64 arithmetic; the state and the arithmetic stay float64 in the launch)
+        if args.dtype == "f64" and not os.environ.get("KMPC_BENCH_NO_F32_LEG"):
             a32 = copy.copy(args)
             a32.dtype = "f32"
-            a32.no_probe = True
             leg("cfg2", a32, "cfg2-f32")
 
+    # how many ranks RCCL itself reports (ncclCommCount of this process's communicator -- the one the shared-model loop all-reduces
+    # on; a per-trajectory configuration creates one here, after the measurement, only to be able to say so): lets SCALE be checked
+    rccl_ranks_seen = None
+    if dist is not None and args.backend == "nccl":
+        from koopmpc.sharding import process_communicator
+
+        rccl_ranks_seen = process_communicator(dev).count()
     if rank == 0:
         total = B * world
         roof = res["roofline"]
@@ -754,7 +876,8 @@ def main():
                 "workload": (c["text"] if args.verbose_line else name) + "; %d trajectories per GPU x %d GPU(s); %d settle steps after the RLS reset + the "
                             "warm-up are set-up; arithmetic in %s" % (B, world, settle, args.dtype),
                 "global_batch": total,
-                "process_group": {"world_size": pg_world, "backend": pg_backend, "ranks_share_device": bool(args.same_device)},
+                "process_group": {"world_size": pg_world, "backend": pg_backend, "ranks_share_device": bool(args.same_device),
+                                  "rccl_ranks_seen": rccl_ranks_seen},
                 **({"rehearsal": "ranks share cuda:0 / gloo collectives: exercises the multi-rank code path, NOT a scaling measurement"}
                    if (args.same_device or (world > 1 and args.backend != "nccl")) else {}),
                 "parallelism": ("trajectory-sharded x%d, one RCCL all-reduce of the %d-element Gram block per step" % (world, (2 * L + 3) * (L + 1))) if res["shared"]
@@ -785,7 +908,7 @@ def main():
                           "trajectory-steps in %.1f core-seconds (%.1f s wall); NumPy oracle, %s; host has %d cores"
                           % (cores, cpu["settle"], done, busy, wall,
                              "SciPy L-BFGS-B as duffing.py:857-859" if cpu["solver"] == "lbfgsb" else "exact active-set QP in place of quadprog, one pooled model per worker",
-                             os.cpu_count()),
+                             os.cpu_count()) + "; " + cpu["cores_note"],
                 "regime": regime,
                 "single_core_value": cpu["one"][0],
                 "post_reset_value": tv,
@@ -793,7 +916,10 @@ def main():
             }
         print(json.dumps(out), flush=True)
     if dist is not None:
+        from koopmpc.sharding import destroy_process_communicator
+
         dist.barrier()
+        destroy_process_communicator()
         dist.destroy_process_group()
 
 

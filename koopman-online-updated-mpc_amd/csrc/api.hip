@@ -835,6 +835,8 @@ struct Impl : kmpc_handle {
         HIPCHK(hipMemsetAsync(dWork, 0, sizeof(int32_t) * (size_t)B, s));
       }
       r.work = dWork;
+      static const int tail = dbg_env("KMPC_PLACE_TAIL") ? atoi(dbg_env("KMPC_PLACE_TAIL")) : 5;  // (measurement aid; 0 = the whole launch)
+      r.work_tail = tail;
       // ... across the workgroups too where the batch allows the card deal (whole workgroups; the rank kernel is O(B^2 / lanes))
       if (place_valid && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= 16384 && !dbg_env("KMPC_ROLLOUT_NO_GLOBAL_PLACE")) r.perm = dPerm;
     }

@@ -127,6 +127,12 @@ template <typename T> struct RolloutArgs {
   // waves of the SIMDs -- served first -- take the expensive solves, the youngest, whose end is the step's end, the cheap ones (the
   // 20-step launch of cfg2: - 5 %).  Results do not depend on it (a trajectory's arithmetic is its own).  Null: wave w takes trajectory w.
   int32_t* work;
+  // ... counted over the LAST work_tail steps of a launch only (0: all of them).  What predicts the next launch's solver work is the
+  // recent state of a trajectory's solver -- a carried tableau about to go stale, a set that keeps changing --, not its history: ranked by
+  // the work of a whole 20-step window the deal made the driver's window 4 % SLOWER than no placement at all (0.714 against 0.69 ms; the
+  // four heaviest strata are then reliably the heaviest and sit on waves 0-3 of every workgroup, the lightest on 12-15), ranked by the
+  // last 5 steps 6 % faster (0.645 ms; profiles/r5_cfg2_placement_window.txt)
+  int work_tail;
   // perm [B] (optional, B a multiple of 16): slot -> trajectory for the WHOLE batch, written by place_kernel from `work` after the
   // previous launch: the trajectories sorted by work are dealt like cards -- the G heaviest to wave 0 of the G workgroups, the next G
   // to wave 1 in reverse order (snake), ... -- so that every workgroup gets one trajectory of each of sixteen work strata (equal sums:

@@ -22,6 +22,14 @@
 #pragma once
 #include "step_body.h"
 
+// experiment (EXTRA=-DKMPC_EXP_PRIO2): a solve that turns out to be heavy (a rebuild of the tableau, a second Newton iteration) raises
+// its wave's issue priority -- longest remaining work first, decided when the work is known instead of predicted from the last launch
+#ifdef KMPC_EXP_PRIO2
+#define EXP_HEAVY() __builtin_amdgcn_s_setprio(3)
+#else
+#define EXP_HEAVY()
+#endif
+
 namespace kmpc {
 
 // sum over the lanes of each half (lanes 0-31 / 32-63); every lane gets its half's sum
@@ -220,6 +228,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   unsigned Smask = carried ? cs.smask : 0u;
   if (half || !carried) load_h_rows();  // H rows; without a carried tableau also in lanes 0-31 (T = 2H below)
   if (!carried) {
+    EXP_HEAVY();
     if (!half) {
 #pragma unroll
       for (int j = 0; j < N_; ++j) M[j] *= 2.0;
@@ -301,6 +310,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
       for (int pass = 0; pass < 2; ++pass) {
         if (rebuild) {  // T = 2H, nothing swept in
           KCOUNT(++tc_rebuild);
+          EXP_HEAVY();
           if (!half) {
             load_h_rows();
 #pragma unroll
@@ -316,6 +326,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
           // (a saturated solution met from the all-free tableau, or the other way round)
           if (__builtin_popcount(Smask ^ Fmask) > __builtin_popcount(Fmask) + 2) {
             KCOUNT(++tc_rebuild);
+            EXP_HEAVY();
             if (!half) {
               load_h_rows();
 #pragma unroll
@@ -439,6 +450,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     if (Jok) J0 = Ja;
     if (it == 0) KTRACE(12);
     ++it;
+    EXP_HEAVY();
   }
   KTRACE(13);
 #ifdef KMPC_TRACE

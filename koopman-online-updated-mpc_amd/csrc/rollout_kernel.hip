@@ -159,6 +159,9 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
 #ifdef KMPC_TRACE
     if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 16] = wall_clock64();  // this wave is ready for step k
 #endif
+    if constexpr (!RBF) {  // (RolloutArgs::work_tail: the solver work that ranks the next launch is that of the last steps)
+      if (R.work_tail > 0 && k == R.steps - R.work_tail && lane == 0) ((lds_i32*)reinterpret_cast<int*>(sXn + wv * 4 + 2))[2] = 0;
+    }
     double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
     if constexpr (RBF) {
       if (live && (lane & PSI_MASK) < L) {
@@ -396,7 +399,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
     if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 17] = wall_clock64();  // lift done
     if (lane == 0 && b < 8192 && k == 0) {
       kmpc_trace_buf[b * 32 + 19] = wall_clock64();
-      for (int sl = 22; sl < 28; ++sl) kmpc_trace_buf[b * 32 + sl] = 0ull;  // (qp_rl's work counters: summed over the launch)
+      for (int sl = 22; sl < 30; ++sl) kmpc_trace_buf[b * 32 + sl] = 0ull;  // (qp_rl's work counters: summed over the launch)
     }
 #endif
     if (live) {

@@ -24,6 +24,19 @@
 #include <type_traits>
 #include "qp_rl.h"
 
+// experiment (make dev EXTRA=-DKMPC_EXP_PRIO): issue priority by progress through the step -- the waves of a SIMD that lag get served
+// first, so that the four of them finish together instead of oldest-first one after the other
+#ifdef KMPC_EXP_PRIO
+#define EXP_PRIO(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define EXP_PRIO(p)
+#endif
+#ifdef KMPC_EXP_PRIO2  // (qp_rl.h: EXP_HEAVY)
+#define EXP_PRIO2(p) __builtin_amdgcn_s_setprio(p)
+#else
+#define EXP_PRIO2(p)
+#endif
+
 namespace kmpc {
 
 // ---------------------------------------------------------------------------------------
@@ -230,6 +243,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   double* const qg = qxa + N;
 
   KTRACE(0);
+  EXP_PRIO(3);
+  EXP_PRIO2(1);
   const double up = uniform_value(a.u_prev[b]);  // (one trajectory per wave: scalar registers; K = 200 - 2 %)
   double xw_pre = 0.0;
   constexpr int REFN = (Q_ * N_ + 63) / 64;
@@ -320,6 +335,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     }
   }
 
+  EXP_PRIO(2);
   // =====================================================================================
   // phase 2: condensed QP.  v_{j+1} = A v_j (v_0 = B) in lanes 0-31, w_{j+1} = A w_j (w_0 = psi) in lanes 32-63; the rows of C
   // in the same registers give g_j = C_o v_j and C_o w_j.  Every lane writes its value of the step to LDS -- the output rows
@@ -452,9 +468,13 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   // phase 3: box QP (rows in lanes, carried tableau: qp_rl.h)
   // =====================================================================================
   if (sv.phases & PH_QP) {
+    EXP_PRIO(1);
     if (qp_rl<N_>(sR, sf, a, sv, b, qxo, red + 15, M, rs, rsi, cs, up, xw_pre)) {
       // crawling solve (rare): H moves to this trajectory's global scratch block, the active-set loop of qp_lds works with an
       // LDS tableau in its place
+#ifdef KMPC_TRACE
+      if (tid == 0 && b < 8192) kmpc_trace_buf[b * 32 + 28] += 1ull;
+#endif
       block_sync<64>();
       double* const Hg = a.qp_scratch + (size_t)b * N * N;
       for (int e = tid; e < N * N; e += 64) Hg[e] = sR[(e / N) * rl_stride(N_) + (e % N)];
@@ -477,6 +497,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       ci[3] = cs.trust;
     }
     block_sync<64>();
+    EXP_PRIO(0);
+    EXP_PRIO2(0);
     if (sv.cov_ahead) {
       // the covariance half of the NEXT step's update: its regressor [psi(x_k); u_k] is complete now
       const double uk = (a.du_mode ? up : 0.0) + red[15];  // (the solve leaves its first move there)

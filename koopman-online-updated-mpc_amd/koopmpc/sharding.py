@@ -37,11 +37,45 @@ def max_over_ranks(value, device=None):
     return float(t.item())
 
 
+def exchange_unique_id(idb, device=None):
+    """Rank 0's 128-byte RCCL unique id to every rank of the default process group, validated: every rank must hold the same bytes
+    before anyone calls ncclCommInitRank (which blocks until all ranks have joined -- a rank with another id would hang the job, so a
+    mismatch raises on EVERY rank instead).  idb: the id on rank 0, ignored elsewhere.  Returns the 128 bytes."""
+    import hashlib
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    world, rank = dist.get_world_size(), dist.get_rank()
+    on_dev = dist.get_backend() != "gloo"
+    raw = torch.frombuffer(bytearray(idb if rank == 0 else bytes(128)), dtype=torch.uint8).clone()
+    if on_dev:
+        raw = raw.to(device if device is not None else "cuda")
+    dist.broadcast(raw, src=0)
+    got = bytes(raw.cpu().numpy().tobytes())
+    if os.environ.get("KMPC_TEST_CORRUPT_UID_RANK") == str(rank):  # (test hook: tests/test_host_cpu.py)
+        got = bytes([got[0] ^ 0xFF]) + got[1:]
+    h = int.from_bytes(hashlib.sha256(got).digest()[:7], "little")
+    mine = torch.tensor([h], dtype=torch.int64)
+    if on_dev:
+        mine = mine.to(raw.device)
+    seen = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(seen, mine)
+    hs = [int(v.item()) for v in seen]
+    if any(v != hs[0] for v in hs):
+        raise RuntimeError("RCCL unique id differs between the ranks (rank %d holds %x; all: %s)" % (rank, h, [hex(v) for v in hs]))
+    return got
+
+
 class NcclCommunicator:
     """An RCCL communicator of this process's own for the native shared-model loop (kmpc_shared_rollout): rank 0 draws the unique id,
-    torch.distributed's default process group carries it to the other ranks (any backend: it is 128 bytes), every rank joins with
-    ncclCommInitRank.  Without a process group: a one-rank communicator.  The RCCL is the one that lives in the process (torch's own
-    copy when it exports the symbols, else the system librccl) -- the one kmpc_shared_rollout resolves ncclAllReduce from."""
+    torch.distributed's default process group carries it to the other ranks (any backend: it is 128 bytes), every rank checks that all
+    ranks hold the SAME id (a hash all-gather: a rank that joined with another id would hang ncclCommInitRank for everybody) and
+    joins with ncclCommInitRank.  Without a process group: a one-rank communicator.  The RCCL is the one that lives in the process
+    (torch's own copy when it exports the symbols, else the system librccl) -- the one kmpc_shared_rollout resolves ncclAllReduce from.
+    Use `process_communicator()` for the one communicator a process needs; `with NcclCommunicator(...) as c:` / `destroy()` / garbage
+    collection release it (ncclCommDestroy: device buffers, proxy threads, xGMI channels)."""
 
     def __init__(self, device=None):
         import ctypes as C
@@ -49,6 +83,7 @@ class NcclCommunicator:
         import torch
         import torch.distributed as dist
 
+        self.handle = None
         proc = C.CDLL(None)
         try:
             proc.ncclCommInitRank
@@ -68,11 +103,7 @@ class NcclCommunicator:
             if rc != 0:
                 raise RuntimeError("ncclGetUniqueId failed with code %d" % rc)
         if world > 1:
-            raw = torch.frombuffer(bytearray(bytes(uid)), dtype=torch.uint8).clone()
-            if dist.get_backend() != "gloo":
-                raw = raw.to(device if device is not None else "cuda")
-            dist.broadcast(raw, src=0)
-            C.memmove(C.byref(uid), bytes(raw.cpu().numpy().tobytes()), 128)
+            C.memmove(C.byref(uid), exchange_unique_id(bytes(uid) if rank == 0 else None, device), 128)
         if device is not None:
             torch.cuda.set_device(device)
         comm = C.c_void_p()
@@ -81,6 +112,21 @@ class NcclCommunicator:
         if rc != 0:
             raise RuntimeError("ncclCommInitRank failed with code %d" % rc)
         self.handle, self.world, self.rank = comm, world, rank
+        n = self.count()
+        if n != world:
+            self.destroy()
+            raise RuntimeError("NcclCommunicator: RCCL reports %d ranks, the process group has %d" % (n, world))
+
+    def count(self):
+        """ncclCommCount: the number of ranks RCCL itself sees in this communicator."""
+        import ctypes as C
+
+        n = C.c_int(-1)
+        self.rccl.ncclCommCount.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        rc = self.rccl.ncclCommCount(self.handle, C.byref(n))
+        if rc != 0:
+            raise RuntimeError("ncclCommCount failed with code %d" % rc)
+        return int(n.value)
 
     def destroy(self):
         import ctypes as C
@@ -89,3 +135,35 @@ class NcclCommunicator:
             self.rccl.ncclCommDestroy.argtypes = [C.c_void_p]
             self.rccl.ncclCommDestroy(self.handle)
             self.handle = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.destroy()
+        return False
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:  # (interpreter shutdown: the library may be gone already)
+            pass
+
+
+_process_comm = None
+
+
+def process_communicator(device=None):
+    """THE RCCL communicator of this process (created on first use, shared by every controller: a communicator pins device buffers,
+    proxy threads and xGMI channels for as long as it lives -- one per process is all the path needs)."""
+    global _process_comm
+    if _process_comm is None or _process_comm.handle is None:
+        _process_comm = NcclCommunicator(device)
+    return _process_comm
+
+
+def destroy_process_communicator():
+    global _process_comm
+    if _process_comm is not None:
+        _process_comm.destroy()
+        _process_comm = None

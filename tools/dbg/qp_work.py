@@ -15,14 +15,15 @@ name = "cfg2"
 c = bench.CONFIGS[name]; w = bench.workload_inputs(name, c["L"], c["N"])
 B, G = 4096, 16
 loop = bench.Loop(name, w, B, torch.float64, torch.device("cuda", 0), 0, cold=cold)
-loop.advance(c["settle"], 0); loop.advance(5, c["settle"]); torch.cuda.synchronize()
+start = int(os.environ.get("KMPC_QPW_START", c["settle"] + 5))  # first step of the traced window, counted from the RLS reset
+loop.advance(start - 5, 0); loop.advance(5, start - 5); torch.cuda.synchronize()
 import time
 t0 = time.time()
 snap = (loop.m.state_to(), loop.X.clone())
 while time.time() - t0 < 1.0:
-    loop.m.state_from(snap[0]); loop.X.copy_(snap[1]); loop.advance(steps, c["settle"] + 5); torch.cuda.synchronize()
+    loop.m.state_from(snap[0]); loop.X.copy_(snap[1]); loop.advance(steps, start); torch.cuda.synchronize()
 loop.m.state_from(snap[0]); loop.X.copy_(snap[1]); loop.m.iters.zero_()
-loop.advance(steps, c["settle"] + 5); torch.cuda.synchronize()
+loop.advance(steps, start); torch.cuda.synchronize()
 lib = _ffi.load()
 buf = np.zeros(8192 * 32, dtype=np.uint64)
 lib.kmpc_trace_read.restype = C.c_int; lib.kmpc_trace_read.argtypes = [C.c_void_p, C.c_size_t]
@@ -34,12 +35,14 @@ carried, easy = t[:, 27] % 1000, t[:, 27] // 1000
 body = t[:, 21] / 100.0 / steps
 print("%d-step launch (%s start): per trajectory-step means: sweeps %.3f rebuilds %.3f refinement passes %.3f iterations %.3f prediction rounds %.3f backtracks %.3f"
       % (steps, "cold" if cold else "warm", sw.mean() / steps, rb.mean() / steps, ps.mean() / steps, it.mean() / steps, rounds.mean() / steps, ls.mean() / steps))
+fb = t[:, 28]
+print("window: steps %d..%d from the RLS reset; fall-back (active-set on global scratch) solves per trajectory-step %.4f (trajectories with any: %d)" % (start, start + steps - 1, fb.mean() / steps, int((fb > 0).sum())))
 print("solves that began with a carried tableau: %.3f; 'easy' solves (one iteration, no sweep, no rebuild, no round): %.3f" % (carried.mean() / steps, easy.mean() / steps))
 print("distribution over trajectories of easy steps out of %d: " % steps, np.bincount(easy.astype(int), minlength=steps + 1).tolist())
 print("refinement passes per trajectory-step, histogram of the per-trajectory mean (bins of 0.5):", np.histogram(ps / steps, bins=np.arange(0, 8.5, 0.5))[0].tolist())
-A = np.stack([np.ones(B), sw / steps, rb / steps, ps / steps, it / steps, rounds / steps], 1)
+A = np.stack([np.ones(B), sw / steps, rb / steps, ps / steps, it / steps, rounds / steps, ls / steps, fb / steps], 1)
 coef = np.linalg.lstsq(A, body, rcond=None)[0]
-print("body us/step ~ %.2f + %.2f sweeps + %.2f rebuilds + %.2f passes + %.2f iterations + %.2f rounds  (least squares over the waves)" % tuple(coef))
+print("body us/step ~ %.2f + %.2f sweeps + %.2f rebuilds + %.2f passes + %.2f iterations + %.2f rounds + %.2f backtracks + %.2f fall-backs  (least squares over the waves)" % tuple(coef))
 wgfin = (t[:, 18].reshape(-1, G).max(1) - t[:, 19].min()) / 100.0
 order = np.argsort(wgfin)
 print("workgroup finish: min %.0f p10 %.0f median %.0f p90 %.0f max %.0f us" % (wgfin.min(), np.percentile(wgfin, 10), np.median(wgfin), np.percentile(wgfin, 90), wgfin.max()))
@@ -50,6 +53,14 @@ for label, sel in (("fastest 10%", order[:len(order) // 10]), ("middle 20%", ord
     print("  %-12s finish %.0f us | per trajectory-step: sweeps %.2f (max traj %.2f) rebuilds %.3f (max %.2f) passes %.2f (max %.2f) iterations %.2f (max %.2f)" % (
         label, wgfin[sel].mean(), sw.reshape(-1, G)[sel].mean() / steps, sw.reshape(-1, G)[sel].max() / steps, rb.reshape(-1, G)[sel].mean() / steps, rb.reshape(-1, G)[sel].max() / steps,
         ps.reshape(-1, G)[sel].mean() / steps, ps.reshape(-1, G)[sel].max() / steps, it.reshape(-1, G)[sel].mean() / steps, it.reshape(-1, G)[sel].max() / steps))
+wait = t[:, 20] / 100.0 / steps
+print("per wave and step (us): body median %.2f p90 %.2f max %.2f | lift + barrier wait median %.2f p10 %.2f p90 %.2f" % (np.median(body), np.percentile(body, 90), body.max(), np.median(wait), np.percentile(wait, 10), np.percentile(wait, 90)))
+bw = body.reshape(-1, G)
+print("per workgroup: mean over waves of body %.2f, max over waves %.2f (medians over the workgroups); corr(finish, max-wave body) %.2f, corr(finish, mean body) %.2f"
+      % (np.median(bw.mean(1)), np.median(bw.max(1)), np.corrcoef(wgfin, bw.max(1))[0, 1], np.corrcoef(wgfin, bw.mean(1))[0, 1]))
+for g in order[-4:]:
+    print("   slow workgroup %3d finish %.0f us: wave bodies (us/step) %s | iterations/step %s | fall-backs %s" % (
+        g, wgfin[g], np.round(bw[g], 1).tolist(), np.round(it.reshape(-1, G)[g] / steps, 2).tolist(), fb.reshape(-1, G)[g].tolist()))
 worst = np.argsort(-body)[:12]
 print("the 12 slowest waves: body us/step, sweeps, rebuilds, passes, iterations, rounds per step")
 for b in worst:
