@@ -131,6 +131,12 @@ struct Impl : kmpc_handle {
   double* dImg = nullptr;
   long sImg = 0;
   bool use_img = false, img_valid = false, dense_valid = true;
+  // KMPC_F32 handle of a register-state dimension set (row g2: BASELINE configs[1] names fp32; SURVEY G6: fp32 panels, float64
+  // covariance): kmpc_rollout runs the float64 fused roll-out behind float32 panels.  `core` is a float64 handle of the same
+  // configuration that owns the state while roll-outs run (its wave image; psi_{k-1}, u_{k-1}, the warm start in float64); the
+  // float32 blocks of this handle are the form every other entry point works on.  Whichever side was written last is the valid one
+  // (dense_valid / img_valid as for the wave image) and the other is rebuilt on demand by a cast over the blocks (core_push / core_pull).
+  Impl<double>* core = nullptr;
   // four-wave solver (threads = 256, float64): every trajectory's last tableau and its variable set, kept from step to step
   // (StepArgs::qp_carry); any change of the model from outside forgets them (the next solve starts from 2H)
   T* dQpCarry = nullptr;
@@ -199,6 +205,16 @@ struct Impl : kmpc_handle {
         HIPCHK(hipMalloc(&dImg, sizeof(double) * (size_t)sImg * B));
       }
     }
+    if constexpr (sizeof(T) == 4) {
+      if (threads == 64 && c.output_kind != KMPC_OUT_LIFT && !c.delta_u && rollout_io32_available(n, L, N, q, c.lift_kind != KMPC_LIFT_MLP) &&
+          !dbg_env("KMPC_NO_IO32_ROLLOUT")) {  // (the variable is a measurement / test aid: float32 handles as per-step launches)
+        kmpc_config c64 = c;
+        c64.dtype = KMPC_F64;
+        core = new Impl<double>();
+        const int rc = core->init(c64);
+        if (rc) { err = "float64 core of the float32 handle: " + core->err; delete core; core = nullptr; return rc; }
+      }
+    }
     if (c.lift_kind == KMPC_LIFT_MLP) {
       if (c.layers != 2 && c.layers != 3) FAIL(-2, "layers (hidden layers) must be 2 or 3");
       if (c.hidden < 1 || c.hidden > 128) FAIL(-2, "hidden must be in 1..128");
@@ -232,6 +248,7 @@ struct Impl : kmpc_handle {
   }
 
   ~Impl() override {
+    delete core;
     for (void* ptr : {(void*)dP, (void*)dK, (void*)dQ, (void*)dC, (void*)dPsi[0], (void*)dPsi[1], (void*)dUprev, (void*)dWarm,
                       (void*)dW1, (void*)db1, (void*)dWh[0], (void*)dWh[1], (void*)dbh[0], (void*)dbh[1], (void*)dWo,
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
@@ -258,8 +275,49 @@ struct Impl : kmpc_handle {
         HIPCHK(launch_image_to_state(dImg, sImg, n, L, B, (double*)dP, sP, (double*)dK, sK, (double*)dQ, sQ, (double*)dC, sC, s));
         dense_valid = true;
       }
+    } else {
+      if (core && !dense_valid) {
+        const int rc = core_pull(s);
+        if (rc) return rc;
+        dense_valid = true;
+      }
     }
     if (will_modify) img_valid = false;
+    return 0;
+  }
+  // float32 handle <-> its float64 core: the state blocks (same strides on both sides), psi_{k-1}, u_{k-1}, the warm start, the flags
+  int core_push(hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+      int rc = core->ensure_dense(s, true);
+      if (rc) { err = core->err; return rc; }
+      HIPCHK((launch_cast<float, double>((const float*)dP, core->dP, (size_t)sP * B, s)));
+      HIPCHK((launch_cast<float, double>((const float*)dK, core->dK, (size_t)sK * B, s)));
+      HIPCHK((launch_cast<float, double>((const float*)dQ, core->dQ, (size_t)sQ * B, s)));
+      HIPCHK((launch_cast<float, double>((const float*)dC, core->dC, (size_t)sC * B, s)));
+      HIPCHK((launch_cast<float, double>((const float*)dPsi[0], core->dPsi[0], (size_t)L * B, s)));
+      HIPCHK((launch_cast<float, double>((const float*)dPsi[1], core->dPsi[1], (size_t)L * B, s)));
+      HIPCHK((launch_cast<float, double>((const float*)dUprev, core->dUprev, (size_t)B, s)));
+      HIPCHK((launch_cast<float, double>((const float*)dWarm, core->dWarm, (size_t)N * B, s)));
+      core->cur = cur; core->have_prev = have_prev; core->rls_fresh = rls_fresh; core->update_on = update_on;
+      core->cfg.P0 = cfg.P0; core->cfg.barQ0 = cfg.barQ0;
+      core->dense_valid = true; core->img_valid = false;
+    }
+    return 0;
+  }
+  int core_pull(hipStream_t s) {
+    if constexpr (sizeof(T) == 4) {
+      int rc = core->ensure_dense(s, false);
+      if (rc) { err = core->err; return rc; }
+      HIPCHK((launch_cast<double, float>(core->dP, (float*)dP, (size_t)sP * B, s)));
+      HIPCHK((launch_cast<double, float>(core->dK, (float*)dK, (size_t)sK * B, s)));
+      HIPCHK((launch_cast<double, float>(core->dQ, (float*)dQ, (size_t)sQ * B, s)));
+      HIPCHK((launch_cast<double, float>(core->dC, (float*)dC, (size_t)sC * B, s)));
+      HIPCHK((launch_cast<double, float>(core->dPsi[0], (float*)dPsi[0], (size_t)L * B, s)));
+      HIPCHK((launch_cast<double, float>(core->dPsi[1], (float*)dPsi[1], (size_t)L * B, s)));
+      HIPCHK((launch_cast<double, float>(core->dUprev, (float*)dUprev, (size_t)B, s)));
+      HIPCHK((launch_cast<double, float>(core->dWarm, (float*)dWarm, (size_t)N * B, s)));
+      cur = core->cur; have_prev = core->have_prev; rls_fresh = core->rls_fresh;
+    }
     return 0;
   }
   // (called where the model or the state is replaced from outside: set_model, reset, offline fit, checkpoint import)
@@ -270,6 +328,13 @@ struct Impl : kmpc_handle {
         img_valid = true;
       }
       dense_valid = false;  // (the roll-out writes the image)
+    } else if (core) {
+      if (!img_valid) {
+        const int rc = core_push(s);
+        if (rc) return rc;
+        img_valid = true;
+      }
+      dense_valid = false;  // (the roll-out advances the core's state)
     }
     return 0;
   }
@@ -290,6 +355,7 @@ struct Impl : kmpc_handle {
     hostb[layer].assign(b, b + rows);
     layer_set[layer] = true;
     packed_ok = false;
+    if (core) { const int rc = core->set_encoder_layer(layer, W, b, rows, cols); if (rc) { err = core->err; return rc; } }
     for (int k = 0; k < nl; ++k)
       if (!layer_set[k]) return 0;
     return finalize_encoder();
@@ -353,6 +419,7 @@ struct Impl : kmpc_handle {
     if (L_ != L || n_ != n) FAIL(-3, "centre shape does not match the configuration");
     int rc = upload_padded(dcx, cx, L, n, L, n);
     if (rc) return rc;
+    if (core && (rc = core->set_centres(cx, L_, n_))) { err = core->err; return rc; }
     centres_set = true;
     return 0;
   }
@@ -386,6 +453,7 @@ struct Impl : kmpc_handle {
   }
 
   int set_terminal_weight(const double* PN) override {
+    if (core) { const int rc = core->set_terminal_weight(PN); if (rc) { err = core->err; return rc; } }
     wterm_from_dare = false;
     if (!PN) { have_wterm = false; hostPN.clear(); return 0; }
     std::vector<T> w((size_t)q * q);
@@ -712,7 +780,7 @@ struct Impl : kmpc_handle {
     // Configurations with a fused roll-out instantiation and the MLP lift take ONE launch for the step as well: the
     // roll-out kernel with a single step and no plant (encoder inside on MFMA, no separate lift kernel, psi handed
     // over in registers).  Same results up to the summation order of the encoder.
-    if (fuse_plant < 0 && !accumulate && cfg.lift_kind == KMPC_LIFT_MLP && fused_rollout_ok()) {
+    if (sizeof(T) == 8 && fuse_plant < 0 && !accumulate && cfg.lift_kind == KMPC_LIFT_MLP && fused_rollout_ok()) {
       static const bool two = dbg_env("KMPC_STEP_TWO_KERNELS") != nullptr;  // measurement aid
       if (!two)
         return rollout_fused(-1, const_cast<void*>(X), ref, rpt, 1, 0, -1, 0.05, nullptr, nullptr, st, it, s, U0, Useq);
@@ -728,11 +796,11 @@ struct Impl : kmpc_handle {
       e0 = ev[ev_used]; e1 = ev[ev_used + 1]; e2 = ev[ev_used + 2];
       HIPCHK(hipEventRecord(e0, s));
     }
+    int rc = ensure_dense(s, true);  // (first: on a float32 handle the ping-pong index follows the core's)
+    if (rc) return rc;
     T* psi_now = dPsi[cur];
     T* psi_prev = dPsi[cur ^ 1];
-    int rc = lift_to((const T*)X, psi_now, 1, L, B, s);
-    if (rc) return rc;
-    if ((rc = ensure_dense(s, true))) return rc;
+    if ((rc = lift_to((const T*)X, psi_now, 1, L, B, s))) return rc;
     if (rec) HIPCHK(hipEventRecord(e1, s));
     StepArgs<T> a = base_args(B);
     a.phases = PH_CONDENSE | PH_QP | ((have_prev && update_on) ? PH_RLS : 0);
@@ -763,9 +831,10 @@ struct Impl : kmpc_handle {
   // the loop WITHOUT the online update (duffing.py:738-805, vanderpol.py:645-722): kmpc_step / kmpc_rollout skip the RLS phase and
   // solve with the model as it is; the lift / input history keeps running, so that switching the update back on continues
   bool update_on = true;
-  int set_online_update(int on) override { update_on = on != 0; return 0; }
+  int set_online_update(int on) override { update_on = on != 0; if (core) core->update_on = update_on; return 0; }
   int set_applied_input(const void* U, int Bc, hipStream_t s) override {
     if (!U || Bc != B) FAIL(-3, "kmpc_set_applied_input: U must hold one input per trajectory of the handle");
+    if (core) { const int rc = ensure_dense(s, true); if (rc) return rc; }  // (u_{k-1} is part of what the core owns during roll-outs)
     HIPCHK(hipMemcpyAsync(dUprev, U, sizeof(T) * (size_t)B, hipMemcpyDeviceToDevice, s));
     return 0;
   }
@@ -799,13 +868,25 @@ struct Impl : kmpc_handle {
   int rollout_is_fused() const override { return fused_rollout_ok() ? 1 : 0; }
   bool fused_rollout_ok() const {
     static const bool off = dbg_env("KMPC_NO_FUSED_ROLLOUT") != nullptr;  // measurement aid: per-step launches
+    if (core) return !off && core->fused_rollout_ok();  // (float32 panels around the float64 roll-out)
     return !off && n == 2 && rollout_fused_available<T>(n, L, N, q, threads, cfg.lift_kind != KMPC_LIFT_MLP);
   }
+  // io32: the caller-owned panels (X, ref, Ulog, Xlog, U0out, Useqout) are float32 -- the call comes from a KMPC_F32 handle's core
   int rollout_fused(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
                     void* Ulog, void* Xlog, int32_t* st, int32_t* it, hipStream_t s, void* U0out = nullptr,
-                    void* Useqout = nullptr) {
+                    void* Useqout = nullptr, bool io32 = false) {
     int rc = check_lift_ready();
     if (rc) return rc;
+    if constexpr (sizeof(T) == 4) {
+      if (core) {
+        if ((rc = ensure_image(s))) return rc;
+        core->prof = prof;
+        rc = core->rollout_fused(plant, X, ref, rpt, steps, step0, switch_step, hs, Ulog, Xlog, st, it, s, U0out, Useqout, true);
+        if (rc) { err = core->err; return rc; }
+        have_prev = core->have_prev; rls_fresh = core->rls_fresh; cur = core->cur;
+        return 0;
+      }
+    }
     RolloutArgs<T> r{};
     r.s = base_args(B);
     r.s.u_prev = dUprev; r.s.x_now = (const T*)X;
@@ -829,6 +910,8 @@ struct Impl : kmpc_handle {
     r.have_prev = have_prev ? 1 : 0; r.rls_fresh = rls_fresh ? 1 : 0;
     r.no_update = update_on ? 0 : 1;
     r.U_log = (T*)Ulog; r.X_log = (T*)Xlog;
+    r.io_f32 = io32 ? 1 : 0;
+    if (io32 && !r.s.U0) r.s.U0 = dU0;
     if (!dbg_env("KMPC_ROLLOUT_NO_PLACE")) {  // (the trajectories' solver work of the previous launch: RolloutArgs::work)
       if (!dWork) {
         HIPCHK(hipMalloc(&dWork, sizeof(int32_t) * (size_t)B));
@@ -901,6 +984,10 @@ struct Impl : kmpc_handle {
       // set, restored or stepped through the dense blocks): set-up that the next kmpc_rollout would otherwise pay
       if constexpr (sizeof(T) == 8) {
         if (use_img) return ensure_image(s);
+      } else if (core) {
+        int rc = ensure_image(s);
+        if (!rc && core->use_img && (rc = core->ensure_image(s))) err = core->err;
+        return rc;
       }
       return 0;
     }
@@ -1212,6 +1299,7 @@ struct Impl : kmpc_handle {
     HIPCHK(hipDeviceSynchronize());  // (a roll-out on a non-blocking stream may still be writing the wave image)
     { int rc = ensure_dense(nullptr, false); if (rc) return rc; }
     { int rc = forget_tableaux(nullptr); if (rc) return rc; }  // (a checkpoint is a synchronisation point: exporter and importer continue alike)
+    if (core) img_valid = false;  // (... a float32 handle from its float32 blocks, as the importer will, not from its core's unrounded state)
     HIPCHK(hipDeviceSynchronize());
     BlobHeader hd{};
     hd.magic = 0x4b4d5043; hd.version = 2; hd.dtype = cfg.dtype; hd.n = n; hd.L = L; hd.N = N; hd.B = B;
@@ -1305,10 +1393,17 @@ struct Impl : kmpc_handle {
     prof = on != 0;
     ev_used = 0;
     prof_steps = 0;
+    if (core) core->profile_enable(on);
     return 0;
   }
   int profile_read(double* ms2, int64_t* count, int reset_) override {
     double a0 = 0, a1 = 0;
+    if (core) {  // (the fused launches of a float32 handle are recorded by its core)
+      double c2[2] = {0, 0}; int64_t cc = 0;
+      const int rc = core->profile_read(c2, &cc, reset_);
+      if (rc) { err = core->err; return rc; }
+      a0 += c2[0]; a1 += c2[1]; prof_steps += cc;
+    }
     for (size_t i = 0; i + 2 < ev_used + 0 && i + 2 < ev.size(); i += 3) {
       HIPCHK(hipEventSynchronize(ev[i + 2]));
       float t0 = 0, t1 = 0;
@@ -1318,7 +1413,7 @@ struct Impl : kmpc_handle {
     }
     if (ms2) { ms2[0] = a0; ms2[1] = a1; }
     if (count) *count = prof_steps;  // control steps covered by the recorded launches
-    if (reset_) { ev_used = 0; prof_steps = 0; }
+    if (reset_ || core) { ev_used = 0; prof_steps = 0; }
     return 0;
   }
 

@@ -230,6 +230,18 @@ hipError_t launch_image_to_state(const double* img, long stride, int n, int L, i
   return hipGetLastError();
 }
 
+template <typename S, typename D> __global__ __launch_bounds__(256) void cast_kernel(const S* __restrict__ src, D* __restrict__ dst, size_t count) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < count; i += (size_t)gridDim.x * 256) dst[i] = (D)src[i];
+}
+template <typename S, typename D> hipError_t launch_cast(const S* src, D* dst, size_t count, hipStream_t s) {
+  if (count == 0) return hipSuccess;
+  const size_t g = (count + 255) / 256;
+  hipLaunchKernelGGL((cast_kernel<S, D>), dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, src, dst, count);
+  return hipGetLastError();
+}
+template hipError_t launch_cast<float, double>(const float*, double*, size_t, hipStream_t);
+template hipError_t launch_cast<double, float>(const double*, float*, size_t, hipStream_t);
+
 // place_kernel: rank of every trajectory by last launch's solver work, then the card deal of RolloutArgs::perm.  Sixteen lanes share
 // the scan of one element (B / 16 comparisons each): 256 workgroups of 256 threads for B = 4096, ~3 us.
 __global__ __launch_bounds__(256) void place_kernel(const int32_t* __restrict__ work, int B, int32_t* __restrict__ perm) {

@@ -126,6 +126,7 @@ template <typename T> struct RolloutArgs {
   // Newton points: qp_rl's estimate).  The sixteen trajectories of a workgroup are dealt to its waves by it, heaviest first: the oldest
   // waves of the SIMDs -- served first -- take the expensive solves, the youngest, whose end is the step's end, the cheap ones (the
   // 20-step launch of cfg2: - 5 %).  Results do not depend on it (a trajectory's arithmetic is its own).  Null: wave w takes trajectory w.
+  int io_f32;               // 1: the caller-owned panels (X, ref, U0, Useq, U_log, X_log) are float32 (rollout_kernel's IOT = float)
   int32_t* work;
   // ... counted over the LAST work_tail steps of a launch only (0: all of them).  What predicts the next launch's solver work is the
   // recent state of a trajectory's solver -- a carried tableau about to go stale, a set that keeps changing --, not its history: ranked by
@@ -190,6 +191,7 @@ struct V2Dims {
 };
 // true: the fused roll-out of this dimension set keeps the state in registers and streams its wave image (step_v2.h)
 bool rollout_uses_image(int n, int L, int N, int q);
+bool rollout_io32_available(int n, int L, int N, int q, bool rbf);
 long state_image_elems(int L, int n);
 // dense row-major state blocks <-> wave image, whole batch (aux_kernels.hip)
 hipError_t launch_state_to_image(const double* P, long sP, const double* K, long sK, const double* Q, long sQ, const double* C, long sC,
@@ -208,6 +210,8 @@ template <typename T> hipError_t launch_fill_state(T* P, long strideP, int p, T 
                                                    T Q0, T* K, long strideK, T* C, long strideC, int n, int B,
                                                    hipStream_t s);
 hipError_t launch_axpby(double* g, const double* d, double a, int count, hipStream_t s);
+// dst[i] = (D)src[i]: the state blocks of a float32 handle <-> its float64 core (api.hip core_push / core_pull)
+template <typename S, typename D> hipError_t launch_cast(const S* src, D* dst, size_t count, hipStream_t s);
 template <typename T> hipError_t launch_gram(const GramArgs<T>& a, double forget, double* gram, hipStream_t s);
 template <typename T> hipError_t launch_shared_solve(const double* gram, int L, int n, double dP, double dQ, int use_C,
                                                      T* Kout, T* Cout, hipStream_t s, T* Pout = nullptr,

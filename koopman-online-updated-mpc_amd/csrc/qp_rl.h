@@ -185,7 +185,7 @@ struct QpCarry {  // what a solve leaves for the next one (registers of the step
 // M: on entry lanes t < N of half 0 hold the carried tableau rows (cs.valid) -- loaded by the caller BEFORE H was written into
 // sR --, sR holds H (N x N, row-major).  On exit (return false) the rows of the final tableau are in sR and cs describes them.
 // Return true: the solve has to continue in the active-set loop of qp_lds from qx_out (H is still in sR; nothing carried).
-template <int N_>
+template <int N_, typename IOT = double>
 __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const StepArgs<double>& a, const StepVar<double>& sv, const int b,
                                       double* qx_out, double* u_slot, double (&M)[N_], double& rs, double& rsi, QpCarry& cs, double up, double xw_pre) {
   typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -472,22 +472,22 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     return true;
   }
   if (own && !half) {
-    if (a.Useq) a.Useq[(size_t)t * B + b] = x;
+    if (a.Useq) io_st<IOT>(a.Useq, (size_t)t * B + b, x);
     if (a.x_warm) a.x_warm[(size_t)t * B + b] = x;
   }
   if (tid == 0) {
     const double uout = a.du_mode ? uprev + x : x;  // U0 = U0 + dU*(1)   (Tank_System.m:192)
     *u_slot = x;  // (the first move, for a covariance update done ahead: step_v2.h)
-    if (sv.U0) sv.U0[b] = uout;
+    if (sv.U0) io_st<IOT>(sv.U0, b, uout);
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
       double x1, x2;  // (x_next, when given, is the roll-out's LDS slot -- step_body.h lds_ld: as a select of two addresses these were
       // flat loads, which wait for both counters: behind the step's write-back a drain of every outstanding store, K = 20 - 4 %)
       if (sv.x_next) { x1 = lds_ld(sv.x_next); x2 = lds_ld(sv.x_next + 1); }
-      else { x1 = a.X_rw[b]; x2 = a.X_rw[(size_t)B + b]; }
+      else { x1 = io_ld<IOT>(a.X_rw, b); x2 = io_ld<IOT>(a.X_rw, (size_t)B + b); }
       plant_apply<double>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
-      a.X_rw[b] = x1;
-      a.X_rw[(size_t)B + b] = x2;
+      io_st<IOT>(a.X_rw, b, x1);
+      io_st<IOT>(a.X_rw, (size_t)B + b, x2);
       if (sv.x_next) { lds_st(sv.x_next, x1); lds_st(sv.x_next + 1, x2); }
     }
     if (sv.x_next) {

@@ -88,8 +88,12 @@ template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads(
   constexpr size_t waves = (KS_ >= 0 && N_ > 24 && fit > 8 && !ro_one_region<L_, N_, Q_, KS_>()) ? 8 : fit;
   return waves > 8 ? 1024 : (waves > 4 ? 512 : 256);  // 4 / 2 / 1 waves per SIMD
 }
-template <int L_, int N_, int Q_, int NW, int KS_>
+// IOT: element type of the caller-owned panels (X, ref, U0, Useq, U_log, X_log): double, or float for the float32-I/O roll-out of a
+// KMPC_F32 handle (row g2; register-state dimension sets only) -- the state, the handle's own vectors and all arithmetic stay float64,
+// and x_{k+1} is carried from step to step in LDS in float64: only what crosses the boundary is rounded (step_body.h io_ld / io_st)
+template <int L_, int N_, int Q_, int NW, int KS_, typename IOT = double>
 __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollout_kernel(const RolloutArgs<double> ra) {
+  static_assert(sizeof(IOT) == 8 || ro_v2<L_, N_, Q_>(), "float32 I/O: register-state dimension sets only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   double* const smem = reinterpret_cast<double*>(smem_raw);
   constexpr int NC = NW == 4 ? 4 : 16;  // trajectory columns of the cooperative encoder
@@ -128,7 +132,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
   if (!RBF && tid0 < 4 * NC) sXn[tid0] = 0.0;  // (columns of trajectories this workgroup does not have)
   __syncthreads();
   if (!RBF && (tid0 & 63) < 4)
-    sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? ra.s.X_rw[(size_t)(tid0 & 63) * B + b] : 0.0;
+    sXn[wave * 4 + (tid0 & 63)] = (live && (int)(tid0 & 63) < n) ? io_ld<IOT>(ra.s.X_rw, (size_t)(tid0 & 63) * B + b) : 0.0;
 
   if constexpr (ro_v2<L_, N_, Q_>()) {
     if (live) step_v2_init<L_, N_, Q_>(smem + ra.wbase + wave * ra.wstride);
@@ -167,7 +171,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       if (live && (lane & PSI_MASK) < L) {
         double x[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = (i < n) ? a.X_rw[(size_t)i * B + b] : 0.0;
+        for (int i = 0; i < 4; ++i) x[i] = (i < n) ? io_ld<IOT>(a.X_rw, (size_t)i * B + b) : 0.0;
         const double* c = R.cx + (size_t)(lane & PSI_MASK) * n;
         if (R.rbf_matlab) {
           double r2 = 0.0;
@@ -417,7 +421,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       sv.phases = PH_CONDENSE | PH_QP | ((have_prev && !R.no_update) ? PH_RLS : 0);
       sv.first_update = fresh ? 1 : 0;
       sv.plant_switched = (R.switch_step >= 0 && R.step0 + k >= R.switch_step) ? 1 : 0;
-      sv.U0 = R.U_log ? R.U_log + (size_t)k * B : a.U0;
+      sv.U0 = R.U_log ? io_at<IOT>(R.U_log, (size_t)k * B) : a.U0;
       sv.x_next = RBF ? nullptr : sXn + wv * 4;
       sv.cov_done = (k > 0 && !R.no_update) ? 1 : 0;
       // (waves without an encoder tile do the next step's covariance half inside the next lift instead: see above)
@@ -430,13 +434,13 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       // (y = psi, Q_ == L_: ill-conditioned H, crawling solves are common -- those instantiations keep the register safeguard)
       if constexpr (V2) {
         double* imgb = R.img + (size_t)bk * R.img_stride;
-        step_v2<L_, N_, Q_, LOWREG, !LOWREG>(a, sv, bk, wsm, imgb);
+        step_v2<L_, N_, Q_, LOWREG, !LOWREG, IOT>(a, sv, bk, wsm, imgb);
       } else {
         step_body<double, 64, L_, N_, Q_, LOWREG, !LOWREG || Q_ == L_, ro_one_region<L_, N_, Q_, KS_>()>(a, sv, bk, wsm);
       }
       if (R.X_log) {
         __threadfence_block();
-        if (lane < n) R.X_log[((size_t)k * n + lane) * B + b] = a.X_rw[(size_t)lane * B + b];
+        if (lane < n) io_st<IOT>(R.X_log, ((size_t)k * n + lane) * B + b, io_ld<IOT>(a.X_rw, (size_t)lane * B + b));
       }
     }
 #ifdef KMPC_TRACE
@@ -481,8 +485,12 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
   if (elems < scratch) elems = scratch;
   return elems + ro_keep(Lp, waves);
 }
-static int g_rollout_workgroup = 0;  // kmpc_set_rollout_workgroup
+#ifdef KMPC_ROLLOUT_IO32_TU
+extern int g_rollout_workgroup;
+#else
+int g_rollout_workgroup = 0;  // kmpc_set_rollout_workgroup
 void set_rollout_workgroup(int trajectories) { g_rollout_workgroup = trajectories; }
+#endif
 static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1 << 30) {
   const size_t cap = 160 * 1024 / sizeof(double);
   if (!rbf) {
@@ -520,22 +528,22 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
   return 0;
 }
-template <int L_, int N_, int Q_, int NW, int KS_>
+template <int L_, int N_, int Q_, int NW, int KS_, typename IOT = double>
 static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, size_t lds, hipStream_t s) {
   static size_t configured_dev[16] = {};  // (function attributes are per device)
   size_t& configured = configured_dev[device_slot()];
   if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW, KS_>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW, KS_, IOT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
   const int grid = (k.s.B + waves - 1) / waves;
-  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_>), dim3(grid), dim3(64 * waves), lds, s, k);
+  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_, IOT>), dim3(grid), dim3(64 * waves), lds, s, k);
   return hipGetLastError();
 }
 
-template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
+template <int L_, int N_, int Q_, typename IOT = double> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
   RolloutArgs<double> k = a;
   const bool rbf = a.lift_rbf != 0;
   constexpr bool V2 = ro_v2<L_, N_, Q_>();
@@ -556,7 +564,12 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
   const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
-  if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1>(k, waves, lds, s);
+  if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1, IOT>(k, waves, lds, s);
+  if constexpr (sizeof(IOT) == 4) {  // (float32 I/O: workgroups of sixteen and eight trajectories -- what rollout_waves picks for these sets)
+    if (waves == 16) return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25, IOT>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0, IOT>(k, waves, lds, s);
+    if (waves == 8) return ks25 ? launch_rollout_nw<L_, N_, Q_, 8, 25, IOT>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 8, 0, IOT>(k, waves, lds, s);
+    return hipErrorInvalidValue;
+  } else {
   // (workgroup sizes whose per-wave regions alone exceed the LDS are not instantiated)
   constexpr size_t pw = V2 ? v2_lds_elems(L_, Q_, N_)
                         : ro_one_region<L_, N_, Q_, 0>()
@@ -570,8 +583,40 @@ template <int L_, int N_, int Q_> static hipError_t launch_rollout_impl(const Ro
   if constexpr (16 * pw <= cap)
     if (waves == 16) return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0>(k, waves, lds, s);
   return hipErrorInvalidValue;
+  }
 }
 
+#ifdef KMPC_ROLLOUT_IO32_TU
+// the float32-I/O instantiations (register-state dimension sets), compiled as their own translation unit (rollout_kernel_io32.hip)
+hipError_t launch_rollout_io32(const RolloutArgs<double>& a, hipStream_t s) {
+  if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
+  if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
+    return hipErrorInvalidValue;
+  if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2, float>(a, s);  // BASELINE cfg2 ("fp32")
+#ifndef KMPC_DEV_CFG2_ONLY
+  if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2, float>(a, s);
+  if (a.s.L == 8 && a.s.N == 10 && a.s.q == 2) return launch_rollout_impl<8, 10, 2, float>(a, s);
+  if (a.s.L == 10 && a.s.N == 20 && a.s.q == 1) return launch_rollout_impl<10, 20, 1, float>(a, s);
+  if (a.s.L == 20 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<20, 30, 2, float>(a, s);
+#endif
+  return hipErrorInvalidValue;
+}
+#else
+#ifdef KMPC_TRACE  // (the measurement build has no float32-I/O instantiations)
+hipError_t launch_rollout_io32(const RolloutArgs<double>&, hipStream_t) { return hipErrorInvalidValue; }
+#else
+hipError_t launch_rollout_io32(const RolloutArgs<double>& a, hipStream_t s);
+#endif
+// true: a KMPC_F32 handle of this dimension set has the fused roll-out with float32 panels around the float64 state
+bool rollout_io32_available(int n, int L, int N, int q, bool rbf) {
+#ifdef KMPC_TRACE
+  return false;
+#endif
+#ifdef KMPC_DEV_CFG2_ONLY
+  if (!(L == 20 && N == 20 && q == 2)) return false;
+#endif
+  return n == 2 && step_v2_dims(L, N, q) && rollout_fused_available<double>(n, L, N, q, 64, rbf);
+}
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
   if (sizeof(T) != 8 || threads == 256 || n > 4) return false;
   const bool inst = (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
@@ -583,6 +628,7 @@ template <typename T> bool rollout_fused_available(int n, int L, int N, int q, i
 bool rollout_uses_image(int n, int L, int N, int q) { return n == 2 && step_v2_dims(L, N, q); }
 template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
   if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
+  if (a.io_f32) return launch_rollout_io32(a, s);
   if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
     return hipErrorInvalidValue;
   if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
@@ -603,5 +649,7 @@ template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a
 template <> hipError_t launch_rollout_fused<float>(const RolloutArgs<float>&, hipStream_t) { return hipErrorInvalidValue; }
 template bool rollout_fused_available<float>(int, int, int, int, int, bool);
 template bool rollout_fused_available<double>(int, int, int, int, int, bool);
+
+#endif  // KMPC_ROLLOUT_IO32_TU
 
 }  // namespace kmpc

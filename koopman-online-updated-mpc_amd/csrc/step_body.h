@@ -177,6 +177,13 @@ __device__ __forceinline__ double uniform_value(double v) {  // a value every la
 }
 __device__ __forceinline__ float uniform_value(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
 template <typename T> __device__ __forceinline__ T tclip(T v, T lo, T hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// Caller-owned panels of a roll-out with float32 I/O (IOT = float, row g2 of the scope table: BASELINE configs[1] names fp32, SURVEY G6
+// asks for fp32 panels around a float64 state): the StepArgs / RolloutArgs fields keep their T* type, the element is addressed and
+// converted as IOT.  With IOT = T these are plain loads and stores.
+template <typename IOT, typename T> __device__ __forceinline__ T io_ld(const T* base, size_t i) { return (T) reinterpret_cast<const IOT*>(base)[i]; }
+template <typename IOT, typename T> __device__ __forceinline__ void io_st(T* base, size_t i, T v) { reinterpret_cast<IOT*>(base)[i] = (IOT)v; }
+template <typename IOT, typename T> __device__ __forceinline__ T* io_at(T* base, size_t i) { return reinterpret_cast<T*>(reinterpret_cast<IOT*>(base) + i); }
+template <typename IOT, typename T> __device__ __forceinline__ const T* io_at(const T* base, size_t i) { return reinterpret_cast<const T*>(reinterpret_cast<const IOT*>(base) + i); }
 
 // ---- register-resident mat-vec chain (condense, static path): the current vector lives in the lanes and is
 // read with the f64 DPP row broadcast of gfx90a+ -- v_fmac_f64_dpp ... row_newbcast:n multiplies by lane n of
@@ -1225,7 +1232,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
 // ACTIVE-SET method on the same tableau: Newton direction on the free set, ratio test to the first blocking
 // bound, one wrong-signed multiplier released per minimiser -- monotone and finite for a strictly convex QP.
 // ---------------------------------------------------------------------------------------
-template <typename T, int TPB>
+template <typename T, int TPB, typename IOT = T>
 __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T* qxa, T* qg, T* red,
                                        const StepArgs<T>& a, const StepVar<T>& sv, int b, int N, bool as_from_start) {
   const int tid = local_tid<TPB>(), B = a.B;
@@ -1440,21 +1447,21 @@ __device__ __forceinline__ void qp_lds(const T* sH, const T* sf, T* sM, T* qx, T
   block_sync<TPB>();
 
   if (mine) {
-    if (a.Useq) a.Useq[(size_t)tid * B + b] = qx[tid];
+    if (a.Useq) io_st<IOT>(a.Useq, (size_t)tid * B + b, qx[tid]);
     if (a.x_warm) a.x_warm[(size_t)tid * B + b] = qx[tid];
   }
   if (tid == 0) {
     const T uout = a.du_mode ? uprev + qx[0] : qx[0];
-    if (sv.U0) sv.U0[b] = uout;
+    if (sv.U0) io_st<IOT>(sv.U0, b, uout);
     if (a.u_store) a.u_store[b] = uout;
     if (a.plant >= 0) {  // x_loc = f_update(0, x_loc, u_loc)   (duffing.py:871)
       // fused roll-out: x_k waits in the workgroup's LDS slot (no HBM round trip at the end of the step)
       T x1, x2;  // (x_next, when given, is the roll-out's LDS slot: lds_ld above)
       if (sv.x_next) { x1 = lds_ld(sv.x_next); x2 = lds_ld(sv.x_next + 1); }
-      else { x1 = a.X_rw[b]; x2 = a.X_rw[(size_t)B + b]; }
+      else { x1 = io_ld<IOT>(a.X_rw, b); x2 = io_ld<IOT>(a.X_rw, (size_t)B + b); }
       plant_apply<T>(a.plant, sv.plant_switched, a.plant_h, x1, x2, uout);
-      a.X_rw[b] = x1;
-      a.X_rw[(size_t)B + b] = x2;
+      io_st<IOT>(a.X_rw, b, x1);
+      io_st<IOT>(a.X_rw, (size_t)B + b, x2);
       if (sv.x_next) { lds_st(sv.x_next, x1); lds_st(sv.x_next + 1, x2); }
     }
     if (sv.x_next) {  // ... and the status / iteration counters are accumulated next to it, written once at the end

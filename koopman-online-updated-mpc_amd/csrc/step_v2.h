@@ -217,7 +217,7 @@ template <int N_> __device__ __forceinline__ double* v2_cov_slot(double* sm) { r
 template <int L_> __device__ __forceinline__ int v2_cov_index(int lane) { return lane < 32 ? lane : (lane - 32 < L_ ? lane : 32 + L_ - 1 + (L_ & 1)); }
 
 // sv.psi_now_v / psi_prev_v: lane with (lane & 31) = i < L carries psi_i (BOTH halves).  img: this trajectory's wave image.
-template <int L_, int N_, int Q_, bool LOWREG, bool ASREG>
+template <int L_, int N_, int Q_, bool LOWREG, bool ASREG, typename IOT = double>
 __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar<double>& sv, const int b, double* const sm, double* const img) {
   typedef double d2_t __attribute__((ext_vector_type(2)));
   constexpr int P_ = L_ + 1, CP = (L_ + 2) / 2, NC = 2 * CP, NX = 2, S2 = 2 * L_ + 1, S1 = L_ + NX;
@@ -250,11 +250,11 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   constexpr int REFN = (Q_ * N_ + 63) / 64;
   double refp[REFN];
   if (sv.phases & PH_CONDENSE) {
-    const double* refg = a.ref + (a.ref_per_traj ? (size_t)b * q * N : 0);
+    const double* refg = io_at<IOT>(a.ref, a.ref_per_traj ? (size_t)b * q * N : 0);
 #pragma unroll
     for (int i = 0; i < REFN; ++i) {
       const int e = tid + i * 64, ec = e < q * N ? e : 0, k = ec / q, r = ec - k * q;
-      refp[i] = refg[r * N + k];
+      refp[i] = io_ld<IOT>(refg, r * N + k);
     }
   }
 
@@ -285,7 +285,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     const int xr = t - L_ < 0 ? 0 : (t - L_ < NX ? t - L_ : NX - 1);
     double xn;  // (x_next, when given, is the roll-out's LDS slot: step_body.h lds_ld)
     if (sv.x_next) xn = lds_ld(sv.x_next + xr);
-    else xn = a.x_now[(size_t)xr * B + b];
+    else xn = io_ld<IOT>(a.x_now, (size_t)xr * B + b);
     // z = [psi(x_{k-1}); u_{k-1}] in the lanes of both halves
     const double z = t < L_ ? sv.psi_prev_v : (t == L_ ? up : 0.0);
     KTRACE(1);
@@ -469,7 +469,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   // =====================================================================================
   if (sv.phases & PH_QP) {
     EXP_PRIO(1);
-    if (qp_rl<N_>(sR, sf, a, sv, b, qxo, red + 15, M, rs, rsi, cs, up, xw_pre)) {
+    if (qp_rl<N_, IOT>(sR, sf, a, sv, b, qxo, red + 15, M, rs, rsi, cs, up, xw_pre)) {
       // crawling solve (rare): H moves to this trajectory's global scratch block, the active-set loop of qp_lds works with an
       // LDS tableau in its place
 #ifdef KMPC_TRACE
@@ -480,7 +480,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       for (int e = tid; e < N * N; e += 64) Hg[e] = sR[(e / N) * rl_stride(N_) + (e % N)];
       __threadfence_block();
       block_sync<64>();
-      qp_lds<double, 64>(Hg, sf, sR, qxo, qxa, qg, red, a, sv, b, N, true);
+      qp_lds<double, 64, IOT>(Hg, sf, sR, qxo, qxa, qg, red, a, sv, b, N, true);
       block_sync<64>();
       for (int e = tid; e < N * q; e += 64) sEr[N * q + e] = 0.0;  // (the solver's vectors may have covered the zeros behind e_N)
       if (tid == 0) red[15] = qxo[0];

@@ -1353,6 +1353,7 @@ def test_cfg2_full_size_properties(torch_mod, KM):
     ("duffing", ["--weights", "weights_duffing.npz", "--batch", "5", "--steps", "30"]),
     ("vanderpol", ["--weights", "weights_vdp.npz", "--batch", "1", "--steps", "30"]),
     ("vanderpol_RBF", ["--batch", "6", "--steps", "25", "--horizon", "30"]),
+    ("vanderpol_RBF", ["--plant", "duffing", "--batch", "6", "--steps", "25", "--switch-step", "12"]),  # (duffing_RBF.py: :40, 118, 342, 506)
     ("tank", ["--weights", "weights_tank.npz", "--batch", "4", "--steps", "30"]),
     ("tank", ["--batch", "8", "--steps", "12", "--shared", "--Nlift", "32", "--horizon", "40"]),
 ])
