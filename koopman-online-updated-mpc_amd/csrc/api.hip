@@ -257,6 +257,7 @@ struct Impl : kmpc_handle {
                       (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet, (void*)dDelta, (void*)dQpList, (void*)dWork, (void*)dPerm})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
+    if (evPlace) (void)hipEventDestroy(evPlace);
   }
 
   // upload a (rows x cols) host double matrix into a zero-padded (prow x pcol) device matrix of T
@@ -922,6 +923,9 @@ struct Impl : kmpc_handle {
       r.work_tail = tail;
       // ... across the workgroups too where the batch allows the card deal (whole workgroups; the rank kernel is O(B^2 / lanes))
       if (place_valid && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= 16384 && !dbg_env("KMPC_ROLLOUT_NO_GLOBAL_PLACE")) r.perm = dPerm;
+      // (work and perm were written on the stream of the previous call: a call on another stream waits for them -- a torn perm would
+      //  hand one trajectory to two waves and skip another: ADVICE r4)
+      if (evPlace && place_stream != s) HIPCHK(hipStreamWaitEvent(s, evPlace, 0));
     }
     if constexpr (sizeof(T) == 8) {
       if (use_img) {
@@ -946,6 +950,11 @@ struct Impl : kmpc_handle {
       place_valid = true;
     } else {
       place_valid = false;
+    }
+    if (r.work) {
+      if (!evPlace) HIPCHK(hipEventCreateWithFlags(&evPlace, hipEventDisableTiming));
+      HIPCHK(hipEventRecord(evPlace, s));
+      place_stream = s;
     }
     if (rec) {
       HIPCHK(hipEventRecord(ev[ev_used + 2], s));
@@ -1015,6 +1024,8 @@ struct Impl : kmpc_handle {
   int32_t* dWork = nullptr;  // [B] solver work of every trajectory in the last fused launch (RolloutArgs::work)
   int32_t* dPerm = nullptr;  // [B] slot -> trajectory for the next fused launch (RolloutArgs::perm); valid after a launch that wrote dWork
   bool place_valid = false;
+  hipEvent_t evPlace = nullptr;      // recorded behind the launch (and the rank pass) that wrote dWork / dPerm
+  hipStream_t place_stream = nullptr;
   int32_t* dQpList = nullptr;  // two alternating counters, then the list of the trajectories shared_fast_kernel left to the solve-only kernel
   int qp_list_parity = 0;
   T* dWt = nullptr;  // PN - Qw I (terminal block of Q_bar)

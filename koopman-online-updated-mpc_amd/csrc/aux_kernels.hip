@@ -5,6 +5,7 @@
 //   Van der Pol  x1' = 2 x2, x2' = 2 x2 - 10 x1^2 x2 - 0.8 x1 + u vanderpol_RBF.py:113
 //             after step 100: x1' = x2, x2' = -3 x2 - 10 x1^2 x2 - 3 x1 + u  vanderpol.py:923-931
 //   RK4, h = 0.05                                                duffing.py:256-261
+#include <cstdio>
 #include "kernels.h"
 #include <cstdlib>
 #include "plant_device.h"
@@ -13,7 +14,17 @@ namespace kmpc {
 
 const char* dbg_env(const char* name) {
   static const bool on = getenv("KMPC_DEBUG") != nullptr;
-  return on ? getenv(name) : nullptr;
+  if (!on) {
+    // a measurement switch in the environment of a process that has not asked for them: say so once instead of silently running the
+    // default path (a script that compares "with" and "without" would otherwise compare the default with itself)
+    static bool warned = false;
+    if (!warned && getenv(name)) {
+      warned = true;
+      fprintf(stderr, "libkoopmpc: %s is set but ignored -- the KMPC_* measurement switches are read only when KMPC_DEBUG is set\n", name);
+    }
+    return nullptr;
+  }
+  return getenv(name);
 }
 
 

@@ -295,7 +295,15 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
       ++polish;
     }
     if (it >= max_iter || refresh > 4) { status = 1; break; }
-    if (it >= N_ + 14 || ncrawl >= 2 * N_ + 8) { status = 3; break; }  // crawling: the caller finishes with the active-set loop of qp_lds
+    // (hand-over point: N + 14 iterations / 2 N + 8 refused steps until round 5.  A solve that has not converged in N iterations is
+    //  crawling and costs its workgroup ~2 us per further iteration at every lift barrier; handed over at N: post-reset window + 6.6 %,
+    //  settled window unchanged; at 12 the fall-back's 70 us are paid by solves that would have finished: no gain --
+    //  profiles/r5_cfg2_crawl_threshold_ab.txt.  -DKMPC_EXP_CRAWL_IT / _LS: measurement builds)
+#ifndef KMPC_EXP_CRAWL_IT
+#define KMPC_EXP_CRAWL_IT (N_)
+#define KMPC_EXP_CRAWL_LS (N_ + 4)
+#endif
+    if (it >= KMPC_EXP_CRAWL_IT || ncrawl >= KMPC_EXP_CRAWL_LS) { status = 3; break; }  // crawling: the caller finishes with the active-set loop of qp_lds
     // a carried tableau that has not brought the point inside the tolerance in four iterations is replaced by a fresh one
     if (carried && it >= 4 && Bmask != 0u) rebuild = true;
     unsigned Fmask = ~Imask & ownmask;

@@ -32,6 +32,12 @@ __device__ unsigned long long kmpc_lift_buf[512 * 16];
 extern "C" int kmpc_lift_trace_read(void* host, size_t bytes) {
   return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kmpc_lift_buf), bytes, 0, hipMemcpyDeviceToHost);
 }
+// per trajectory (< 4096) and step (< 32) of the last launch: low words of the clock when the wave was ready for the step, when the lift
+// was done, when the step body ended (10 ns ticks; tools/dbg/step_timeline.py)
+__device__ unsigned kmpc_step_buf[4096 * 96];
+extern "C" int kmpc_step_trace_read(void* host, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(kmpc_step_buf), bytes, 0, hipMemcpyDeviceToHost);
+}
 #else
 #define LSTAMP(i)
 #endif
@@ -402,8 +408,10 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
 #ifdef KMPC_TRACE
     if (lane == 0 && b < 8192) kmpc_trace_buf[b * 32 + 17] = wall_clock64();  // lift done
     if (lane == 0 && b < 8192 && k == 0) {
+      // where this wave runs: XCC_ID (hwreg 20, bits 3:0) | HW_ID (hwreg 4: wave, simd, pipe, cu, sh, se) << 8
+      kmpc_trace_buf[b * 32 + 29] = (unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | 20) | ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) << 8);
       kmpc_trace_buf[b * 32 + 19] = wall_clock64();
-      for (int sl = 22; sl < 30; ++sl) kmpc_trace_buf[b * 32 + sl] = 0ull;  // (qp_rl's work counters: summed over the launch)
+      for (int sl = 22; sl < 29; ++sl) kmpc_trace_buf[b * 32 + sl] = 0ull;  // (qp_rl's work counters: summed over the launch)
     }
 #endif
     if (live) {
@@ -449,6 +457,11 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       kmpc_trace_buf[b * 32 + 18] = t18;  // step k done
       // whole-launch sums: barrier wait + lift, step body (k == 0 resets)
       const unsigned long long dl = kmpc_trace_buf[b * 32 + 17] - kmpc_trace_buf[b * 32 + 16], db = t18 - kmpc_trace_buf[b * 32 + 17];
+      if (b < 4096 && k < 32) {
+        kmpc_step_buf[b * 96 + 3 * k] = (unsigned)kmpc_trace_buf[b * 32 + 16];
+        kmpc_step_buf[b * 96 + 3 * k + 1] = (unsigned)kmpc_trace_buf[b * 32 + 17];
+        kmpc_step_buf[b * 96 + 3 * k + 2] = (unsigned)t18;
+      }
       kmpc_trace_buf[b * 32 + 20] = (k == 0 ? 0ull : kmpc_trace_buf[b * 32 + 20]) + dl;
       kmpc_trace_buf[b * 32 + 21] = (k == 0 ? 0ull : kmpc_trace_buf[b * 32 + 21]) + db;
     }

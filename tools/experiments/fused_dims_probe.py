@@ -2,6 +2,7 @@
 """Dev tool: fused roll-out vs per-step launches on the larger dimension sets (same controller, same states):
 agreement of the closed loop and steps/s of both.  python tools/fused_dims_probe.py"""
 import os, subprocess, sys, time
+os.environ.setdefault("KMPC_DEBUG", "1")  # (the library reads KMPC_NO_FUSED_ROLLOUT and the other measurement switches only with this set)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "koopman-online-updated-mpc_amd"))
 import numpy as np, torch
