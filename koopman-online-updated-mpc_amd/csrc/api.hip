@@ -198,7 +198,7 @@ struct Impl : kmpc_handle {
       HIPCHK(hipMemset(dQpCarrySet, 0, sizeof(int32_t) * (size_t)B * 4));
     }
     if constexpr (sizeof(T) == 8) {
-      use_img = threads == 64 && c.output_kind != KMPC_OUT_LIFT && rollout_uses_image(n, L, N, q) &&
+      use_img = threads == 64 && (c.output_kind != KMPC_OUT_LIFT || q == L) && rollout_uses_image(n, L, N, q) &&
                 rollout_fused_available<T>(n, L, N, q, threads, c.lift_kind != KMPC_LIFT_MLP);
       if (use_img) {
         sImg = state_image_elems(L, n);

@@ -75,6 +75,19 @@ __device__ __forceinline__ double half_max(double s) {
   half_gather(rt, r0, r1);
   return r0 > r1 ? r0 : r1;
 }
+// minimum over the lanes of each half
+__device__ __forceinline__ double half_min(double s) {
+  double w;
+  w = dpp_shr_keep(s, 1); s = w < s ? w : s;
+  w = dpp_shr_keep(s, 2); s = w < s ? w : s;
+  w = dpp_shr_keep(s, 4); s = w < s ? w : s;
+  w = dpp_shr_keep(s, 8); s = w < s ? w : s;
+  double rt = 0.0;
+  fmac_rowbcast<15, true>(rt, s, 1.0);
+  double r0, r1;
+  half_gather(rt, r0, r1);
+  return r0 < r1 ? r0 : r1;
+}
 // lanes t and 32 + t: lo = the value of lane t in both, hi = that of lane 32 + t
 __device__ __forceinline__ void halves_both_q(double a, double& lo, double& hi) {
   const int al = __double2loint(a), ah = __double2hiint(a);
@@ -185,7 +198,14 @@ struct QpCarry {  // what a solve leaves for the next one (registers of the step
 // M: on entry lanes t < N of half 0 hold the carried tableau rows (cs.valid) -- loaded by the caller BEFORE H was written into
 // sR --, sR holds H (N x N, row-major).  On exit (return false) the rows of the final tableau are in sR and cs describes them.
 // Return true: the solve has to continue in the active-set loop of qp_lds from qx_out (H is still in sR; nothing carried).
-template <int N_, typename IOT = double>
+// AS: the active-set safeguard in registers (round 5; qp_regs has had it on its 8 x 8 grid since round 2).  When projected Newton crawls
+// (ill-conditioned, almost fully saturated problems: y = psi makes H ill-conditioned, vanderpol.py:456-459) the solve continues on the
+// SAME tableau as a primal active-set method: Newton direction on the free set, ratio test to the first blocking bound (which joins
+// the working set W), and at a minimiser of the face the worst wrong-signed multiplier leaves W -- monotone and finite for a strictly
+// convex QP, one sweep and two row products per iteration.  Compiled in for the lifted-output sets only: in the y = C x kernels the
+// mode's live state costs 14 more spilled vector registers and 3.3 % of the settled cfg2 window for solves that are 1 in 10 000 there
+// (profiles/r5_cfg2_active_set_ab.txt; as a block behind the loop: the same; as a called function: - 12 %).
+template <int N_, typename IOT = double, bool AS = false>
 __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const StepArgs<double>& a, const StepVar<double>& sv, const int b,
                                       double* qx_out, double* u_slot, double (&M)[N_], double& rs, double& rsi, QpCarry& cs, double up, double xw_pre) {
   typedef double d2_t __attribute__((ext_vector_type(2)));
@@ -264,6 +284,9 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   bool Jok = false;
   int it = 0, status = 1, refresh = 0, polish = 0, rtot = 0, ncrawl = 0, nref = 0;
   bool nopredict = false, rebuild = false;
+  bool mode_as = false, at_min = false;  // (AS only)
+  unsigned Wmask = 0u;
+  constexpr int AS_IT = 10, AS_CRAWL = 9;  // projected-Newton iterations / refused steps after which an AS solve changes mode
 #ifdef KMPC_TRACE
   int tc_sweeps = 0, tc_rebuild = 0, tc_pass = 0, tc_ls = 0, tc_mv = 1;  // (work counters of the trace build: slots 22-27, summed over the launch)
   const bool tc_carried0 = carried;
@@ -291,10 +314,18 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     const unsigned Imask = (unsigned)__ballot(inI);
     if ((unsigned)__ballot(own && !(tabs(g) <= 1e300)) != 0u || (Jok && (!(J0 == J0) || tabs(J0) > 1e300))) { status = 2; break; }
     if (Bmask == 0u && (it > 0 || !warm)) {
-      if (!refine || polish >= 2) { status = 0; break; }
+      if (!refine || (AS && mode_as) || polish >= 2) { status = 0; break; }
       ++polish;
     }
     if (it >= max_iter || refresh > 4) { status = 1; break; }
+    if constexpr (AS) {
+      if (it >= 6 * N_ + 40) { status = 3; break; }  // (never seen: the caller would finish with the active-set loop of qp_lds)
+      if (!mode_as && (it >= AS_IT || ncrawl >= AS_CRAWL)) {  // crawling: on as an active-set method
+        mode_as = true;
+        at_min = false;
+        Wmask = Imask;
+      }
+    } else {
     // (hand-over point: N + 14 iterations / 2 N + 8 refused steps until round 5.  A solve that has not converged in N iterations is
     //  crawling and costs its workgroup ~2 us per further iteration at every lift barrier; handed over at N: post-reset window + 6.6 %,
     //  settled window unchanged; at 12 the fall-back's 70 us are paid by solves that would have finished: no gain --
@@ -304,12 +335,23 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
 #define KMPC_EXP_CRAWL_LS (N_ + 4)
 #endif
     if (it >= KMPC_EXP_CRAWL_IT || ncrawl >= KMPC_EXP_CRAWL_LS) { status = 3; break; }  // crawling: the caller finishes with the active-set loop of qp_lds
+    }
     // a carried tableau that has not brought the point inside the tolerance in four iterations is replaced by a fresh one
     if (carried && it >= 4 && Bmask != 0u) rebuild = true;
-    unsigned Fmask = ~Imask & ownmask;
+    if constexpr (AS) {
+      if (mode_as && at_min) {  // x minimises the cost on the free set: release the worst wrong-signed multiplier
+        // (every per-variable quantity is mirrored in the two halves of the wave: both compute the same maximum; the branch is scalar)
+        const bool inW = ((Wmask >> t) & 1u) != 0u;
+        const double vr = (own && inW && !inI) ? tabs(g) / gs : 0.0;
+        const double vmax = uniform_value(half_max(vr));
+        if (vmax > tol) Wmask &= ~(1u << (__ffs((int)(unsigned)__ballot(!half && vr == vmax)) - 1));
+        at_min = false;
+      }
+    }
+    unsigned Fmask = ((AS && mode_as) ? ~Wmask : ~Imask) & ownmask;
     if (it == 0) KTRACE(9);
 
-    const bool predict = !nopredict && predict_on;
+    const bool predict = !(AS && mode_as) && !nopredict && predict_on;
     int rounds = 0;
     bool broke = false, isF = false, exact = false;  // exact: the direction's residual gradient on F is at rounding level
     double pdir = 0.0, hp = 0.0;
@@ -403,15 +445,33 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
 
     double alpha = 1.0, xa = x, hxa = 0.0, Ja = J0;
     bool redo = false;
+    int jb = -1;
+    if constexpr (AS) {
+      if (mode_as) {
+        // ratio test: the largest step along the Newton direction that keeps the free variables inside the box
+        double al = 1e300;
+        if (isF && pdir < 0.0 && x + pdir < lb) al = (lb - x) / pdir;
+        if (isF && pdir > 0.0 && x + pdir > ub) al = (ub - x) / pdir;
+        const double amin = uniform_value(half_min(al));  // (mirrored in both halves; scalar: the branch below is uniform)
+        alpha = amin < 1.0 ? (amin > 0.0 ? amin : 0.0) : 1.0;
+        if (amin < 1.0) {
+          jb = __ffs((int)(unsigned)__ballot(!half && own && al == amin)) - 1;
+          Wmask |= (1u << jb);
+        } else {
+          at_min = true;
+        }
+      }
+    }
     while (true) {
       double dstep = pdir;
       if (!isF) {
         const double g0 = 2.0 * hx + fi;
-        dstep = own ? ((g0 > 0.0 ? lb : (g0 < 0.0 ? ub : x)) - x) : 0.0;
+        dstep = (own && !(AS && mode_as)) ? ((g0 > 0.0 ? lb : (g0 < 0.0 ? ub : x)) - x) : 0.0;
         if (rounds > 0 && own && !inI) dstep = qx_out[t] - x;
       }
       const double xu = x + alpha * dstep;
       xa = own ? tclip(xu, lb, ub) : 0.0;
+      if constexpr (AS) { if (t == jb) xa = pdir < 0.0 ? lb : ub; }  // (the blocking variable lands exactly on its bound)
       // the full, unclipped Newton step: H xa = H x + H p, and H p is what the refinement ended with
       const bool plain = alpha == 1.0 && rounds == 0 && (unsigned)__ballot(own && (isF ? xa != xu : xa != x)) == 0u;
       if (plain) {
@@ -421,8 +481,8 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
         halves_both_q(rl_matvec<N_>(M, xa), lo, hi);
         hxa = own ? hi : 0.0;
       }
-      if (plain && exact) {  // (the exact Newton point of the face, not clipped: accepted without the sums)
-        Jok = false;
+      if ((plain && exact) || (AS && mode_as)) {  // (the exact Newton point of the face, not clipped: accepted without the sums;
+        Jok = false;                              //  an active-set step -- exact line search along a Newton direction -- is always taken)
         break;
       }
       if (!Jok) {

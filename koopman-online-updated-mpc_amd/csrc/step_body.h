@@ -2067,6 +2067,81 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       const double bs = a.du_mode ? sK[rr * p + L] * (chain ? up : 1.0) : 0.0;
       block_sync_lds<TPB>();  // (C may sit where g is written from now on)
       int cur = 0;
+#ifdef KMPC_EXP_A2
+      if (!a.du_mode) {
+        // Round 4 -- double steps with A^2: v_{j+2} = A^2 v_j, the even and the odd vectors of a chain advance together (twice the
+        // multiply-adds per barrier round, half the rounds: the recursion's pace is its 51 rounds of LDS write - barrier - LDS
+        // read, 0.39 us each, not its arithmetic).  A^2 on the matrix cores (wave w = row tile w, four column tiles), written over
+        // A in LDS; the vectors of a chain alternate between two pairs of buffers (the second pair where C, psi and the tail of
+        // region 1 were).
+        double* const Eb[2] = {chain ? sW : sV, chain ? sy : sC};
+        double* const Ob[2] = {(chain ? sW : sV) + L_, chain ? sX + L_ * (L_ + 1) : sC + L_};
+        {  // v_1 = A v_0, w_1 = A w_0 with the rows of A
+          const double x0 = Eb[0][hh * 32 + l16], x1 = Eb[0][hh * 32 + 16 + l16];
+          double ac4[4] = {0.0, 0.0, 0.0, 0.0};
+          chain_dot<32>(ac4, x0, x1, row);
+          const double part = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
+          double pa, pb;
+          half_gather(part, pa, pb);
+          if (hh == 0) Ob[0][rr] = pa + pb;
+        }
+        {  // A^2
+          typedef double d4a __attribute__((ext_vector_type(4)));
+          const int mt = tid >> 6;
+          double afr[16];
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) afr[ks] = sK[(16 * mt + (ln & 15)) * (L_ + 1) + 4 * ks + (ln >> 4)];
+          d4a acc2[4];
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt) {
+            d4a c = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int ks = 0; ks < 16; ++ks)
+              c = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], sK[(4 * ks + (ln >> 4)) * (L_ + 1) + 16 * nt + (ln & 15)], c, 0, 0, 0);
+            acc2[nt] = c;
+          }
+          block_sync_lds<TPB>();  // every wave has read its fragments of A (and v_1, w_1 are in place)
+#pragma unroll
+          for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sK[(16 * mt + (ln >> 4) + 4 * r) * (L_ + 1) + 16 * nt + (ln & 15)] = acc2[nt][r];
+          block_sync_lds<TPB>();
+#pragma unroll
+          for (int l = 0; l < 32; ++l) row[l] = sK[rr * p + hh * 32 + l];
+        }
+        // pairs (v_2m, v_2m+1) -> (v_2m+2, v_2m+3); the outputs of two pairs are reduced together
+        for (int m0 = 0; 2 * m0 <= N; m0 += 2) {
+          double pc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int u = 0; u < 2; ++u) {
+            const int j = 2 * (m0 + u);  // inputs v_j, v_j+1
+            if (j <= N) {
+              const double* const ve = Eb[cur];
+              const double* const vo = Ob[cur];
+              const double xe0 = ve[hh * 32 + l16], xe1 = ve[hh * 32 + 16 + l16];
+              const double xo0 = vo[hh * 32 + l16], xo1 = vo[hh * 32 + 16 + l16];
+              pc[2 * u] = co * ve[ln];
+              pc[2 * u + 1] = co * vo[ln];
+              double ae[4] = {0.0, 0.0, 0.0, 0.0}, ao[4] = {0.0, 0.0, 0.0, 0.0};
+              chain_dot<32>(ae, xe0, xe1, row);
+              chain_dot<32>(ao, xo0, xo1, row);
+              double pa, pb, qa, qb;
+              half_gather((ae[0] + ae[1]) + (ae[2] + ae[3]), pa, pb);
+              half_gather((ao[0] + ao[1]) + (ao[2] + ao[3]), qa, qb);
+              if (hh == 0 && j + 2 <= N) { Eb[cur ^ 1][rr] = pa + pb; Ob[cur ^ 1][rr] = qa + qb; }
+              block_sync_lds<TPB>();
+              cur ^= 1;
+            }
+          }
+          const double g4 = wave_sum4(pc[0], pc[1], pc[2], pc[3], ln);
+          const int j = 2 * m0 + ln;  // lane u < 4 of the wave holds the output of step 2 m0 + u
+          if (ln < 4 && corow < q && j <= N) {
+            if (chain == 0) { if (j < N) sG[j * q + corow] = g4; }
+            else if (j >= 1) sEr[(j - 1) * q + corow] += g4;
+          }
+        }
+      } else
+#endif
       for (int j0 = 0; j0 <= N; j0 += 4) {  // (the outputs of four steps are reduced together: wave_sum4)
         double pc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll

@@ -43,7 +43,18 @@ namespace kmpc {
 // wave image of one trajectory (host + device)
 // ---------------------------------------------------------------------------------------
 // (N <= 32: qp_rl and the H / f pass keep one variable per lane of a 32-lane half)
+// (round 4: q = L is the lifted-output form y = psi -- vanderpol.py:456-459, Koopman_update_Tracking_Lift.m:99-106 --: no output map,
+//  the upper halves of the image (bar_Q, C) travel untouched; q < L: y = C x with q <= 2 rows of C)
+// The q = L form is a compile-time experiment (make dev EXTRA="-DKMPC_EXP_LIFTED_V2 -DKMPC_DEV_LIFT"): measured twice and not shipped --
+// round 4 without, round 5 with the active-set safeguard in registers (qp_rl<.., AS = true>): 34.2 us/step against 29.1 us/step of the
+// shipped 8 x 8-grid kernel at L = 8, N = 10, B = 4096, K = 20 (134 against 116 us at N = 30, RBF): rows in lanes fill 9 of 32 lanes at
+// L = 8, and the H / f pass over q = L outputs is L / 2 times the work of the y = C x sets (profiles/r5_lifted_output_step_v2_ab.txt).
+// The variant also fails test_closed_loop_step_on_reference_states[vanderpol] (the one-step route): not fit for use as it stands.
+#ifdef KMPC_EXP_LIFTED_V2
+static constexpr bool step_v2_dims(int L, int N, int q) { return q > 0 && (q == L || q <= 2) && L + 2 <= 32 && N <= 32 && L >= 2; }
+#else
 static constexpr bool step_v2_dims(int L, int N, int q) { return q != L && q > 0 && L + 2 <= 32 && N <= 32 && L >= 2; }
+#endif
 // LDS of one trajectory (elements):
 //   R    N x N   H while a solve runs, the tableau of the last solve between two solves (qp_rl.h)          persistent
 //   cs   130     row scales of that tableau (2 x 32), its variable set / validity (2 ints), the gains of a covariance
@@ -222,6 +233,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   typedef double d2_t __attribute__((ext_vector_type(2)));
   constexpr int P_ = L_ + 1, CP = (L_ + 2) / 2, NC = 2 * CP, NX = 2, S2 = 2 * L_ + 1, S1 = L_ + NX;
   constexpr int N = N_, q = Q_;
+  constexpr bool LIFT = Q_ == L_;  // y = psi
   static_assert(step_v2_dims(L_, N_, Q_), "step_v2: dimension set");
   static_assert(N_ <= 32 && L_ + 2 <= 32, "step_v2: one variable / one state row per lane of a 32-lane half");
   const int tid = local_tid<64>();
@@ -287,7 +299,8 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     if (sv.x_next) xn = lds_ld(sv.x_next + xr);
     else xn = io_ld<IOT>(a.x_now, (size_t)xr * B + b);
     // z = [psi(x_{k-1}); u_{k-1}] in the lanes of both halves
-    const double z = t < L_ ? sv.psi_prev_v : (t == L_ ? up : 0.0);
+    // (lifted output: zeros in the upper half -- bar_Q and C stay as they are)
+    const double z = (LIFT && half) ? 0.0 : (t < L_ ? sv.psi_prev_v : (t == L_ ? up : 0.0));
     KTRACE(1);
     const double u2 = sv.cov_done ? sCov[v2_cov_index<L_>(tid)] : v2_rls_cov<L_, false>(img, z, a.lam);
     KTRACE(2);
@@ -347,17 +360,21 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     gather_rows<S1>(isA ? (half ? psin : R1[L_]) : 0.0, v0, v1);
     // delta-u form (Tank_System.m:110-113): x+ = A x + B s, s = 1 on the v chain and u_prev on the w chain
     const double bs = (a.du_mode && isA) ? R1[L_] * (half ? up : 1.0) : 0.0;
-    const int ro = t - L_ - a.cy0;
+    // y = C x: the rows of C_o give g_j = C_o v_j and C_o w_j at step j (j = 0 .. N).  y = psi: the outputs are the vectors themselves,
+    // g_0 = B and step j leaves g_{j+1} = v_{j+1}, w_{j+1} (j = 0 .. N-1)
+    const int ro = LIFT ? t : t - L_ - a.cy0;
     const bool isO = ro >= 0 && ro < q;
-    double* const optr = isO ? (half ? sEr - q + ro : sG + ro) : dump + tid;
+    double* const optr = isO ? (LIFT ? (half ? sEr + ro : sG + q + ro) : (half ? sEr - q + ro : sG + ro)) : dump + tid;
+    if constexpr (LIFT) { if (isO && !half) sG[ro] = R1[L_]; }
     KTRACE(5);
+    constexpr int JN = LIFT ? N_ - 1 : N_;
 #pragma unroll
-    for (int j = 0; j <= N_; ++j) {
+    for (int j = 0; j <= JN; ++j) {
       double acc = bs;
       rowdot_one<L_, NC>(acc, v0, v1, R1);
       if constexpr (v2_chain_dump(N_)) optr[j * q] = acc;
       else if (isO) optr[j * q] = acc;
-      if (j < N_) gather_rows<S1>(acc, v0, v1);
+      if (j < JN) gather_rows<S1>(acc, v0, v1);
     }
     block_sync<64>();
     // e_j = C_o w_j - r_{j-1}
@@ -414,6 +431,26 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     // of a step could only be requested behind the previous step's stores and waited for in full (20 x ~230 cycles = 1.9 of the
     // 33 us of a cfg2 step).  In a chunk the reads of all its steps are in flight together.
     constexpr int HCH = 10;
+    if constexpr (Q_ > 2) {
+      // (y = psi: q-vectors of length L -- a loop, not N x q loads hoisted into registers)
+      const double* const wv_ = (hf ? sEr : sG) + (idx < N_ ? idx : 0) * Q_;  // (lanes beyond N: results unused, addresses kept inside)
+#pragma unroll 1
+      for (int tt = 0; tt < N_; ++tt) {
+        double s0 = 0.0, s1 = 0.0;
+#pragma unroll
+        for (int r = 0; r < Q_; r += 2) {
+          s0 = tfma(sG[tt * Q_ + r], wv_[tt * Q_ + r], s0);
+          if (r + 1 < Q_) s1 = tfma(sG[tt * Q_ + r + 1], wv_[tt * Q_ + r + 1], s1);
+        }
+        acc += s0 + s1;
+        if (!hf && idx < N_ - tt) {
+          const double hv = Qw * acc + rdiag;
+          const int bb = N_ - 1 - tt;
+          sR[(bb - idx) * NS + bb] = hv;
+          sR[bb * NS + bb - idx] = hv;
+        }
+      }
+    } else
     static_for<0, (N_ + HCH - 1) / HCH>([&](auto CC) {
       constexpr int c0 = decltype(CC)::value * HCH, c1 = c0 + HCH < N_ ? c0 + HCH : N_;
       double hv[HCH];
@@ -448,7 +485,9 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       const double* ga = sG + (N - 1 - aa) * q;
       const double* gb = sG + (N - 1 - bb) * q;
       double acc = 0.0;
+#pragma unroll 1
       for (int r = 0; r < q; ++r)
+#pragma unroll 2
         for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * (0.5 * (Wt[r * q + s2] + Wt[s2 * q + r])) * gb[s2];
       sR[aa * rl_stride(N_) + bb] += acc;
     }
@@ -456,7 +495,9 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       const double* ga = sG + (N - 1 - aa) * q;
       const double* eN = sEr + (N - 1) * q;
       double acc = 0.0;
+#pragma unroll 1
       for (int r = 0; r < q; ++r)
+#pragma unroll 2
         for (int s2 = 0; s2 < q; ++s2) acc += ga[r] * Wt[r * q + s2] * eN[s2];
       sf[aa] += 2.0 * acc;
     }
@@ -469,7 +510,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   // =====================================================================================
   if (sv.phases & PH_QP) {
     EXP_PRIO(1);
-    if (qp_rl<N_, IOT>(sR, sf, a, sv, b, qxo, red + 15, M, rs, rsi, cs, up, xw_pre)) {
+    if (qp_rl<N_, IOT, LIFT>(sR, sf, a, sv, b, qxo, red + 15, M, rs, rsi, cs, up, xw_pre)) {
       // crawling solve (rare): H moves to this trajectory's global scratch block, the active-set loop of qp_lds works with an
       // LDS tableau in its place
 #ifdef KMPC_TRACE
@@ -502,7 +543,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
     if (sv.cov_ahead) {
       // the covariance half of the NEXT step's update: its regressor [psi(x_k); u_k] is complete now
       const double uk = (a.du_mode ? up : 0.0) + red[15];  // (the solve leaves its first move there)
-      const double gains = v2_rls_cov<L_, false>(img, t < L_ ? psin : (t == L_ ? uk : 0.0), a.lam);
+      const double gains = v2_rls_cov<L_, false>(img, (LIFT && half) ? 0.0 : (t < L_ ? psin : (t == L_ ? uk : 0.0)), a.lam);
       if (!half || t < L_) sCov[v2_cov_index<L_>(tid)] = gains;
     }
   }
