@@ -340,3 +340,22 @@ def test_bench_one_rank_rccl_reports_ranks_seen(torch_mod):
     pg = d["config"]["process_group"]
     assert pg["world_size"] == 1 and pg["backend"] == "nccl" and pg["rccl_ranks_seen"] == 1
     assert d["config"]["worst_qp_status"] == 0 and d["config"]["finite"] is True
+
+
+def test_two_rccl_ranks_on_one_gpu_are_refused_cleanly(torch_mod):
+    """The world > 1 branch of koopmpc.sharding.NcclCommunicator on the only hardware a pool box has: two processes, both on cuda:0.
+    The unique id travels from rank 0 over the (gloo) process group, both ranks pass the hash check, both call
+    ncclCommInitRank(world = 2) -- and RCCL refuses two ranks on one device (ncclInvalidUsage, code 5: duplicate GPU).  What the test
+    pins: that branch runs to the RCCL call on both ranks, and a failure there is an exception and a non-zero exit on EVERY rank within
+    seconds -- not a hang, not a re-exec.  (The same code with one GPU per rank is what the driver's 8-GPU run executes.)"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", "rccl_two_ranks_one_gpu.py")], cwd=ROOT, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=300)
+    out = p.stdout
+    assert p.returncode == 0, out[-2000:]
+    if "communicator refused" in out:
+        for r in (0, 1):
+            assert ("rank %d: communicator refused: ncclCommInitRank failed with code 5" % r) in out, out[-2000:]
+        assert out.count("| exit 3") == 2, out[-2000:]
+    else:  # (an RCCL that accepts two ranks on one device: then the sums must be right and RCCL must count two ranks)
+        for r in (0, 1):
+            assert ("rank %d: ncclAllReduce rc 0, ranks seen 2, sum 3.0" % r) in out, out[-2000:]
