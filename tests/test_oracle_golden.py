@@ -369,3 +369,68 @@ def test_matlab_lift_forms_and_rk4():
     x = np.array([0.4, -1.1])
     xp, xm = ko.plant_step("duffing", x, 0.7), ko.plant_step("duffing_matlab", x, 0.7)
     assert 1e-9 < np.abs(xp - xm).max() < 1e-4
+
+
+def test_delta_u_controller_against_a_literal_transcription_of_tank_system_m():
+    """cfg4's checker, OracleDeltaUController, restates Tank_System.m from its text (no MATLAB / Octave here and the reference holds no
+    fixture for it: VERDICT r4 weak 1).  A second, independent transcription pins it: (1) the condensed QP built the way the .m file
+    writes it -- A~ = [A B; 0 I], B~ = [B; I], C~ = C [I 0], Cy = [0 1] (:110-113, 265-268), Compact_Form1 rows Cy C~ A~^k by matrix
+    POWERS, Compact_Form2 by the Shift_Matrix construction (:272-288), H = CF2' Q_bar CF2 + R_bar, f = 2 (CF1 Lift_xu)' Q_bar CF2 -
+    2 Yr' Q_bar CF2 (:186, 287-289) -- equals the oracle's recursion-built H, f to rounding; (2) the cost the increments produce when
+    the ORIGINAL model x+ = A x + B u is simulated with absolute inputs u_k = U0 + sum dU (no augmentation at all) equals
+    dU' H dU + f' dU + const; (3) quadprog's constraint set -- A_cons / b_cons on the first increment (:182-185) inside the box
+    +-0.5 (:188) -- is the box the oracle folds it into, and the oracle's minimiser passes the KKT test of that constraint set."""
+    rng = np.random.RandomState(4)
+    L, n, N, Qw, Rw = 6, 2, 9, 10.0, 1e-3
+    A = 0.9 * np.linalg.qr(rng.randn(L, L))[0] + 0.05 * rng.randn(L, L)
+    B = rng.randn(L, 1)
+    C = rng.randn(n, L)
+    psi = rng.randn(L)
+    U0, umin, umax = 7.8, -8.0, 8.0
+    Yr = np.ones((N, 1))
+    ctl = ko.OracleDeltaUController(lambda x: x, L, n, N, A, B, C, cy0=1, q=1, Qw=Qw, Rw=Rw)
+    ctl.u = U0
+    At, Bt, Co, xt = ctl.qp(psi)
+    _, _, H, f, const = ko.condense(At, Bt, Co, xt, np.ones((1, N)), N, Qw, Rw)
+    # ---- (1) the .m file's own construction
+    nu = 1
+    Am = np.block([[A, B], [np.zeros((nu, L)), np.eye(nu)]])
+    Bm = np.concatenate([B, np.eye(nu)], axis=0)
+    Cm = C @ np.concatenate([np.eye(L), np.zeros((L, nu))], axis=1)
+    Cy = np.array([[0.0, 1.0]])
+    Shift = np.kron(np.concatenate([np.zeros((1, N)), np.concatenate([np.eye(N - 1), np.zeros((N - 1, 1))], axis=1)], axis=0), np.eye(nu))
+    CF1 = np.concatenate([Cy @ Cm @ np.linalg.matrix_power(Am, k) for k in range(1, N + 1)], axis=0)
+    CF2 = np.zeros((0, N))
+    for k in range(1, N + 1):
+        vt = np.zeros((1, 0))
+        for j in range(1, N + 1):
+            vt = np.concatenate([Cy @ Cm @ np.linalg.matrix_power(Am, j - 1) @ Bm, vt], axis=1)
+        CF2 = np.concatenate([vt @ np.linalg.matrix_power(Shift, k - 1), CF2], axis=0)
+    Qbar, Rbar = np.kron(np.eye(N), Qw * np.eye(1)), np.kron(np.eye(N), Rw * np.eye(1))
+    Hm = CF2.T @ Qbar @ CF2 + Rbar
+    Hm = (Hm + Hm.T) / 2
+    Lift_xu = np.concatenate([psi, [U0]]).reshape(-1, 1)
+    fm = (2 * (CF1 @ Lift_xu).T @ Qbar @ CF2 - 2 * Yr.T @ Qbar @ CF2).ravel()
+    assert np.abs(H - Hm).max() <= 1e-11 * np.abs(Hm).max() and np.abs(f - fm).max() <= 1e-11 * np.abs(fm).max()
+    # ---- (2) the original model simulated with absolute inputs
+    for _ in range(5):
+        dU = rng.uniform(-0.5, 0.5, N)
+        x, u, J = psi.copy(), U0, 0.0
+        for k in range(N):
+            u = u + dU[k]
+            x = A @ x + B[:, 0] * u
+            J += Qw * float((C @ x)[1] - 1.0) ** 2 + Rw * dU[k] ** 2
+        assert abs(J - (dU @ H @ dU + f @ dU + const)) <= 1e-10 * max(1.0, abs(J))
+    # ---- (3) the constraint set: first increment inside [umin - U0, umax - U0] and every increment inside +-0.5
+    u_new, dUo, _ = ctl.step(psi, np.ones((1, N)))  # (lift = identity: x is psi here)
+    lbv = np.full(N, -0.5); ubv = np.full(N, 0.5)
+    ubv[0] = min(0.5, umax - U0); lbv[0] = max(-0.5, umin - U0)
+    assert ubv[0] == pytest.approx(0.2) and abs(u_new - (U0 + dUo[0])) < 1e-15 and u_new <= umax + 1e-12
+    g = 2 * Hm @ dUo + fm
+    for i in range(N):  # KKT of min dU' H dU + f' dU over that set
+        if dUo[i] <= lbv[i] + 1e-9:
+            assert g[i] >= -1e-7 * max(1.0, np.abs(fm).max())
+        elif dUo[i] >= ubv[i] - 1e-9:
+            assert g[i] <= 1e-7 * max(1.0, np.abs(fm).max())
+        else:
+            assert abs(g[i]) <= 1e-7 * max(1.0, np.abs(fm).max())
