@@ -25,8 +25,12 @@ Rank 0 prints ONE JSON line.  `roofline` is for the dominant kernel: algorithmic
 formula, kmpc_algorithmic_bytes_per_step) x trajectories x steps per launch / its duration measured with
 HIP events on the launch stream in the timed pass itself; `flop_frac` (SURVEY 8d flop formulas with the
 measured Newton-solve count / 78.6 TFLOP/s) beside `hbm_frac`, `bound` = the governing one of the two.
-The default run (cfg2, one GPU) appends `other_configs`: short legs of cfg3, cfg3-L20, cfg4, cfg5 with the
-same K / W.  `cpu_baseline` times the NumPy oracle run the way the reference runs (per-trajectory Python
+The default run (cfg2, one GPU) appends `other_configs`: short legs of cfg4, cfg3, cfg3-L20, cfg5, cfg2 at
+16384 trajectories (a state beyond the Infinity Cache) and cfg2 behind float32 panels (BASELINE configs[1] names fp32)
+with the same K / W, and beside the headline: `replicas` (the timed window five more times: min / median / max of the
+kernel's fraction), `switch_window_*` (K steps from step 95 of a run that starts at the RLS reset: the plant's
+parameter switch of duffing.py:991-992 lies inside), `cold_start_*` (every QP from clip(0) like the reference) and
+`post_reset_*` (the same K steps right after the reset).  `cpu_baseline` times the NumPy oracle run the way the reference runs (per-trajectory Python
 loop, SciPy L-BFGS-B on the shooting cost, duffing.py:857-859) on a bounded sample of the same workload IN
 THE SAME REGIME (the settle steps after the reset are set-up, the steps after them are timed): one worker
 process per host core the process may use (affinity mask, capped by the cgroup quota; the count is in the line), forked before
@@ -852,7 +856,10 @@ def main():
     if dist is not None and args.backend == "nccl":
         from koopmpc.sharding import process_communicator
 
-        rccl_ranks_seen = process_communicator(dev).count()
+        try:
+            rccl_ranks_seen = process_communicator(dev).count()
+        except Exception as e:  # (reported in the line; the measurement above stands)
+            rccl_ranks_seen = "%s: %s" % (type(e).__name__, e)
     if rank == 0:
         total = B * world
         roof = res["roofline"]

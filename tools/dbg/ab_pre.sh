@@ -1,5 +1,8 @@
 #!/bin/bash
-# Dev tool (GPU box): the driver's window of cfg2 under several settings of the bench flow / the library's placement switches
+# Dev tool (GPU box): the driver's window of cfg2 (all legs, three replicas) under several environment settings of ONE library,
+# alternating:   LIB=libkoopmpc_dev.so tools/dbg/ab_pre.sh KMPC_PLACE_TAIL=5 KMPC_PLACE_TAIL=3 "X=1"
+# (round 5 used it with a KMPC_BENCH_PRE switch of bench.py -- the length of the launch in front of the timed one -- that is gone again:
+#  the launch in front is the W warm-up steps, as the driver runs it; profiles/r5_cfg2_placement_window.txt)
 root=${GRAFT_REPO_ROOT:-/root/repo}
 export KMPC_DEBUG=1
 for rep in 1 2; do for v in "$@"; do
