@@ -1060,6 +1060,7 @@ struct Impl : kmpc_handle {
     if (!X || !delta) FAIL(-3, "kmpc_shared_local_gram: null pointer");
     int rc = shared_alloc();
     if (rc) return rc;
+    if (core && (rc = ensure_dense(s, true))) return rc;  // (psi, u_{k-1} and the ping-pong index are this side's from here on)
     T* psi_now = dPsi[cur];
     T* psi_prev = dPsi[cur ^ 1];
     GramArgs<T> g{};
@@ -1150,6 +1151,7 @@ struct Impl : kmpc_handle {
       FAIL(-3, "kmpc_shared_solve: per-trajectory terminal blocks do not apply to the shared model (kmpc_terminal_from_dare with per_trajectory = 0)");
     int rc = shared_alloc();
     if (rc) return rc;
+    if (core && (rc = ensure_dense(s, true))) return rc;
     const T* wt = !have_wterm ? nullptr : (wterm_from_dare ? (const T*)dWtB : dWt);
     const int okind = cfg.output_kind == KMPC_OUT_LIFT ? OUT_LIFT : OUT_CX;
     const int cy0 = cfg.output_kind == KMPC_OUT_LIFT ? 0 : cfg.out_row0;
