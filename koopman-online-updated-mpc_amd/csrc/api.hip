@@ -944,6 +944,13 @@ struct Impl : kmpc_handle {
       HIPCHK(hipEventRecord(ev[ev_used + 1], s));  // (no separate lift kernel)
     }
     HIPCHK(launch_rollout_fused<T>(r, s));
+    // (profiling: the closing event sits right behind the roll-out kernel -- until round 5 it sat behind the rank pass below, whose
+    //  9 us at B = 4096 were counted into "the dominant kernel's duration": rocprofv3 0.630 ms against 0.647 ms from these events)
+    if (rec) {
+      HIPCHK(hipEventRecord(ev[ev_used + 2], s));
+      ev_used += 3;
+      prof_steps += steps;
+    }
     if (r.work && steps >= 4 && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= 16384) {
       if (!dPerm) HIPCHK(hipMalloc(&dPerm, sizeof(int32_t) * (size_t)B));
       HIPCHK(launch_place(dWork, B, dPerm, s));  // (the next launch's deal: RolloutArgs::perm)
@@ -955,11 +962,6 @@ struct Impl : kmpc_handle {
       if (!evPlace) HIPCHK(hipEventCreateWithFlags(&evPlace, hipEventDisableTiming));
       HIPCHK(hipEventRecord(evPlace, s));
       place_stream = s;
-    }
-    if (rec) {
-      HIPCHK(hipEventRecord(ev[ev_used + 2], s));
-      ev_used += 3;
-      prof_steps += steps;
     }
     // the host-side flags follow the kernel's own bookkeeping
     if (update_on && (steps >= 2 || (steps == 1 && have_prev))) rls_fresh = false;
