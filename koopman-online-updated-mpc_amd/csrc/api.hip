@@ -41,6 +41,10 @@ struct kmpc_handle {
   virtual int generate_and_fit(int plant, const void* X0, const void* U, int n_traj, int n_steps, double hs, double ridge,
                                int init_rls, void* A, void* B, void* C, void* Xo, void* Yo, hipStream_t s) = 0;
   int device = 0;
+  // the stream of the handle's last stream-ordered call (set by the C entry points): the few entry points that work on the null stream
+  // (kmpc_set_model, checkpoints, the first shared-model call) wait for THAT stream instead of the whole device (a
+  // device-wide synchronisation stalls the caller's unrelated streams and cannot be captured)
+  hipStream_t last_stream = nullptr;
   virtual int qp_solve(const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, hipStream_t s) = 0;
   virtual int step(const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it,
                    hipStream_t s) = 0;
@@ -260,6 +264,12 @@ struct Impl : kmpc_handle {
     if (evPlace) (void)hipEventDestroy(evPlace);
   }
 
+  // the handle's own outstanding work has finished (the stream of its last call, then the null stream the caller is about to use)
+  int sync_own() {
+    if (last_stream) HIPCHK(hipStreamSynchronize(last_stream));
+    HIPCHK(hipStreamSynchronize(nullptr));
+    return 0;
+  }
   // upload a (rows x cols) host double matrix into a zero-padded (prow x pcol) device matrix of T
   int upload_padded(T* dst, const double* src, int rows, int cols, int prow, int pcol) {
     std::vector<T> tmp((size_t)prow * pcol, T(0));
@@ -433,7 +443,7 @@ struct Impl : kmpc_handle {
     }
     // (a roll-out enqueued on a non-blocking stream may still be writing the wave image: the null-stream conversion below does
     //  not wait for such a stream by itself)
-    HIPCHK(hipDeviceSynchronize());
+    { int rc = sync_own(); if (rc) return rc; }
     { int rc = ensure_dense(nullptr, true); if (rc) return rc; }
     { int rc = forget_tableaux(nullptr); if (rc) return rc; }
     HIPCHK(hipMemcpy(dTmp, k.data(), k.size() * sizeof(T), hipMemcpyHostToDevice));
@@ -449,7 +459,7 @@ struct Impl : kmpc_handle {
       HIPCHK(hipMemcpy(dKs, dK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice));
       HIPCHK(hipMemcpy(dCs, dC, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice));
     }
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
   }
 
@@ -1052,8 +1062,8 @@ struct Impl : kmpc_handle {
     HIPCHK(hipMalloc(&dFs, sizeof(T) * (size_t)N * (L + 1)));  // (one more column in the delta-u form)
     HIPCHK(hipMalloc(&df0s, sizeof(T) * (size_t)N));
     // until samples exist the shared model is the offline one (trajectory 0's copy, duffing.py:811-813)
-    HIPCHK(hipDeviceSynchronize());  // (before the conversion: non-blocking streams do not order with the null stream)
-    { int rc = ensure_dense(nullptr, false); if (rc) return rc; HIPCHK(hipDeviceSynchronize()); }
+    { int rc = sync_own(); if (rc) return rc; }  // (before the conversion: non-blocking streams do not order with the null stream)
+    { int rc = ensure_dense(nullptr, false); if (rc) return rc; HIPCHK(hipStreamSynchronize(nullptr)); }
     HIPCHK(hipMemcpy(dKs, dK, sizeof(T) * (size_t)L * p, hipMemcpyDeviceToDevice));
     HIPCHK(hipMemcpy(dCs, dC, sizeof(T) * (size_t)n * L, hipMemcpyDeviceToDevice));
     return 0;
@@ -1311,11 +1321,11 @@ struct Impl : kmpc_handle {
   }
   int state_export(void* blob, int64_t bytes) override {
     if (bytes < state_bytes() || !blob) FAIL(-3, "kmpc_state_export: buffer too small");
-    HIPCHK(hipDeviceSynchronize());  // (a roll-out on a non-blocking stream may still be writing the wave image)
+    { int rc = sync_own(); if (rc) return rc; }  // (a roll-out on a non-blocking stream may still be writing the wave image)
     { int rc = ensure_dense(nullptr, false); if (rc) return rc; }
     { int rc = forget_tableaux(nullptr); if (rc) return rc; }  // (a checkpoint is a synchronisation point: exporter and importer continue alike)
     if (core) img_valid = false;  // (... a float32 handle from its float32 blocks, as the importer will, not from its core's unrounded state)
-    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipStreamSynchronize(nullptr));
     BlobHeader hd{};
     hd.magic = 0x4b4d5043; hd.version = 2; hd.dtype = cfg.dtype; hd.n = n; hd.L = L; hd.N = N; hd.B = B;
     hd.have_prev = have_prev ? 1 : 0; hd.rls_fresh = rls_fresh ? 1 : 0;
@@ -1360,7 +1370,7 @@ struct Impl : kmpc_handle {
     const int64_t wb = !hd.have_wterm ? 0 : (hd.wterm_from_dare ? (int64_t)sizeof(double) : (int64_t)sizeof(T)) * hd.wterm_blocks * q * q;
     const int64_t sb = hd.has_shared ? (int64_t)sizeof(double) * gram_elems() + (int64_t)sizeof(T) * ((int64_t)L * p + (int64_t)n * L) : 0;
     if (bytes < (int64_t)sizeof(BlobHeader) + (int64_t)sizeof(T) * base_elems() + sb + wb) FAIL(-3, "kmpc_state_import: buffer too small");
-    HIPCHK(hipDeviceSynchronize());
+    { int rc = sync_own(); if (rc) return rc; }
     dense_valid = true; img_valid = false;  // (the blob overwrites every dense block)
     { int rc = forget_tableaux(nullptr); if (rc) return rc; }
     if (hd.has_shared) { int rc = shared_alloc(); if (rc) return rc; }
@@ -1479,6 +1489,7 @@ int kmpc_destroy(kmpc_handle* h) {
 const char* kmpc_last_error(const kmpc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 #define NN(h) if (!(h)) return -1; DeviceGuard dev_guard_((h)->device)
+#define NNS(h, s) NN(h); (h)->last_stream = (hipStream_t)(s)
 int kmpc_set_encoder(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { NN(h); return h->set_encoder_layer(layer, W, b, rows, cols); }
 int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { return kmpc_set_encoder(h, layer, W, b, rows, cols); }
 int kmpc_set_centres(kmpc_handle* h, const double* cx, int L, int n) { NN(h); return h->set_centres(cx, L, n); }
@@ -1486,7 +1497,7 @@ int kmpc_set_model(kmpc_handle* h, const double* A, const double* B, const doubl
 int kmpc_set_terminal_weight(kmpc_handle* h, const double* PN) { NN(h); return h->set_terminal_weight(PN); }
 int kmpc_terminal_from_dare(kmpc_handle* h, const double* Q, double R, int maxiter, double eps, int per_trajectory,
                             double* PN_out, int32_t* iters_out, void* s) {
-  NN(h);
+  NNS(h, s);
   return h->terminal_from_dare(Q, R, maxiter, eps, per_trajectory, PN_out, iters_out, (hipStream_t)s);
 }
 int kmpc_solve_dare(const void* A, const void* B, const double* Q, double R, int maxiter, double eps, int nb, int L,
@@ -1514,42 +1525,42 @@ int kmpc_set_rollout_workgroup(int trajectories) {
   kmpc::set_rollout_workgroup(trajectories);
   return 0;
 }
-int kmpc_reset(kmpc_handle* h, void* s) { NN(h); return h->reset((hipStream_t)s); }
-int kmpc_state_init(kmpc_handle* h, double P0_scale, double barQ0_scale, void* s) { NN(h); return h->state_init(P0_scale, barQ0_scale, (hipStream_t)s); }
+int kmpc_reset(kmpc_handle* h, void* s) { NNS(h, s); return h->reset((hipStream_t)s); }
+int kmpc_state_init(kmpc_handle* h, double P0_scale, double barQ0_scale, void* s) { NNS(h, s); return h->state_init(P0_scale, barQ0_scale, (hipStream_t)s); }
 int kmpc_state_init_from(kmpc_handle* h, const double* K_A0, const double* P0, const double* barX0, const double* barQ0, void* s) {
-  NN(h);
+  NNS(h, s);
   return h->state_init_from(K_A0, P0, barX0, barQ0, (hipStream_t)s);
 }
-int kmpc_lift(kmpc_handle* h, const void* X, void* Psi, int B, void* s) { NN(h); return h->lift(X, Psi, B, (hipStream_t)s); }
-int kmpc_rls_update(kmpc_handle* h, const void* psi, const void* u, const void* psin, const void* xn, int B, void* s) { NN(h); return h->rls_update(psi, u, psin, xn, B, (hipStream_t)s); }
-int kmpc_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->get_model(A, B, C, (hipStream_t)s); }
-int kmpc_condense(kmpc_handle* h, const void* psi, const void* ref, int rpt, void* H, void* f, int B, void* s) { NN(h); return h->condense(psi, ref, rpt, H, f, nullptr, B, (hipStream_t)s); }
-int kmpc_condense_cost(kmpc_handle* h, const void* psi, const void* ref, int rpt, void* H, void* f, void* c, int B, void* s) { NN(h); return h->condense(psi, ref, rpt, H, f, c, B, (hipStream_t)s); }
+int kmpc_lift(kmpc_handle* h, const void* X, void* Psi, int B, void* s) { NNS(h, s); return h->lift(X, Psi, B, (hipStream_t)s); }
+int kmpc_rls_update(kmpc_handle* h, const void* psi, const void* u, const void* psin, const void* xn, int B, void* s) { NNS(h, s); return h->rls_update(psi, u, psin, xn, B, (hipStream_t)s); }
+int kmpc_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NNS(h, s); return h->get_model(A, B, C, (hipStream_t)s); }
+int kmpc_condense(kmpc_handle* h, const void* psi, const void* ref, int rpt, void* H, void* f, int B, void* s) { NNS(h, s); return h->condense(psi, ref, rpt, H, f, nullptr, B, (hipStream_t)s); }
+int kmpc_condense_cost(kmpc_handle* h, const void* psi, const void* ref, int rpt, void* H, void* f, void* c, int B, void* s) { NNS(h, s); return h->condense(psi, ref, rpt, H, f, c, B, (hipStream_t)s); }
 int kmpc_mpc_solve(kmpc_handle* h, const void* A, const void* Bv, const void* C, int shared, const void* psi, const void* ref, int rpt,
                    double lb, double ub, double Qw, double Rw, const double* PN, void* U, void* U0, void* fun, int32_t* st, int32_t* it,
                    int B, void* s) {
-  NN(h);
+  NNS(h, s);
   return h->mpc_solve(A, Bv, C, shared, psi, ref, rpt, lb, ub, Qw, Rw, PN, U, U0, fun, st, it, B, (hipStream_t)s);
 }
 int kmpc_generate_and_fit(kmpc_handle* h, int plant, const void* X0, const void* U, int n_traj, int n_steps, double hs, double ridge,
                           int init_rls, void* A, void* B, void* C, void* Xo, void* Yo, void* s) {
-  NN(h);
+  NNS(h, s);
   return h->generate_and_fit(plant, X0, U, n_traj, n_steps, hs, ridge, init_rls, A, B, C, Xo, Yo, (hipStream_t)s);
 }
-int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, void* s) { NN(h); return h->qp_solve(H, f, U, st, it, B, (hipStream_t)s); }
-int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
-int kmpc_set_applied_input(kmpc_handle* h, const void* U, int B, void* s) { NN(h); return h->set_applied_input(U, B, (hipStream_t)s); }
+int kmpc_qp_solve(kmpc_handle* h, const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, void* s) { NNS(h, s); return h->qp_solve(H, f, U, st, it, B, (hipStream_t)s); }
+int kmpc_step(kmpc_handle* h, const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NNS(h, s); return h->step(X, ref, rpt, U0, Useq, st, it, (hipStream_t)s); }
+int kmpc_set_applied_input(kmpc_handle* h, const void* U, int B, void* s) { NNS(h, s); return h->set_applied_input(U, B, (hipStream_t)s); }
 int kmpc_set_online_update(kmpc_handle* h, int on) { NN(h); return h->set_online_update(on); }
-int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NN(h); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
-int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NN(h); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
-int kmpc_offline_fit(kmpc_handle* h, const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A, void* B, void* C, void* s) { NN(h); return h->offline_fit(X, Y, U, M, ridge, init_rls, A, B, C, (hipStream_t)s); }
+int kmpc_plant_step(kmpc_handle* h, int plant, void* X, const void* U, double hs, int sw, int B, void* s) { NNS(h, s); return h->plant_step(plant, X, U, hs, sw, B, (hipStream_t)s); }
+int kmpc_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int rpt, int steps, int step0, int sw, double hs, void* Ulog, void* Xlog, int32_t* st, int32_t* it, void* s) { NNS(h, s); return h->rollout(plant, X, ref, rpt, steps, step0, sw, hs, Ulog, Xlog, st, it, (hipStream_t)s); }
+int kmpc_offline_fit(kmpc_handle* h, const void* X, const void* Y, const void* U, int M, double ridge, int init_rls, void* A, void* B, void* C, void* s) { NNS(h, s); return h->offline_fit(X, Y, U, M, ridge, init_rls, A, B, C, (hipStream_t)s); }
 int64_t kmpc_gram_elems(const kmpc_handle* h) { return h ? h->gram_elems() : -1; }
 // The one collective of the path for native callers: sum of the per-rank Gram blocks over an RCCL communicator.
 // RCCL is resolved at run time from the process (the caller created the communicator with the RCCL it loaded; under
 // PyTorch that is torch's own copy and KoopmanMPC.shared_step goes through torch.distributed instead) -- the library
 // itself does not link against it.
 int kmpc_allreduce_gram(kmpc_handle* h, double* delta, void* nccl_comm, void* s) {
-  NN(h);
+  NNS(h, s);
   if (!delta || !nccl_comm) return -3;
   typedef ncclResult_t (*allreduce_fn)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t);
   const allreduce_fn fn = (allreduce_fn)resolve_nccl_allreduce();
@@ -1557,18 +1568,18 @@ int kmpc_allreduce_gram(kmpc_handle* h, double* delta, void* nccl_comm, void* s)
   const ncclResult_t rc = fn(delta, delta, (size_t)h->gram_elems(), ncclDouble, ncclSum, (ncclComm_t)nccl_comm, (hipStream_t)s);
   return rc == ncclSuccess ? 0 : -(2000 + (int)rc);
 }
-int kmpc_shared_local_gram(kmpc_handle* h, const void* X, double* delta, void* s) { NN(h); return h->shared_local_gram(X, delta, (hipStream_t)s); }
+int kmpc_shared_local_gram(kmpc_handle* h, const void* X, double* delta, void* s) { NNS(h, s); return h->shared_local_gram(X, delta, (hipStream_t)s); }
 int kmpc_gram_accumulate(kmpc_handle* h, const void* X, double* delta, void* s) { return kmpc_shared_local_gram(h, X, delta, s); }
-int kmpc_shared_solve(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NN(h); return h->shared_solve(delta, ref, U0, Useq, st, it, (hipStream_t)s); }
+int kmpc_shared_solve(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it, void* s) { NNS(h, s); return h->shared_solve(delta, ref, U0, Useq, st, it, (hipStream_t)s); }
 int kmpc_shared_solve_plant(kmpc_handle* h, const double* delta, const void* ref, void* U0, void* Useq, int32_t* st, int32_t* it,
                             int plant, void* X, int switched, double hstep, void* s) {
-  NN(h);
+  NNS(h, s);
   return h->shared_solve_plant(delta, ref, U0, Useq, st, it, plant, X, switched, hstep, (hipStream_t)s);
 }
-int kmpc_shared_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NN(h); return h->shared_get_model(A, B, C, (hipStream_t)s); }
+int kmpc_shared_get_model(kmpc_handle* h, void* A, void* B, void* C, void* s) { NNS(h, s); return h->shared_get_model(A, B, C, (hipStream_t)s); }
 int kmpc_shared_rollout(kmpc_handle* h, int plant, void* X, const void* ref, int steps, int step0, int switch_step, double hstep, void* comm,
                         void* Ulog, void* Xlog, void* U0out, void* Useq, int32_t* st, int32_t* it, void* s) {
-  NN(h);
+  NNS(h, s);
   return h->shared_rollout(plant, X, ref, steps, step0, switch_step, hstep, comm, Ulog, Xlog, U0out, Useq, st, it, (hipStream_t)s);
 }
 int64_t kmpc_state_bytes(const kmpc_handle* h) { return h ? h->state_bytes() : -1; }
