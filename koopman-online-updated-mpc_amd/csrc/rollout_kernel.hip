@@ -318,7 +318,7 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
             double* const wsm0 = smem + woff0;
             const double uk = a.u_prev[bk0];  // u_{k-1}: the previous step stored it (u_store) when its solve ended
             const int t0 = lane & 31;
-            const double z0 = (Q_ == L_ && lane >= 32) ? 0.0 : (t0 < L_ ? psi_prev_reg : (t0 == L_ ? uk : 0.0));  // (y = psi: step_v2.h)
+            const double z0 = t0 < L_ ? psi_prev_reg : (t0 == L_ ? uk : 0.0);
             const double gains0 = v2_rls_cov<L_, true>(R.img + (size_t)bk0 * R.img_stride, z0, a.lam);
             if (lane < 32 || t0 < L_) v2_cov_slot<N_>(wsm0)[v2_cov_index<L_>(lane)] = gains0;
           } else {

@@ -2067,201 +2067,6 @@ __device__ __forceinline__ void step_body(const StepArgs<T>& a, const StepVar<T>
       const double bs = a.du_mode ? sK[rr * p + L] * (chain ? up : 1.0) : 0.0;
       block_sync_lds<TPB>();  // (C may sit where g is written from now on)
       int cur = 0;
-#ifdef KMPC_EXP_KRYLOV8
-      if (!a.du_mode) {
-        // Round 5, MEASURED AND NOT SHIPPED (compile-time experiment): kernel 2.50 -> 3.14 ms at 32768 trajectories (results unchanged:
-        // parity probe 2.4e-12, tests green).  The idea below assumed that float64 MFMA work runs BESIDE the float64 vector work of the
-        // other waves; on gfx950 it does not come for free -- the scheme issues 288 MFMAs per wave (590 kflop, the three squarings
-        // alone 393) in place of 209 kflop of row-broadcast multiply-adds, and the launch got longer by about that ratio of the
-        // recursion's share: the f64 matrix rate of CDNA4 equals its f64 vector rate (78.6 TFLOP/s both), the two compete.
-        // The recursion in strides of EIGHT on the matrix cores.  The kernel is bound by vector-instruction issue (VALU busy
-        // 82 % of the wave cycles, profiles/r4_cfg5_summary.txt) and the recursion's 51 x 32 row-broadcast multiply-adds (+ their
-        // gathers, LDS traffic and barriers) were a third of its 7 000 vector instructions per wave, while the matrix pipe did nothing.
-        //   (a) v_1 .. v_7, w_1 .. w_7 by the rows of A as before (eight rounds; every thread that owns a vector element keeps it),
-        //   (b) A <- A^2 <- A^4 <- A^8 in place on v_mfma_f64_16x16x4_f64 (wave w = row tile w, four column tiles),
-        //   (c) wave w takes its sixteen rows of A^8 as A-fragments into registers -- from here on the 33 KB of the model block are free --,
-        //   (d) V = [v_0 .. v_7 | w_0 .. w_7] is ONE 64 x 16 B-operand: V <- A^8 V gives the next eight vectors of BOTH chains in
-        //       sixteen MFMAs per wave and round, six rounds to the horizon's end; the outputs C_o v_j, C_o w_j are wave sums as before.
-        // Arithmetic: the same products in another association (A^8 v instead of A (A (... v))): outputs to ~1e-12 relative of the
-        // sequential recursion at rho(A) <= 1.2.
-        typedef double d4k __attribute__((ext_vector_type(4)));
-        constexpr int S8 = 8, LDV = 16;
-        static_assert(N_ > S8, "Krylov stride");
-        const int mt = tid >> 6, kq = ln >> 4, cc = ln & 15;
-        double keep[S8];  // threads with hh == 0: element rr of v_0 .. v_7 (chain 0) / w_0 .. w_7 (chain 1)
-        keep[0] = (chain ? sW : sV)[rr];
-        // ---- (a)
-#pragma unroll
-        for (int j0 = 0; j0 < S8; j0 += 4) {
-          double pc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            double* const vb = (chain ? sW : sV) + cur * L;
-            const double x0 = vb[hh * 32 + l16], x1 = vb[hh * 32 + 16 + l16];
-            pc[u] = co * vb[ln];
-            if (j + 1 < S8) {
-              double ac4[4] = {0.0, 0.0, 0.0, 0.0};
-              chain_dot<32>(ac4, x0, x1, row);
-              const double part = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
-              double pa, pb;
-              half_gather(part, pa, pb);
-              const double acc = pa + pb;
-              keep[j + 1] = acc;
-              if (hh == 0) (chain ? sW : sV)[(cur ^ 1) * L + rr] = acc;  // v_{j+1} / w_{j+1}
-            }
-            block_sync_lds<TPB>();
-            cur ^= 1;
-          }
-          const double g4 = wave_sum4(pc[0], pc[1], pc[2], pc[3], ln);
-          const int j = j0 + ln;  // lane u < 4 of the wave holds the output of step j0 + u
-          if (ln < 4 && corow < q) {
-            if (chain == 0) sG[j * q + corow] = g4;              // g_j = Co v_j
-            else if (j >= 1) sEr[(j - 1) * q + corow] += g4;     // e_j = Co w_j - r_{j-1}
-          }
-        }
-        // ---- (b) three squarings in place (every wave reads its fragments of the old power, barrier, writes its stripe of the new one)
-        double afr[16];
-#pragma unroll 1
-        for (int sq = 0; sq < 3; ++sq) {
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) afr[ks] = sK[(16 * mt + cc) * (L_ + 1) + 4 * ks + kq];
-          d4k acc2[4];
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            d4k c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks)
-              c = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], sK[(4 * ks + kq) * (L_ + 1) + 16 * nt + cc], c, 0, 0, 0);
-            acc2[nt] = c;
-          }
-          block_sync_lds<TPB>();
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sK[(16 * mt + kq + 4 * r) * (L_ + 1) + 16 * nt + cc] = acc2[nt][r];
-          block_sync_lds<TPB>();
-        }
-        // ---- (c) this wave's rows of A^8 as A-fragments; then the model block is free: the two V buffers take its place
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) afr[ks] = sK[(16 * mt + cc) * (L_ + 1) + 4 * ks + kq];
-        block_sync_lds<TPB>();
-        double* const Vb0 = sK;
-        double* const Vb1 = sK + L_ * LDV;
-        if (hh == 0) {
-#pragma unroll
-          for (int i = 0; i < S8; ++i) Vb0[rr * LDV + chain * S8 + i] = keep[i];
-        }
-        block_sync_lds<TPB>();
-        // ---- (d)
-        int vcur = 0;
-#pragma unroll 1
-        for (int rd = 1; S8 * rd <= N; ++rd) {
-          const double* const Vc = vcur ? Vb1 : Vb0;
-          double* const Vn = vcur ? Vb0 : Vb1;
-          d4k c0 = {0.0, 0.0, 0.0, 0.0}, c1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int ks = 0; ks < 16; ks += 2) {
-            c0 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], Vc[(4 * ks + kq) * LDV + cc], c0, 0, 0, 0);
-            c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks + 1], Vc[(4 * ks + 4 + kq) * LDV + cc], c1, 0, 0, 0);
-          }
-#pragma unroll
-          for (int r = 0; r < 4; ++r) Vn[(16 * mt + kq + 4 * r) * LDV + cc] = c0[r] + c1[r];
-          block_sync_lds<TPB>();
-          // outputs of the eight new vectors of this wave's chain: lane l < 4 of the wave collects columns l and 4 + l
-          const double* const vcol = Vn + ln * LDV + chain * S8;
-          const double ga = wave_sum4(co * vcol[0], co * vcol[1], co * vcol[2], co * vcol[3], ln);
-          const double gb = wave_sum4(co * vcol[4], co * vcol[5], co * vcol[6], co * vcol[7], ln);
-          if (ln < 4 && corow < q) {
-#pragma unroll
-            for (int hfl = 0; hfl < 2; ++hfl) {
-              const int j = S8 * rd + 4 * hfl + ln;
-              const double g4 = hfl ? gb : ga;
-              if (j <= N) {
-                if (chain == 0) { if (j < N) sG[j * q + corow] = g4; }
-                else sEr[(j - 1) * q + corow] += g4;
-              }
-            }
-          }
-          vcur ^= 1;
-        }
-      } else
-#endif
-#ifdef KMPC_EXP_A2
-      if (!a.du_mode) {
-        // Round 4 -- double steps with A^2: v_{j+2} = A^2 v_j, the even and the odd vectors of a chain advance together (twice the
-        // multiply-adds per barrier round, half the rounds: the recursion's pace is its 51 rounds of LDS write - barrier - LDS
-        // read, 0.39 us each, not its arithmetic).  A^2 on the matrix cores (wave w = row tile w, four column tiles), written over
-        // A in LDS; the vectors of a chain alternate between two pairs of buffers (the second pair where C, psi and the tail of
-        // region 1 were).
-        double* const Eb[2] = {chain ? sW : sV, chain ? sy : sC};
-        double* const Ob[2] = {(chain ? sW : sV) + L_, chain ? sX + L_ * (L_ + 1) : sC + L_};
-        {  // v_1 = A v_0, w_1 = A w_0 with the rows of A
-          const double x0 = Eb[0][hh * 32 + l16], x1 = Eb[0][hh * 32 + 16 + l16];
-          double ac4[4] = {0.0, 0.0, 0.0, 0.0};
-          chain_dot<32>(ac4, x0, x1, row);
-          const double part = (ac4[0] + ac4[1]) + (ac4[2] + ac4[3]);
-          double pa, pb;
-          half_gather(part, pa, pb);
-          if (hh == 0) Ob[0][rr] = pa + pb;
-        }
-        {  // A^2
-          typedef double d4a __attribute__((ext_vector_type(4)));
-          const int mt = tid >> 6;
-          double afr[16];
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) afr[ks] = sK[(16 * mt + (ln & 15)) * (L_ + 1) + 4 * ks + (ln >> 4)];
-          d4a acc2[4];
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt) {
-            d4a c = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int ks = 0; ks < 16; ++ks)
-              c = __builtin_amdgcn_mfma_f64_16x16x4f64(afr[ks], sK[(4 * ks + (ln >> 4)) * (L_ + 1) + 16 * nt + (ln & 15)], c, 0, 0, 0);
-            acc2[nt] = c;
-          }
-          block_sync_lds<TPB>();  // every wave has read its fragments of A (and v_1, w_1 are in place)
-#pragma unroll
-          for (int nt = 0; nt < 4; ++nt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) sK[(16 * mt + (ln >> 4) + 4 * r) * (L_ + 1) + 16 * nt + (ln & 15)] = acc2[nt][r];
-          block_sync_lds<TPB>();
-#pragma unroll
-          for (int l = 0; l < 32; ++l) row[l] = sK[rr * p + hh * 32 + l];
-        }
-        // pairs (v_2m, v_2m+1) -> (v_2m+2, v_2m+3); the outputs of two pairs are reduced together
-        for (int m0 = 0; 2 * m0 <= N; m0 += 2) {
-          double pc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int u = 0; u < 2; ++u) {
-            const int j = 2 * (m0 + u);  // inputs v_j, v_j+1
-            if (j <= N) {
-              const double* const ve = Eb[cur];
-              const double* const vo = Ob[cur];
-              const double xe0 = ve[hh * 32 + l16], xe1 = ve[hh * 32 + 16 + l16];
-              const double xo0 = vo[hh * 32 + l16], xo1 = vo[hh * 32 + 16 + l16];
-              pc[2 * u] = co * ve[ln];
-              pc[2 * u + 1] = co * vo[ln];
-              double ae[4] = {0.0, 0.0, 0.0, 0.0}, ao[4] = {0.0, 0.0, 0.0, 0.0};
-              chain_dot<32>(ae, xe0, xe1, row);
-              chain_dot<32>(ao, xo0, xo1, row);
-              double pa, pb, qa, qb;
-              half_gather((ae[0] + ae[1]) + (ae[2] + ae[3]), pa, pb);
-              half_gather((ao[0] + ao[1]) + (ao[2] + ao[3]), qa, qb);
-              if (hh == 0 && j + 2 <= N) { Eb[cur ^ 1][rr] = pa + pb; Ob[cur ^ 1][rr] = qa + qb; }
-              block_sync_lds<TPB>();
-              cur ^= 1;
-            }
-          }
-          const double g4 = wave_sum4(pc[0], pc[1], pc[2], pc[3], ln);
-          const int j = 2 * m0 + ln;  // lane u < 4 of the wave holds the output of step 2 m0 + u
-          if (ln < 4 && corow < q && j <= N) {
-            if (chain == 0) { if (j < N) sG[j * q + corow] = g4; }
-            else if (j >= 1) sEr[(j - 1) * q + corow] += g4;
-          }
-        }
-      } else
-#endif
       for (int j0 = 0; j0 <= N; j0 += 4) {  // (the outputs of four steps are reduced together: wave_sum4)
         double pc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
