@@ -20,7 +20,9 @@ static thread_local std::string g_create_error;
 struct kmpc_handle {
   kmpc_config cfg{};
   std::string err;
-  virtual ~kmpc_handle() {}
+  virtual ~kmpc_handle() {
+    for (auto& mk : marks) (void)hipEventDestroy(mk.e);
+  }
   virtual int set_encoder_layer(int layer, const double* W, const double* b, int rows, int cols) = 0;
   virtual int set_centres(const double* cx, int L, int n) = 0;
   virtual int set_model(const double* A, const double* B, const double* C) = 0;
@@ -41,10 +43,46 @@ struct kmpc_handle {
   virtual int generate_and_fit(int plant, const void* X0, const void* U, int n_traj, int n_steps, double hs, double ridge,
                                int init_rls, void* A, void* B, void* C, void* Xo, void* Yo, hipStream_t s) = 0;
   int device = 0;
-  // the stream of the handle's last stream-ordered call (set by the C entry points): the few entry points that work on the null stream
-  // (kmpc_set_model, checkpoints, the first shared-model call) wait for THAT stream instead of the whole device (a
-  // device-wide synchronisation stalls the caller's unrelated streams and cannot be captured)
-  hipStream_t last_stream = nullptr;
+  // The few entry points that work on the null stream (kmpc_set_model, checkpoints, the first shared-model call) wait for the handle's OWN
+  // outstanding work instead of the whole device (a device-wide synchronisation stalls the caller's unrelated streams).
+  // What that work is: every stream-ordered entry point ends by recording a handle-owned event on its stream (one event per distinct
+  // stream the caller has used with this handle); sync_own() waits for those events.  An event stays valid after the caller has
+  // destroyed the stream, and a roll-out on stream A followed by a call on stream B leaves both recorded (the raw handle of
+  // "the last stream" dangled and covered one stream only).  Calls made while their stream is being captured into a graph leave no mark.
+  struct StreamMark { hipStream_t s; hipEvent_t e; unsigned long long age; };
+  std::vector<StreamMark> marks;
+  unsigned long long mark_clock = 0;
+  void mark_stream(hipStream_t s) {
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) { (void)hipGetLastError(); return; }
+    if (cap != hipStreamCaptureStatusNone) return;
+    StreamMark* m = nullptr;
+    for (auto& mk : marks)
+      if (mk.s == s) { m = &mk; break; }
+    if (!m) {
+      if (marks.size() >= 16) {  // (a caller that keeps making streams: the least recently used mark is waited for and reused)
+        m = &marks[0];
+        for (auto& mk : marks)
+          if (mk.age < m->age) m = &mk;
+        (void)hipEventSynchronize(m->e);
+        m->s = s;
+      } else {
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); return; }
+        marks.push_back(StreamMark{s, e, 0});
+        m = &marks.back();
+      }
+    }
+    m->age = ++mark_clock;
+    if (hipEventRecord(m->e, s) != hipSuccess) (void)hipGetLastError();
+  }
+  hipError_t sync_marks() {
+    for (auto& mk : marks) {
+      const hipError_t e = hipEventSynchronize(mk.e);
+      if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+  }
   virtual int qp_solve(const void* H, const void* f, void* U, int32_t* st, int32_t* it, int B, hipStream_t s) = 0;
   virtual int step(const void* X, const void* ref, int rpt, void* U0, void* Useq, int32_t* st, int32_t* it,
                    hipStream_t s) = 0;
@@ -264,9 +302,10 @@ struct Impl : kmpc_handle {
     if (evPlace) (void)hipEventDestroy(evPlace);
   }
 
-  // the handle's own outstanding work has finished (the stream of its last call, then the null stream the caller is about to use)
+  // the handle's own outstanding work has finished (the events behind its stream-ordered calls, then the null stream the caller is
+  // about to use)
   int sync_own() {
-    if (last_stream) HIPCHK(hipStreamSynchronize(last_stream));
+    HIPCHK(sync_marks());
     HIPCHK(hipStreamSynchronize(nullptr));
     return 0;
   }
@@ -463,13 +502,27 @@ struct Impl : kmpc_handle {
     return 0;
   }
 
+  // (a float32 handle's float64 core gets the block this handle itself works with -- PN - Qw I rounded to float32 -- so that the
+  //  fused roll-outs, the per-step entry points and a checkpoint loaded into another handle all use the same weight: core_weight)
+  int core_weight(const std::vector<T>* w) {
+    if (!core) return 0;
+    std::vector<double> pn;
+    if (w) {
+      pn.resize(w->size());
+      for (int r = 0; r < q; ++r)
+        for (int c2 = 0; c2 < q; ++c2) pn[(size_t)r * q + c2] = (double)(*w)[(size_t)r * q + c2] + (r == c2 ? cfg.Qw : 0.0);
+    }
+    const int rc = core->set_terminal_weight(w ? pn.data() : nullptr);
+    if (rc) err = core->err;
+    return rc;
+  }
   int set_terminal_weight(const double* PN) override {
-    if (core) { const int rc = core->set_terminal_weight(PN); if (rc) { err = core->err; return rc; } }
     wterm_from_dare = false;
-    if (!PN) { have_wterm = false; hostPN.clear(); return 0; }
+    if (!PN) { have_wterm = false; hostPN.clear(); return core_weight(nullptr); }
     std::vector<T> w((size_t)q * q);
     for (int r = 0; r < q; ++r)
       for (int c2 = 0; c2 < q; ++c2) w[(size_t)r * q + c2] = (T)(PN[(size_t)r * q + c2] - (r == c2 ? cfg.Qw : 0.0));
+    { const int rc = core_weight(&w); if (rc) return rc; }
     if (!dWt) HIPCHK(hipMalloc(&dWt, sizeof(T) * (size_t)q * q));
     HIPCHK(hipMemcpy(dWt, w.data(), w.size() * sizeof(T), hipMemcpyHostToDevice));
     hostPN.assign(PN, PN + (size_t)q * q);
@@ -1411,7 +1464,20 @@ struct Impl : kmpc_handle {
     }
     have_wterm = hd.have_wterm != 0; wterm_from_dare = hd.wterm_from_dare != 0; wterm_per_traj = hd.wterm_per_traj != 0;
     cfg.P0 = hd.P0; cfg.barQ0 = hd.barQ0;
-    return 0;
+    // the host copy of a given P_N (kmpc_mpc_solve with another Q re-forms the block from it) and -- float32 handle with a float64
+    // core -- the core's terminal weight follow the blob: the core only learns about a weight through set_terminal_weight, so a
+    // checkpoint loaded into a fresh handle would otherwise run its fused roll-outs WITHOUT the terminal block, and one without a block
+    // loaded over a handle that had one would keep using it
+    hostPN.clear();
+    if (have_wterm && !wterm_from_dare) {
+      std::vector<T> w((size_t)q * q);
+      HIPCHK(hipMemcpy(w.data(), dWt, sizeof(T) * w.size(), hipMemcpyDeviceToHost));
+      hostPN.resize(w.size());
+      for (int r = 0; r < q; ++r)
+        for (int c2 = 0; c2 < q; ++c2) hostPN[(size_t)r * q + c2] = (double)w[(size_t)r * q + c2] + (r == c2 ? cfg.Qw : 0.0);
+      return core_weight(&w);
+    }
+    return core_weight(nullptr);
   }
 
   int profile_enable(int on) override {
@@ -1423,11 +1489,12 @@ struct Impl : kmpc_handle {
   }
   int profile_read(double* ms2, int64_t* count, int reset_) override {
     double a0 = 0, a1 = 0;
-    if (core) {  // (the fused launches of a float32 handle are recorded by its core)
+    int64_t core_steps = 0;
+    if (core) {  // (the fused launches of a float32 handle are recorded by its core; both halves keep their totals on a non-resetting read)
       double c2[2] = {0, 0}; int64_t cc = 0;
       const int rc = core->profile_read(c2, &cc, reset_);
       if (rc) { err = core->err; return rc; }
-      a0 += c2[0]; a1 += c2[1]; prof_steps += cc;
+      a0 += c2[0]; a1 += c2[1]; core_steps = cc;
     }
     for (size_t i = 0; i + 2 < ev_used + 0 && i + 2 < ev.size(); i += 3) {
       HIPCHK(hipEventSynchronize(ev[i + 2]));
@@ -1437,8 +1504,8 @@ struct Impl : kmpc_handle {
       a0 += t0; a1 += t1;
     }
     if (ms2) { ms2[0] = a0; ms2[1] = a1; }
-    if (count) *count = prof_steps;  // control steps covered by the recorded launches
-    if (reset_ || core) { ev_used = 0; prof_steps = 0; }
+    if (count) *count = prof_steps + core_steps;  // control steps covered by the recorded launches
+    if (reset_) { ev_used = 0; prof_steps = 0; }
     return 0;
   }
 
@@ -1489,7 +1556,12 @@ int kmpc_destroy(kmpc_handle* h) {
 const char* kmpc_last_error(const kmpc_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
 
 #define NN(h) if (!(h)) return -1; DeviceGuard dev_guard_((h)->device)
-#define NNS(h, s) NN(h); (h)->last_stream = (hipStream_t)(s)
+// (stream-ordered entry points: when the call returns, the handle's event for this stream is recorded behind what it enqueued)
+struct StreamMarkAtExit {
+  kmpc_handle* h; hipStream_t s;
+  ~StreamMarkAtExit() { h->mark_stream(s); }
+};
+#define NNS(h, s) NN(h); StreamMarkAtExit mark_at_exit_{(h), (hipStream_t)(s)}
 int kmpc_set_encoder(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { NN(h); return h->set_encoder_layer(layer, W, b, rows, cols); }
 int kmpc_set_encoder_layer(kmpc_handle* h, int layer, const double* W, const double* b, int rows, int cols) { return kmpc_set_encoder(h, layer, W, b, rows, cols); }
 int kmpc_set_centres(kmpc_handle* h, const double* cx, int L, int n) { NN(h); return h->set_centres(cx, L, n); }

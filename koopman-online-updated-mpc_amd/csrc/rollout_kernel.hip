@@ -560,7 +560,11 @@ template <int L_, int N_, int Q_, typename IOT = double> static hipError_t launc
   RolloutArgs<double> k = a;
   const bool rbf = a.lift_rbf != 0;
   constexpr bool V2 = ro_v2<L_, N_, Q_>();
-  const int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
+  int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
+  // (float32 panels: workgroups of sixteen and eight trajectories are instantiated; a request for four -- kmpc_set_rollout_workgroup(4),
+  //  KMPC_ROLLOUT_WAVES=4 -- is served by eight: the register-state sets always fit eight per CU.  ADVICE r5: the handle reported a fused
+  //  roll-out and the launch then failed)
+  if (sizeof(IOT) == 4 && !rbf && waves == 4) waves = 8;
   if (waves == 0) return hipErrorInvalidValue;
   step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));
   if (!a.s.qp_scratch) return hipErrorInvalidValue;

@@ -74,8 +74,11 @@ class NcclCommunicator:
     ranks hold the SAME id (a hash all-gather: a rank that joined with another id would hang ncclCommInitRank for everybody) and
     joins with ncclCommInitRank.  Without a process group: a one-rank communicator.  The RCCL is the one that lives in the process
     (torch's own copy when it exports the symbols, else the system librccl) -- the one kmpc_shared_rollout resolves ncclAllReduce from.
-    Use `process_communicator()` for the one communicator a process needs; `with NcclCommunicator(...) as c:` / `destroy()` / garbage
-    collection release it (ncclCommDestroy: device buffers, proxy threads, xGMI channels)."""
+    Use `process_communicator()` for the one communicator a process needs.  Teardown is EXPLICIT: `with NcclCommunicator(...) as c:`
+    or `destroy()` / `destroy_process_communicator()` -- behind a barrier, with the streams that carry its collectives drained, on every
+    rank (ncclCommDestroy: device buffers, proxy threads, xGMI channels).  Garbage collection does NOT destroy a live communicator:
+    ranks reach their finalisers at unrelated moments (possibly with collectives still queued, possibly after HIP itself has shut
+    down), so `__del__` only warns about the leak."""
 
     def __init__(self, device=None):
         import ctypes as C
@@ -112,6 +115,7 @@ class NcclCommunicator:
         if rc != 0:
             raise RuntimeError("ncclCommInitRank failed with code %d" % rc)
         self.handle, self.world, self.rank = comm, world, rank
+        self.device = None if device is None else torch.device(device)
         n = self.count()
         if n != world:
             self.destroy()
@@ -144,10 +148,14 @@ class NcclCommunicator:
         return False
 
     def __del__(self):
-        try:
-            self.destroy()
-        except Exception:  # (interpreter shutdown: the library may be gone already)
-            pass
+        if getattr(self, "handle", None):
+            try:
+                import warnings
+
+                warnings.warn("NcclCommunicator of %d rank(s) was never destroyed: call destroy() / destroy_process_communicator() "
+                              "behind a barrier before the process ends" % getattr(self, "world", 1), ResourceWarning)
+            except Exception:  # (interpreter shutdown: the warnings machinery may be gone already)
+                pass
 
 
 _process_comm = None
@@ -159,6 +167,14 @@ def process_communicator(device=None):
     global _process_comm
     if _process_comm is None or _process_comm.handle is None:
         _process_comm = NcclCommunicator(device)
+    elif device is not None and _process_comm.device is not None:
+        import torch
+
+        want = torch.device(device)
+        have = _process_comm.device
+        if want.type == "cuda" and have.type == "cuda" and want.index is not None and have.index is not None and want.index != have.index:
+            raise RuntimeError("process_communicator: this process's RCCL communicator lives on %s, asked for %s "
+                               "(one process drives one GPU; destroy_process_communicator() first)" % (have, want))
     return _process_comm
 
 

@@ -1,0 +1,362 @@
+"""Round-6 parity tests of the HIP path (through the C ABI).
+
+  the configurations bench.py times, held against the oracle AT THE SIZE THEY ARE TIMED AT:
+     cfg4  8192 trajectories, kmpc_shared_rollout, pooled model + delta-u QPs                 Tank_System.m:170-291, Koopman_update.m:94-101
+     cfg5  32768 trajectories, four-wave step kernel, the plant switch inside                  duffing.py:823-1012, 991-992
+     cfg2 / cfg3  a fused launch whose 20 steps contain the plant switch (step 102)            duffing.py:991-992
+  advisor findings of round 5 (float32 handle: terminal weight through a checkpoint, a workgroup of four, non-resetting
+  profile reads; the handle's own stream marks)
+
+Runs on the MI355X box:  python -m pytest tests -m gpu
+"""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import koopman_oracle as ko
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def torch_mod():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a HIP device; there is no CPU fallback")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def KM(torch_mod):
+    from koopmpc import KoopmanMPC
+
+    return KoopmanMPC
+
+
+def _t(torch, a, dtype=None):
+    return torch.tensor(np.asarray(a), dtype=dtype or torch.float64, device="cuda:0")
+
+
+def _bench_controller(name, B):
+    """A BASELINE configuration exactly as bench.py builds it (Loop): controller, initial states, reference, oracle-side set-up."""
+    import torch
+
+    import bench
+
+    c = bench.CONFIGS[name]
+    w = bench.workload_inputs(name, c["L"], c["N"])
+    loop = bench.Loop(name, w, B, torch.float64, torch.device("cuda", 0), 0)
+    return c, w, loop
+
+
+# ------------------------------------------------------------------ cfg4 at 8192 trajectories
+def test_cfg4_full_size_shared_rollout_vs_oracle(torch_mod):
+    """BASELINE cfg4 at the size bench.py times it (8192 trajectories per GPU, controller built by bench.Loop), through
+    kmpc_shared_rollout -- lift + Gram sums -> [all-reduce] -> pooled model -> interior / box QPs -> tank plant, 34 steps from the reset,
+    the tank's parameter switch (Tank_System.m:193-196) at step 20 inside.  The loop is taken one native step at a time so that the pooled
+    model of every step can be exported (kmpc_shared_get_model).  Against the oracle:
+      (1) the pooled model itself at FULL size: SharedEdmd (Koopman_update.m:94-101) fed with the oracle's lift of all 8192 states and
+          the inputs the device applied -- [A B] and C of every step within 1e-6 of their scale (the Gram block's condition number is
+          ~1e10 here; the small-batch tests hold 1e-7);
+      (2) 20 randomly chosen trajectories x every step: the delta-u QP of OracleDeltaUController (Tank_System.m:110-113, 182-188,
+          265-268) on the exported pooled model, exact minimiser: |u - u_oracle| <= 1e-6 (the north star's tolerance)."""
+    torch = torch_mod
+    import bench
+
+    B = bench.CONFIGS["cfg4"]["B"]
+    c, w, loop = _bench_controller("cfg4", B)
+    assert loop.native and loop.comm is None
+    L, N = c["L"], c["N"]
+    lift_fn = lambda x: ko.mlp_lift(w["weights"], x)
+    r = w["ref"]
+    steps, sw = 34, 20
+    A, Bm, C = [t.cpu().numpy() for t in loop.m.shared_model()]  # (the offline fit: the model until transitions exist)
+    sh = ko.SharedEdmd(L, 2, P0=1e4, barQ0=1e4)
+    rng = np.random.RandomState(4)
+    pick = np.sort(rng.choice(B, 20, replace=False))
+    uabs = np.zeros(B)
+    prev = None
+    worst_u = worst_m = 0.0
+    compared = skipped = 0
+    for k in range(steps):
+        X = loop.X.cpu().numpy().copy()
+        Ul, Xl = loop.m.shared_rollout("tank", loop.X, loop.r, 1, step0=k, switch_step=sw, comm=None, log=True)
+        u = Ul[0].cpu().numpy()
+        st = loop.m.status.cpu().numpy()
+        assert (st <= 1).all(), k
+        Ag, Bg, Cg = [t.cpu().numpy() for t in loop.m.shared_model()]
+        Psi = lift_fn(X)
+        if prev is not None:
+            sh.add(*ko.SharedEdmd.gram(prev[0], prev[1], Psi, X))
+            A, Bm, C = sh.model()
+            scale = max(np.abs(A).max(), np.abs(Bm).max())
+            worst_m = max(worst_m, np.abs(Ag - A).max() / scale, np.abs(Bg - Bm).max() / scale, np.abs(Cg - C).max() / max(1e-3, np.abs(C).max()))
+        ctl = ko.OracleDeltaUController(lift_fn, L, 2, N, Ag, Bg, Cg)
+        for b in pick:
+            ctl.u = float(uabs[b])
+            At, Bt, Co, xt = ctl.qp(Psi[:, b])
+            _, _, H, f, _ = ko.condense(At, Bt, Co, xt, r, N, ctl.Qw, ctl.Rw)
+            lbv = np.full(N, ctl.lb); ubv = np.full(N, ctl.ub)
+            lbv[0] = max(ctl.lb, ctl.umin - uabs[b]); ubv[0] = min(ctl.ub, ctl.umax - uabs[b])
+            if st[b] != 0 or not np.linalg.cond(H) < 1e12:  # (a pooled model of the very first steps can make H numerically singular)
+                skipped += 1
+                continue
+            dU, _ = ko.qp_exact(H, f, lbv, ubv)
+            worst_u = max(worst_u, abs(uabs[b] + float(dU[0]) - u[b]))
+            compared += 1
+        # the plant the kernel advanced, for the sampled trajectories
+        for b in pick:
+            xo = ko.tank_step(X[:, b], float(u[b]), switched=(k >= sw))
+            assert np.abs(Xl[0, :, b].cpu().numpy() - xo).max() < 1e-9, (k, b)
+        uabs = u.copy()
+        prev = (Psi, u.copy())
+    print("cfg4, B = %d, %d native steps: pooled model vs SharedEdmd at full size %.2e; %d QPs of 20 trajectories vs the oracle "
+          "(%d skipped): max |u - u_oracle| %.2e" % (B, steps, worst_m, compared, skipped, worst_u))
+    assert compared >= 20 * 30
+    assert worst_m < 1e-6 and worst_u < 1e-6
+
+
+# ------------------------------------------------------------------ cfg5 at 32768 trajectories
+def test_cfg5_full_size_rollout_vs_oracle(torch_mod):
+    """BASELINE cfg5 at the size bench.py times it (32768 trajectories per GPU: 7 GB of per-trajectory state), bench.Loop's
+    controller, kmpc_rollout over 14 steps from the RLS reset with the Duffing parameter switch (duffing.py:991-992) at step 8 inside --
+    one lift launch + one four-wave step_kernel launch per step.  10 randomly chosen trajectories against per-trajectory oracle
+    controllers (gain-form RLS, exact QP, duffing.py:847-984) over all steps: |u - u_oracle| <= 1e-6, states 1e-9."""
+    torch = torch_mod
+    import bench
+
+    B = bench.CONFIGS["cfg5"]["B"]
+    c, w, loop = _bench_controller("cfg5", B)
+    L, N = c["L"], c["N"]
+    lift_fn = lambda x: ko.mlp_lift(w["weights"], x)
+    r = w["ref"]
+    A0, B0, C0 = [t.cpu().numpy() for t in loop.m.shared_model()]  # the device's offline fit (every trajectory's start, duffing.py:811-813)
+    X0 = loop.X.cpu().numpy().copy()
+    steps, sw = 14, 8
+    Ul, Xl = loop.m.rollout(c["plant"], loop.X, loop.r, steps, step0=0, switch_step=sw, log=True)
+    assert int(loop.m.status.max().item()) == 0
+    assert bool(torch.isfinite(loop.X).all())
+    Ul, Xl = Ul.cpu().numpy(), Xl.cpu().numpy()
+    rng = np.random.RandomState(5)
+    worst_u = worst_x = 0.0
+    for b in rng.choice(B, 10, replace=False):
+        ctl = ko.OracleController(lift_fn, L, 2, N, c["lb"], c["ub"], A0, B0, C0, P0=c["P0"], barQ0=c["barQ0"], rls="gain")
+        x = X0[:, b].copy()
+        for k in range(steps):
+            uo, _, _ = ctl.step(x, r)
+            worst_u = max(worst_u, abs(Ul[k, b] - uo))
+            ctl.prev = (ctl.prev[0], float(Ul[k, b]))  # (both sides regress on the applied input and continue from the device's state)
+            xo = ko.plant_step(c["plant"], x, float(Ul[k, b]), switched=(k >= sw))
+            worst_x = max(worst_x, float(np.abs(Xl[k, :, b] - xo).max()))
+            x = Xl[k, :, b].copy()
+    print("cfg5, B = %d, %d steps across the switch: 10 trajectories vs per-trajectory oracles: max |u - u_oracle| %.2e, |x - x_oracle| %.2e"
+          % (B, steps, worst_u, worst_x))
+    assert worst_u < 1e-6 and worst_x < 1e-9
+
+
+# ------------------------------------------------------------------ the plant switch inside a fused launch at full size
+@pytest.mark.parametrize("name", ["cfg2", "cfg3"])
+def test_fused_launch_with_the_switch_inside_full_size(torch_mod, name):
+    """bench.py's `switch_window` leg as a test: BASELINE cfg2 (4096 trajectories, (20, 20, 2)) / cfg3 (16384, (8, 30, 2)), bench.Loop's
+    controllers, 95 closed-loop steps from the RLS reset as one launch, then ONE fused K = 20 launch over steps 95..114 -- the plant's
+    parameters switch at step 102 (duffing.py:991-992) INSIDE it, while tableaux are carried and the covariance half of the update
+    runs a step ahead.  32 randomly chosen trajectories against per-trajectory oracle controllers from the reset on (all 115 steps,
+    gain-form RLS, exact QP): inputs within 1e-6 (north star), states within 1e-9."""
+    torch = torch_mod
+    import bench
+
+    B = bench.CONFIGS[name]["B"]
+    c, w, l1 = _bench_controller(name, B)
+    assert l1.m.rollout_is_fused()
+    X0 = l1.X.cpu().numpy().copy()
+    pre, K = bench.SWITCH_WINDOW_START, 20
+    assert pre < 102 <= pre + K - 1
+    Up, Xp = l1.m.rollout(c["plant"], l1.X, l1.r, pre, step0=0, log=True)
+    assert int(l1.m.status.max().item()) == 0
+    Ul, Xl = l1.m.rollout(c["plant"], l1.X, l1.r, K, step0=pre, log=True)
+    assert int(l1.m.status.max().item()) == 0
+    L, N = c["L"], c["N"]
+    Xo, Yo, Uo = w["data"]
+    rbf = c.get("lift") == "rbf"
+    lift_fn = (lambda x: ko.rbf_lift(x, w["centres"])) if rbf else (lambda x: ko.mlp_lift(w["weights"], x))
+    PX, PY = lift_fn(Xo), lift_fn(Yo)
+    Z = np.concatenate([PX, Uo[None, :]], 0)
+    ridge = 1e-9 if rbf else 0.0  # (the model the device fitted: kmpc_offline_fit = Gram form of duffing.py:152-177)
+    Gm = Z @ Z.T + ridge * np.eye(L + 1)
+    K0 = (PY @ Z.T) @ np.linalg.inv(Gm)
+    A0, B0 = K0[:, :L], K0[:, L:]
+    C0 = (Xo @ PX.T) @ np.linalg.inv(PX @ PX.T + ridge * np.eye(L))
+    Uall = np.concatenate([Up.cpu().numpy(), Ul.cpu().numpy()])
+    Xall = np.concatenate([Xp.cpu().numpy(), Xl.cpu().numpy()])
+    rng = np.random.RandomState(17)
+    worst_u = worst_x = worst_u_win = 0.0
+    r = w["ref"]
+    for b in rng.choice(B, 32, replace=False):
+        ctl = ko.OracleController(lift_fn, L, 2, N, c["lb"], c["ub"], A0, B0, C0, P0=c["P0"], barQ0=c["barQ0"], rls="gain")
+        if rbf:  # (vanderpol_RBF.py:434-438: the estimator continues from the offline samples)
+            ctl.gP = np.linalg.inv(Gm); ctl.gK = (PY @ Z.T) @ ctl.gP
+            ctl.gQ = np.linalg.inv(PX @ PX.T + ridge * np.eye(L)); ctl.gC = (Xo @ PX.T) @ ctl.gQ
+        x = X0[:, b].copy()
+        for k in range(pre + K):
+            uo, _, _ = ctl.step(x, r)
+            worst_u = max(worst_u, abs(Uall[k, b] - uo))
+            if k >= pre:
+                worst_u_win = max(worst_u_win, abs(Uall[k, b] - uo))
+            ctl.prev = (ctl.prev[0], float(Uall[k, b]))
+            xo = ko.plant_step(c["plant"], x, float(Uall[k, b]), switched=(k >= 102))
+            worst_x = max(worst_x, float(np.abs(Xall[k, :, b] - xo).max()))
+            x = Xall[k, :, b].copy()
+    print("%s, B = %d: fused launch over steps %d..%d (switch at 102 inside), 32 trajectories vs oracles from the reset: "
+          "max |u - u_oracle| %.2e (in the window %.2e), |x - x_oracle| %.2e" % (name, B, pre, pre + K - 1, worst_u, worst_u_win, worst_x))
+    assert worst_u < 1e-6 and worst_x < 1e-9
+
+
+# ------------------------------------------------------------------ advisor findings of round 5
+def _cfg2_f32(KM, torch, B, seed=101):
+    from koopmpc.synth import initial_states, offline_data, random_mlp_weights
+
+    L, N = 20, 20
+    w = random_mlp_weights(2, 100, 3, L, seed=2024)
+    Xo, Yo, Uo = offline_data()
+    PX, PY = ko.mlp_lift(w, Xo), ko.mlp_lift(w, Yo)
+    Z = np.concatenate([PX, Uo[None, :]], 0)
+    K0 = PY @ np.linalg.pinv(Z)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    model = (f32(K0[:, :L]), f32(K0[:, L:]), f32(Xo @ np.linalg.pinv(PX)))
+    X0 = f32(initial_states(B, seed=seed))
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+
+    def make():
+        m = KM(n=2, L=L, N=N, batch=B, weights=w, dtype=torch.float32, device="cuda:0")
+        m.set_model(*model)
+        return m
+    return w, X0, r, make
+
+
+def test_f32_handle_terminal_weight_travels_through_a_checkpoint(torch_mod, KM):
+    """ADVICE r5 (api.hip state_import): a KMPC_F32 handle runs its fused roll-outs on a float64 core, and the core only learns about a
+    terminal weight through set_terminal_weight.  (1) A checkpoint of a float32 handle WITH a terminal block, loaded into a fresh
+    float32 handle, gives the same next launch bit for bit -- and not the launch of a handle without the block (the block is in
+    effect).  (2) The reverse: a checkpoint WITHOUT a block loaded over a handle that holds one drops it."""
+    torch = torch_mod
+    B = 128
+    w, X0, r, make = _cfg2_f32(KM, torch, B)
+    PN = np.array([[400.0, 30.0], [30.0, 250.0]])
+    ma, mplain = make(), make()
+    ma.set_terminal_weight(PN)
+    assert ma.rollout_is_fused()
+    Xa = torch.tensor(X0, dtype=torch.float32, device="cuda:0").contiguous()
+    Xp = Xa.clone()
+    ma.rollout("duffing", Xa, r, 6)
+    mplain.rollout("duffing", Xp, r, 6)
+    assert not torch.equal(Xa, Xp)  # the terminal block changes the closed loop
+    sd = ma.state_dict()
+    mb = make()
+    mb.load_state_dict(sd)
+    Xb = Xa.clone()
+    Ua, _ = ma.rollout("duffing", Xa, r, 5, step0=6, log=True)
+    Ub, _ = mb.rollout("duffing", Xb, r, 5, step0=6, log=True)
+    assert torch.equal(Ua, Ub) and torch.equal(Xa, Xb)
+    # the per-step route of the restored handle uses the same block (float32 kernels on both)
+    ua, ub = ma.step(Xa, r).clone(), mb.step(Xb, r).clone()
+    assert torch.equal(ua, ub)
+    # (2) a blob without a block over a handle with one
+    sdp = mplain.state_dict()
+    mc = make()
+    mc.set_terminal_weight(PN)
+    mc.load_state_dict(sdp)
+    Xc, Xq = Xp.clone(), Xp.clone()
+    Uc, _ = mc.rollout("duffing", Xc, r, 5, step0=6, log=True)
+    Uq, _ = mplain.rollout("duffing", Xq, r, 5, step0=6, log=True)
+    assert torch.equal(Uc, Uq) and torch.equal(Xc, Xq)
+
+
+def test_f32_rollout_with_a_workgroup_of_four_requested(torch_mod, KM):
+    """ADVICE r5 (rollout_kernel.hip io32 launcher): kmpc_set_rollout_workgroup(4) is a public setting; the float32-panel roll-out only
+    has workgroups of sixteen and eight trajectories.  A KMPC_F32 handle must still run (eight serve the request) and give the result
+    of the default workgroup bit for bit -- a trajectory's arithmetic does not depend on the workgroup it sits in."""
+    torch = torch_mod
+    from koopmpc import _ffi
+
+    lib = _ffi.load()
+    B = 72
+    w, X0, r, make = _cfg2_f32(KM, torch, B, seed=3)
+    m16, m4 = make(), make()
+    X16 = torch.tensor(X0, dtype=torch.float32, device="cuda:0").contiguous()
+    X4 = X16.clone()
+    U16, _ = m16.rollout("duffing", X16, r, 9, log=True)
+    try:
+        assert lib.kmpc_set_rollout_workgroup(4) == 0
+        assert m4.rollout_is_fused()
+        U4, _ = m4.rollout("duffing", X4, r, 9, log=True)
+        torch.cuda.synchronize()
+    finally:
+        lib.kmpc_set_rollout_workgroup(0)
+    assert int(m4.status.max().item()) == 0
+    assert torch.equal(U16, U4) and torch.equal(X16, X4)
+
+
+def test_profile_read_without_reset_keeps_both_halves_of_a_f32_handle(torch_mod, KM):
+    """ADVICE r5 (api.hip profile_read): on a float32 handle the fused launches are recorded by the float64 core and the per-step
+    launches by the handle itself; a NON-resetting read must leave both records in place and count both."""
+    torch = torch_mod
+    B = 64
+    w, X0, r, make = _cfg2_f32(KM, torch, B, seed=8)
+    m = make()
+    X = torch.tensor(X0, dtype=torch.float32, device="cuda:0").contiguous()
+    m.profile(True)
+    m.rollout("duffing", X, r, 7)
+    for _ in range(3):
+        m.step(X, r)
+    p1 = m.profile_read(reset=False)
+    p2 = m.profile_read(reset=False)
+    assert p1["count"] == 10 and p2["count"] == 10, (p1, p2)
+    assert p1["step_ms"] > 0 and abs(p1["step_ms"] - p2["step_ms"]) < 1e-9
+    p3 = m.profile_read(reset=True)
+    assert p3["count"] == 10
+    p4 = m.profile_read(reset=True)
+    assert p4["count"] == 0 and p4["step_ms"] == 0.0
+    m.profile(False)
+
+
+def test_handle_waits_for_every_stream_it_was_used_on(torch_mod, KM):
+    """ADVICE r5 (api.hip sync_own): the entry points that work on the null stream (kmpc_set_model, checkpoints) wait for the handle's
+    own outstanding work through events recorded behind every stream-ordered call -- one per distinct stream.  A roll-out on stream A
+    followed by a call on stream B, then a checkpoint: the blob must be the state AFTER the roll-out (the raw `last stream` of round 5
+    covered B only), also when stream A's Python object has been dropped in between."""
+    torch = torch_mod
+    from koopmpc.synth import random_mlp_weights
+
+    L, N, B = 20, 20, 2048
+    w = random_mlp_weights(2, 100, 3, L, seed=6)
+    rng = np.random.RandomState(2)
+    A, Bm, Cm = rng.randn(L, L) * 0.1, rng.randn(L, 1) * 0.1, rng.randn(2, L) * 0.1
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X0 = 4 * rng.rand(2, B) - 2
+
+    def run(two_streams):
+        m = KM(n=2, L=L, N=N, batch=B, weights=w)
+        m.set_model(A, Bm, Cm)
+        X = _t(torch, X0)
+        torch.cuda.synchronize()
+        sa = torch.cuda.Stream()
+        with torch.cuda.stream(sa):
+            m.rollout("duffing", X, r, 60)  # (tens of milliseconds of work on stream A)
+        if two_streams:
+            sb = torch.cuda.Stream()
+            with torch.cuda.stream(sb):
+                m.Encoder(X0[:, :4])  # an unrelated, short call on stream B
+            del sb
+        del sa
+        blob = m.state_dict()["blob"].copy()  # kmpc_state_export: null stream + the handle's marks
+        torch.cuda.synchronize()
+        return blob, m.state_dict()["blob"].copy()
+
+    for two in (False, True):
+        early, late = run(two)
+        assert np.array_equal(early, late), "checkpoint taken before the roll-out on the other stream had finished (two_streams=%s)" % two
