@@ -175,6 +175,8 @@ hipError_t launch_dare(const DareArgs& a, hipStream_t s);
 
 size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2, bool lds_tableau = true);
 
+// layout version of StepArgs / RolloutArgs as the roll-out plug-ins see them (rollout_jit.hip): bump with any change of the two structs
+#define KMPC_PLUGIN_ABI 6001
 template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s);
 // true if (T, n, L, N, q, threads, lift kind) has a fused roll-out instantiation that fits in LDS
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf);

@@ -1,8 +1,20 @@
 // rollout_kernel.hip -- the fused roll-out: `steps` iterations of the reference loop body (duffing.py:823-1012) in ONE
 // launch, step_body (step_body.h) inside, encoder on MFMA.  Compiled as its own translation unit (in parallel with
 // step_kernel.hip); the trace build includes it into step_kernel.hip instead.
+//
+// Three kinds of translation unit include this file:
+//   rollout_kernel.o        the instantiations compiled into libkoopmpc.so (the dimension sets BASELINE.json and the reference's
+//                           scripts use) and the launchers / dispatch
+//   rollout_kernel_io32.o   the same sets behind float32 panels (KMPC_ROLLOUT_IO32_TU)
+//   a PLUG-IN               ONE dimension set, workgroup size and lift variant, compiled when a handle of a dimension set without a
+//                           built-in instantiation is created (KMPC_ROLLOUT_JIT_TU, rollout_jit.hip; rollout_plugin.hip drives hipcc
+//                           and keeps the code objects on disk): the fused path is a property of the library, not of a list
 #include "step_body.h"
 #include "step_v2.h"
+#ifdef KMPC_ROLLOUT_JIT_TU
+// a plug-in is self-contained: the library decides the workgroup size and hands it over, no debug switches are read
+#define dbg_env(name) ((const char*)nullptr)
+#endif
 
 namespace kmpc {
 
@@ -484,8 +496,14 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
 // CU); the RBF lift needs no cooperation, so the workgroup is as large as the per-trajectory LDS regions allow.
 // 0: does not fit.
 static int ro_one_region_r2(int n, int L, int q, int N) { return n * L <= N * q ? 0 : ((n * L + 1) & ~1); }  // (C where g goes, else its own region)
+// (step_lds_bytes of step_kernel.hip, restated on the constexpr layout functions so that a plug-in needs no symbol of the library)
+static size_t ro_step_lds_elems(int n, int L, int q, int N, int* r1, int* r2, bool lds_tableau) {
+  if (r1) *r1 = step_region1(L, N);
+  if (r2) *r2 = step_region2(n, L, N, lds_tableau);
+  return step_lds_elems(n, L, q, N, lds_tableau);
+}
 static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves, int Lp, int* wstride) {
-  size_t per_wave = (step_lds_bytes(n, L, q, N, sizeof(double), nullptr, nullptr, !tableau_saves_lds(N, L)) / sizeof(double) + 1) & ~(size_t)1;
+  size_t per_wave = (ro_step_lds_elems(n, L, q, N, nullptr, nullptr, !tableau_saves_lds(N, L)) + 1) & ~(size_t)1;
   if (ro_one_region_rt(L, N, q, rbf))
     per_wave = ((size_t)step_region1(L, N) + ro_one_region_r2(n, L, q, N) + vec_elems_one_region(n, L, q, N) + 1) & ~(size_t)1;
   const bool v2 = step_v2_dims(L, N, q);
@@ -498,7 +516,9 @@ static size_t rollout_lds_elems(int n, int L, int q, int N, bool rbf, int waves,
   if (elems < scratch) elems = scratch;
   return elems + ro_keep(Lp, waves);
 }
-#ifdef KMPC_ROLLOUT_IO32_TU
+#if defined(KMPC_ROLLOUT_JIT_TU)
+static int g_rollout_workgroup = 0;  // (unused: the library hands the workgroup size over)
+#elif defined(KMPC_ROLLOUT_IO32_TU)
 extern int g_rollout_workgroup;
 #else
 int g_rollout_workgroup = 0;  // kmpc_set_rollout_workgroup
@@ -556,17 +576,18 @@ static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, siz
   return hipGetLastError();
 }
 
-template <int L_, int N_, int Q_, typename IOT = double> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s) {
+// waves_in > 0: the workgroup size is the caller's decision (plug-ins: the library made it with rollout_waves)
+template <int L_, int N_, int Q_, typename IOT = double> static hipError_t launch_rollout_impl(const RolloutArgs<double>& a, hipStream_t s, int waves_in = 0) {
   RolloutArgs<double> k = a;
   const bool rbf = a.lift_rbf != 0;
   constexpr bool V2 = ro_v2<L_, N_, Q_>();
-  int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
+  int waves = waves_in > 0 ? waves_in : rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
   // (float32 panels: workgroups of sixteen and eight trajectories are instantiated; a request for four -- kmpc_set_rollout_workgroup(4),
   //  KMPC_ROLLOUT_WAVES=4 -- is served by eight: the register-state sets always fit eight per CU.  ADVICE r5: the handle reported a fused
   //  roll-out and the launch then failed)
   if (sizeof(IOT) == 4 && !rbf && waves == 4) waves = 8;
   if (waves == 0) return hipErrorInvalidValue;
-  step_lds_bytes(a.s.n, a.s.L, a.s.q, a.s.N, sizeof(double), &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));
+  ro_step_lds_elems(a.s.n, a.s.L, a.s.q, a.s.N, &k.s.r1, &k.s.r2, !tableau_saves_lds(a.s.N, a.s.L));
   if (!a.s.qp_scratch) return hipErrorInvalidValue;
   if (ro_one_region_rt(a.s.L, a.s.N, a.s.q, rbf)) k.s.r2 = ro_one_region_r2(a.s.n, a.s.L, a.s.q, a.s.N);
   if constexpr (V2) {
@@ -581,6 +602,13 @@ template <int L_, int N_, int Q_, typename IOT = double> static hipError_t launc
   if (lds > 160 * 1024) return hipErrorInvalidValue;
   // (the RBF lift never uses the template's tiling: one instantiation serves every workgroup size)
   const bool ks25 = !rbf && a.KS == 25 && a.Hp == 112;  // the reference's encoders: 100 hidden units
+#ifdef KMPC_ROLLOUT_JIT_TU
+  // a plug-in holds ONE kernel: KMPC_JIT_KS = -1 (RBF lift, any workgroup size), 25 or 0 (MLP lift) with KMPC_JIT_NW trajectories per workgroup
+  constexpr int JKS = KMPC_JIT_KS, JNW = JKS < 0 ? 16 : KMPC_JIT_NW;
+  if (rbf != (JKS < 0)) return hipErrorInvalidValue;
+  if (!rbf && (waves != JNW || ks25 != (JKS == 25))) return hipErrorInvalidValue;
+  return launch_rollout_nw<L_, N_, Q_, JNW, JKS, IOT>(k, waves, lds, s);
+#else
   if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1, IOT>(k, waves, lds, s);
   if constexpr (sizeof(IOT) == 4) {  // (float32 I/O: workgroups of sixteen and eight trajectories -- what rollout_waves picks for these sets)
     if (waves == 16) return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25, IOT>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0, IOT>(k, waves, lds, s);
@@ -601,9 +629,12 @@ template <int L_, int N_, int Q_, typename IOT = double> static hipError_t launc
     if (waves == 16) return ks25 ? launch_rollout_nw<L_, N_, Q_, 16, 25>(k, waves, lds, s) : launch_rollout_nw<L_, N_, Q_, 16, 0>(k, waves, lds, s);
   return hipErrorInvalidValue;
   }
+#endif  // KMPC_ROLLOUT_JIT_TU
 }
 
-#ifdef KMPC_ROLLOUT_IO32_TU
+#if defined(KMPC_ROLLOUT_JIT_TU)
+// (the plug-in's entry point: rollout_jit.hip)
+#elif defined(KMPC_ROLLOUT_IO32_TU)
 // the float32-I/O instantiations (register-state dimension sets), compiled as their own translation unit (rollout_kernel_io32.hip)
 hipError_t launch_rollout_io32(const RolloutArgs<double>& a, hipStream_t s) {
   if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;

@@ -124,9 +124,12 @@ def test_cfg4_full_size_shared_rollout_vs_oracle(torch_mod):
 # ------------------------------------------------------------------ cfg5 at 32768 trajectories
 def test_cfg5_full_size_rollout_vs_oracle(torch_mod):
     """BASELINE cfg5 at the size bench.py times it (32768 trajectories per GPU: 7 GB of per-trajectory state), bench.Loop's
-    controller, kmpc_rollout over 14 steps from the RLS reset with the Duffing parameter switch (duffing.py:991-992) at step 8 inside --
-    one lift launch + one four-wave step_kernel launch per step.  10 randomly chosen trajectories against per-trajectory oracle
-    controllers (gain-form RLS, exact QP, duffing.py:847-984) over all steps: |u - u_oracle| <= 1e-6, states 1e-9."""
+    controller, kmpc_rollout over 116 steps from the RLS reset with the Duffing parameter switch where the reference has it
+    (duffing.py:991-992: from step 102 on) -- one lift launch + one four-wave step_kernel launch per step, tableaux carried in global
+    memory.  8 randomly chosen trajectories against per-trajectory oracle controllers (gain-form RLS, exact QP, duffing.py:847-984)
+    over ALL steps: |u - u_oracle| <= 1e-6, states 1e-9; every QP of the batch solved (status 0).
+    (A switch a few steps after the reset -- tried first -- is not a test of anything: with fewer transitions than regressors the
+    estimator interpolates, the switched plant then gives models with spectral radius >> 1 and H = O(1e24) is not a QP in float64.)"""
     torch = torch_mod
     import bench
 
@@ -137,25 +140,28 @@ def test_cfg5_full_size_rollout_vs_oracle(torch_mod):
     r = w["ref"]
     A0, B0, C0 = [t.cpu().numpy() for t in loop.m.shared_model()]  # the device's offline fit (every trajectory's start, duffing.py:811-813)
     X0 = loop.X.cpu().numpy().copy()
-    steps, sw = 14, 8
+    steps, sw = 116, 102
     Ul, Xl = loop.m.rollout(c["plant"], loop.X, loop.r, steps, step0=0, switch_step=sw, log=True)
-    assert int(loop.m.status.max().item()) == 0
+    nbad = int((loop.m.status != 0).sum().item())
+    assert nbad == 0, "%d of %d trajectories left a QP with status != 0" % (nbad, B)
     assert bool(torch.isfinite(loop.X).all())
     Ul, Xl = Ul.cpu().numpy(), Xl.cpu().numpy()
     rng = np.random.RandomState(5)
-    worst_u = worst_x = 0.0
-    for b in rng.choice(B, 10, replace=False):
+    worst_u = worst_x = worst_u_sw = 0.0
+    for b in rng.choice(B, 8, replace=False):
         ctl = ko.OracleController(lift_fn, L, 2, N, c["lb"], c["ub"], A0, B0, C0, P0=c["P0"], barQ0=c["barQ0"], rls="gain")
         x = X0[:, b].copy()
         for k in range(steps):
             uo, _, _ = ctl.step(x, r)
             worst_u = max(worst_u, abs(Ul[k, b] - uo))
+            if k >= sw:
+                worst_u_sw = max(worst_u_sw, abs(Ul[k, b] - uo))
             ctl.prev = (ctl.prev[0], float(Ul[k, b]))  # (both sides regress on the applied input and continue from the device's state)
             xo = ko.plant_step(c["plant"], x, float(Ul[k, b]), switched=(k >= sw))
             worst_x = max(worst_x, float(np.abs(Xl[k, :, b] - xo).max()))
             x = Xl[k, :, b].copy()
-    print("cfg5, B = %d, %d steps across the switch: 10 trajectories vs per-trajectory oracles: max |u - u_oracle| %.2e, |x - x_oracle| %.2e"
-          % (B, steps, worst_u, worst_x))
+    print("cfg5, B = %d, %d steps from the reset, switch at %d: 8 trajectories vs per-trajectory oracles: max |u - u_oracle| %.2e "
+          "(after the switch %.2e), |x - x_oracle| %.2e" % (B, steps, sw, worst_u, worst_u_sw, worst_x))
     assert worst_u < 1e-6 and worst_x < 1e-9
 
 
