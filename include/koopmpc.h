@@ -264,7 +264,8 @@ int kmpc_plant_step(kmpc_handle* h, int plant, void* X_dev, const void* U_dev, d
  * switch_step = 102; pass a negative value for "never").  Optional outputs: U_log_dev (steps x B),
  * X_log_dev (steps x n x B, the state AFTER each plant step), status_dev[B] (worst QP status of
  * each trajectory over the call), iters_dev[B] (its total number of Newton solves).
- * For float64, single-wave configurations with a static instantiation (kmpc_rollout_is_fused) the whole
+ * For single-wave configurations (kmpc_rollout_is_fused: n = 2, y = C x with q <= 2 or y = psi, (L+1)^2 and N^2 <= 2048, as far as
+ * the LDS holds a workgroup) the whole
  * call is ONE kernel launch: 16 trajectories per workgroup, the encoder evaluated inside on MFMA, no
  * synchronisation between workgroups from the first step to the last.  Same results as the per-step
  * launches up to the summation order of the encoder (1e-12 on the controls).
@@ -309,6 +310,20 @@ int kmpc_profile_enable(kmpc_handle* h, int on);
 int kmpc_profile_read(kmpc_handle* h, double* ms2, int64_t* count, int reset);
 /* 1 if kmpc_rollout runs as one fused kernel for this handle's configuration, else 0         */
 int kmpc_rollout_is_fused(const kmpc_handle* h);
+/* Where that kernel comes from.  The reference's dimensions are constants edited in its scripts (duffing.py:66 Nlift, :632-633
+ * MPCHorizon; Koopman_update.m:67, 70, 113: L = 10, N = 10), so the fused roll-out is not tied to a list: libkoopmpc.so holds the
+ * instantiations of the BASELINE / reference dimension sets, and kmpc_create makes the kernel of any other set as a PLUG-IN --
+ * looked up in the kernel cache ($KMPC_KERNEL_CACHE, <library dir>/kernel_cache, ~/.cache/koopmpc), else compiled from the sources
+ * that ship next to the library (csrc/rollout_jit.hip) with hipcc ($KMPC_HIPCC, /opt/rocm/bin/hipcc): 4-8 s, once per set and machine.
+ * Returns 0: built-in instantiation, 1: plug-in, -1: the plug-in could not be made (the handle works with per-step launches),
+ * 2: the configuration has no fused roll-out; `text` (optional, text_bytes long) receives the file / the reason.                */
+int kmpc_rollout_plugin_status(const kmpc_handle* h, char* text, int text_bytes);
+/* Makes (or finds in the kernel cache) the plug-in that kmpc_create would load for a configuration with these dimensions: n, L, N,
+ * out_rows (0 = n; L for y = psi), lift_kind, the encoder's effective hidden width (kmpc_config.hidden, + 2 n with lift_offset 2),
+ * batch and dtype as in kmpc_config.  Needs no device (hipcc cross-compiles): for installers and for the first rank of a node.
+ * Returns 0 / 1 / -1 / 2 as kmpc_rollout_plugin_status, -3 for bad arguments.                                                   */
+int kmpc_rollout_plugin_prebuild(int n, int L, int N, int out_rows, int lift_kind, int hidden_eff, int batch, int dtype, char* text,
+                                 int text_bytes);
 /* Trajectories per workgroup of the fused roll-out kernel (MLP lift): 4, 8 or 16; 0 = automatic (most
  * trajectories per CU, ties to the larger workgroup).  Process-wide tuning / test knob: every
  * trajectory's arithmetic is the same for every choice, only the scheduling differs.

@@ -30,6 +30,7 @@ struct kmpc_handle {
   virtual int terminal_from_dare(const double* Qh, double R, int maxiter, double eps, int per_traj, double* PN_out,
                                  int32_t* iters_out, hipStream_t s) = 0;
   virtual int rollout_is_fused() const = 0;
+  virtual int rollout_plugin_status(std::string* text) const = 0;
   virtual int reset(hipStream_t s) = 0;
   virtual int state_init(double P0, double barQ0, hipStream_t s) = 0;
   virtual int state_init_from(const double* KA0, const double* P0m, const double* barX0, const double* barQ0m, hipStream_t s) = 0;
@@ -179,6 +180,11 @@ struct Impl : kmpc_handle {
   // float32 blocks of this handle are the form every other entry point works on.  Whichever side was written last is the valid one
   // (dense_valid / img_valid as for the wave image) and the other is rebuilt on demand by a cast over the blocks (core_push / core_pull).
   Impl<double>* core = nullptr;
+  bool is_core = false;  // this handle IS the float64 core of a float32 handle
+  // roll-out plug-in of this handle's dimension set (rollout_plugin.hip): 0 built-in set or no fused roll-out at all, 1 loaded, -1 could not be made
+  int plugin_state = 0;
+  RolloutPluginKey plugin_key{};
+  std::string plugin_msg;
   // four-wave solver (threads = 256, float64): every trajectory's last tableau and its variable set, kept from step to step
   // (StepArgs::qp_carry); any change of the model from outside forgets them (the next solve starts from 2H)
   T* dQpCarry = nullptr;
@@ -239,8 +245,21 @@ struct Impl : kmpc_handle {
       HIPCHK(hipMalloc(&dQpCarrySet, sizeof(int32_t) * (size_t)B * 4));
       HIPCHK(hipMemset(dQpCarrySet, 0, sizeof(int32_t) * (size_t)B * 4));
     }
+    // a dimension set without a built-in fused roll-out gets its kernel now (rollout_plugin.hip: kernel cache, else hipcc, 4-8 s);
+    // a set that cannot be served stays on per-step launches and kmpc_rollout_plugin_status says why
+    {
+      const bool rbf = c.lift_kind != KMPC_LIFT_MLP;
+      const int hid0 = c.hidden + (c.lift_offset == 2 ? 2 * n : 0), Hp0 = hid0 <= 112 ? 112 : 128, Lp0 = ((L + 15) / 16) * 16, KS0 = (hid0 + 3) / 4;
+      const bool io32 = sizeof(T) == 4;
+      const bool wanted = threads == 64 && n == 2 && !is_core && (c.lift_kind != KMPC_LIFT_MLP || (hid0 >= 1 && hid0 <= 128)) &&
+                          (io32 ? (c.output_kind != KMPC_OUT_LIFT && !c.delta_u && rollout_io32_available(n, L, N, q, rbf) && !dbg_env("KMPC_NO_IO32_ROLLOUT"))
+                                : rollout_fused_available<double>(n, L, N, q, threads, rbf));
+      if (wanted && rollout_plugin_key(n, L, N, q, rbf, Lp0, KS0, Hp0, B, io32, &plugin_key)) {
+        plugin_state = rollout_plugin_get(plugin_key, &plugin_msg) ? 1 : -1;
+      }
+    }
     if constexpr (sizeof(T) == 8) {
-      use_img = threads == 64 && (c.output_kind != KMPC_OUT_LIFT || q == L) && rollout_uses_image(n, L, N, q) &&
+      use_img = threads == 64 && plugin_state >= 0 && (c.output_kind != KMPC_OUT_LIFT || q == L) && rollout_uses_image(n, L, N, q) &&
                 rollout_fused_available<T>(n, L, N, q, threads, c.lift_kind != KMPC_LIFT_MLP);
       if (use_img) {
         sImg = state_image_elems(L, n);
@@ -248,11 +267,12 @@ struct Impl : kmpc_handle {
       }
     }
     if constexpr (sizeof(T) == 4) {
-      if (threads == 64 && c.output_kind != KMPC_OUT_LIFT && !c.delta_u && rollout_io32_available(n, L, N, q, c.lift_kind != KMPC_LIFT_MLP) &&
+      if (threads == 64 && plugin_state >= 0 && c.output_kind != KMPC_OUT_LIFT && !c.delta_u && rollout_io32_available(n, L, N, q, c.lift_kind != KMPC_LIFT_MLP) &&
           !dbg_env("KMPC_NO_IO32_ROLLOUT")) {  // (the variable is a measurement / test aid: float32 handles as per-step launches)
         kmpc_config c64 = c;
         c64.dtype = KMPC_F64;
         core = new Impl<double>();
+        core->is_core = true;  // (its launches carry float32 panels: this handle's plug-in, loaded above, serves them)
         const int rc = core->init(c64);
         if (rc) { err = "float64 core of the float32 handle: " + core->err; delete core; core = nullptr; return rc; }
       }
@@ -933,7 +953,16 @@ struct Impl : kmpc_handle {
   bool fused_rollout_ok() const {
     static const bool off = dbg_env("KMPC_NO_FUSED_ROLLOUT") != nullptr;  // measurement aid: per-step launches
     if (core) return !off && core->fused_rollout_ok();  // (float32 panels around the float64 roll-out)
-    return !off && n == 2 && rollout_fused_available<T>(n, L, N, q, threads, cfg.lift_kind != KMPC_LIFT_MLP);
+    return !off && n == 2 && plugin_state >= 0 && rollout_fused_available<T>(n, L, N, q, threads, cfg.lift_kind != KMPC_LIFT_MLP);
+  }
+  // 0: the library's own instantiation, 1: a plug-in (text: its file and whether it was compiled now or found in the kernel cache),
+  // -1: the plug-in could not be made (text: why; the handle works with per-step launches), 2: this configuration has no fused roll-out
+  int rollout_plugin_status(std::string* text) const override {
+    if (plugin_state > 0) { if (text) *text = rollout_plugin_describe(plugin_key); return 1; }
+    if (plugin_state < 0) { if (text) *text = plugin_msg; return -1; }
+    if (!fused_rollout_ok()) { if (text) *text = "no fused roll-out for this configuration (per-step launches)"; return 2; }
+    if (text) *text = "built-in instantiation of libkoopmpc.so";
+    return 0;
   }
   // io32: the caller-owned panels (X, ref, Ulog, Xlog, U0out, Useqout) are float32 -- the call comes from a KMPC_F32 handle's core
   int rollout_fused(int plant, void* X, const void* ref, int rpt, int steps, int step0, int switch_step, double hs,
@@ -1592,6 +1621,30 @@ int kmpc_solve_dare(const void* A, const void* B, const double* Q, double R, int
   return rc;
 }
 int kmpc_rollout_is_fused(const kmpc_handle* h) { NN(h); return h->rollout_is_fused(); }
+// Makes (or finds) the plug-in a handle of this configuration would load -- no device needed: hipcc cross-compiles.  For builds that
+// want the kernel cache filled before the first kmpc_create (__graft_entry__.build(), an installer, the first rank of a node).
+int kmpc_rollout_plugin_prebuild(int n, int L, int N, int out_rows, int lift_kind, int hidden_eff, int batch, int dtype, char* text, int text_bytes) {
+  auto say = [&](const std::string& t) { if (text && text_bytes > 0) snprintf(text, (size_t)text_bytes, "%s", t.c_str()); };
+  const bool rbf = lift_kind != KMPC_LIFT_MLP;
+  const int q = out_rows > 0 ? out_rows : n;
+  if (n != 2 || L < 1 || N < 1 || batch < 1 || (!rbf && (hidden_eff < 1 || hidden_eff > 128)) || (dtype != KMPC_F32 && dtype != KMPC_F64)) { say("bad arguments"); return -3; }
+  const int Hp = hidden_eff <= 112 ? 112 : 128, Lp = ((L + 15) / 16) * 16, KS = (hidden_eff + 3) / 4;
+  const bool io32 = dtype == KMPC_F32;
+  if (!(io32 ? rollout_io32_available(n, L, N, q, rbf) : rollout_fused_available<double>(n, L, N, q, 64, rbf))) { say("no fused roll-out for this configuration"); return 2; }
+  RolloutPluginKey k{};
+  if (!rollout_plugin_key(n, L, N, q, rbf, Lp, KS, Hp, batch, io32, &k)) { say("built-in instantiation of libkoopmpc.so"); return 0; }
+  std::string err;
+  if (!rollout_plugin_get(k, &err)) { say(err); return -1; }
+  say(rollout_plugin_describe(k));
+  return 1;
+}
+int kmpc_rollout_plugin_status(const kmpc_handle* h, char* text, int text_bytes) {
+  if (!h) return -100;
+  std::string t;
+  const int rc = h->rollout_plugin_status(&t);
+  if (text && text_bytes > 0) { snprintf(text, (size_t)text_bytes, "%s", t.c_str()); }
+  return rc;
+}
 int kmpc_set_rollout_workgroup(int trajectories) {
   if (trajectories != 0 && trajectories != 4 && trajectories != 8 && trajectories != 16) return -1;
   kmpc::set_rollout_workgroup(trajectories);

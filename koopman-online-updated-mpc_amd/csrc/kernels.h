@@ -6,6 +6,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <string>
+
 namespace kmpc {
 
 // Measurement / test switches of the library.  They are read from the environment ONLY when KMPC_DEBUG is set (tests/conftest.py and
@@ -182,6 +184,16 @@ template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, 
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf);
 template <typename T> hipError_t launch_rollout_fused(const RolloutArgs<T>& a, hipStream_t s);
 void set_rollout_workgroup(int trajectories);  // 0 = automatic, else 4 / 8 / 16 (process-wide)
+// ---- roll-out plug-ins (rollout_plugin.hip, rollout_jit.hip): the fused roll-out of a dimension set without a built-in instantiation
+struct RolloutPluginKey { int L, N, q, nw, ks, io32; };  // nw: trajectories per workgroup; ks: -1 RBF lift, 25 / 0 MLP lift (compile-time / run-time width)
+typedef hipError_t (*rollout_plugin_fn)(const RolloutArgs<double>* a, int waves, hipStream_t s);
+bool rollout_plugin_dims(int n, int L, int N, int q);  // a plug-in can be generated for this set
+// the loaded plug-in (process table -> kernel cache on disk -> hipcc), or null with *err saying why
+rollout_plugin_fn rollout_plugin_get(const RolloutPluginKey& k, std::string* err, bool build_if_missing = true);
+std::string rollout_plugin_describe(const RolloutPluginKey& k);
+bool rollout_builtin(int L, int N, int q, bool io32);  // libkoopmpc.so itself holds the instantiations of this set
+// the plug-in a launch of this configuration needs; false: none (built-in set, or the set does not fit the fused kernel at all)
+bool rollout_plugin_key(int n, int L, int N, int q, bool rbf, int Lp, int KS, int Hp, int B, bool io32, RolloutPluginKey* out);
 // wave image of one trajectory's state (step_v2.h): [column pair][slot][2] doubles, layer 2 then layer 1
 struct V2Dims {
   int L, n, p, cp, s2, s1;

@@ -655,30 +655,62 @@ hipError_t launch_rollout_io32(const RolloutArgs<double>&, hipStream_t) { return
 #else
 hipError_t launch_rollout_io32(const RolloutArgs<double>& a, hipStream_t s);
 #endif
+// the dimension sets whose instantiations libkoopmpc.so holds itself (BASELINE.json's configurations, the reference's scripts); every
+// other set of rollout_plugin_dims gets its kernel as a plug-in when a handle is created (rollout_plugin.hip)
+bool rollout_builtin(int L, int N, int q, bool io32) {
+#ifdef KMPC_DEV_CFG2_ONLY
+  if (io32) return L == 20 && N == 20 && q == 2;
+  return (L == 20 && N == 20 && q == 2) || (L == 8 && N == 30 && q == 2);
+#endif
+  if (io32)
+    return (L == 20 && N == 20 && q == 2) || (L == 8 && N == 30 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 10 && N == 20 && q == 1) ||
+           (L == 20 && N == 30 && q == 2);
+  return (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
+         (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2) || (L == 10 && N == 20 && q == 1) ||
+         (L == 20 && N == 30 && q == 2) || (L == 32 && N == 40 && q == 2) || (L == 32 && N == 40 && q == 1);
+}
 // true: a KMPC_F32 handle of this dimension set has the fused roll-out with float32 panels around the float64 state
 bool rollout_io32_available(int n, int L, int N, int q, bool rbf) {
 #ifdef KMPC_TRACE
   return false;
 #endif
-#ifdef KMPC_DEV_CFG2_ONLY
-  if (!(L == 20 && N == 20 && q == 2)) return false;
-#endif
   return n == 2 && step_v2_dims(L, N, q) && rollout_fused_available<double>(n, L, N, q, 64, rbf);
 }
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf) {
   if (sizeof(T) != 8 || threads == 256 || n > 4) return false;
-  const bool inst = (L == 20 && N == 20 && q == 2) || (L == 8 && N == 10 && q == 2) || (L == 8 && N == 10 && q == 8) ||
-                    (L == 8 && N == 30 && q == 8) || (L == 8 && N == 30 && q == 2) || (L == 10 && N == 20 && q == 1) ||
-                    (L == 20 && N == 30 && q == 2) || (L == 32 && N == 40 && q == 2) || (L == 32 && N == 40 && q == 1);
+  const bool inst = rollout_builtin(L, N, q, false) || rollout_plugin_dims(n, L, N, q);
   return inst && rollout_waves(n, L, q, N, rbf, 64) > 0;  // (Lp <= 64)
+}
+bool rollout_plugin_key(int n, int L, int N, int q, bool rbf, int Lp, int KS, int Hp, int B, bool io32, RolloutPluginKey* out) {
+  if (rollout_builtin(L, N, q, io32) || !rollout_plugin_dims(n, L, N, q)) return false;
+  if (io32 && !step_v2_dims(L, N, q)) return false;
+  int waves = rollout_waves(n, L, q, N, rbf, Lp, B);
+  if (io32 && !rbf && waves == 4) waves = 8;  // (float32 panels: launch_rollout_impl)
+  if (waves == 0) return false;
+  out->L = L; out->N = N; out->q = q; out->io32 = io32 ? 1 : 0;
+  out->ks = rbf ? -1 : ((KS == 25 && Hp == 112) ? 25 : 0);
+  out->nw = rbf ? 16 : waves;  // (the RBF kernel never uses the template's tiling: one object serves every workgroup size)
+  return true;
+}
+static hipError_t launch_rollout_plugin(const RolloutArgs<double>& a, hipStream_t s) {
+  RolloutPluginKey k{};
+  const bool rbf = a.lift_rbf != 0;
+  if (!rollout_plugin_key(a.s.n, a.s.L, a.s.N, a.s.q, rbf, a.Lp, a.KS, a.Hp, a.s.B, a.io_f32 != 0, &k)) return hipErrorInvalidValue;
+  // (a handle loads its plug-in when it is created; a launch only compiles when the workgroup size was changed afterwards)
+  const rollout_plugin_fn fn = rollout_plugin_get(k, nullptr);
+  if (!fn) return hipErrorInvalidValue;
+  int waves = rollout_waves(a.s.n, a.s.L, a.s.q, a.s.N, rbf, a.Lp, a.s.B);
+  if (a.io_f32 && !rbf && waves == 4) waves = 8;
+  return fn(&a, waves, s);
 }
 // true: the fused roll-out of this dimension set works on the wave image of the state (step_v2.h) instead of the dense blocks
 bool rollout_uses_image(int n, int L, int N, int q) { return n == 2 && step_v2_dims(L, N, q); }
 template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a, hipStream_t s) {
   if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
-  if (a.io_f32) return launch_rollout_io32(a, s);
   if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
     return hipErrorInvalidValue;
+  if (!rollout_builtin(a.s.L, a.s.N, a.s.q, a.io_f32 != 0)) return launch_rollout_plugin(a, s);
+  if (a.io_f32) return launch_rollout_io32(a, s);
   if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);  // BASELINE cfg3 (RBF lift, y = Cx)
 #if !defined(KMPC_DEV_CFG2_ONLY) || defined(KMPC_DEV_LIFT)  // (development builds compile the cfg2 / cfg3 instantiations only)

@@ -50,6 +50,8 @@ SIGNATURES = {
     "kmpc_solve_dare": (_I, [_VP, _VP, _DP, _D, _I, _D, _I, _I, _VP, _VP, _VP, _VP]),
     "kmpc_terminal_from_dare": (_I, [_VP, _DP, _D, _I, _D, _I, _DP, C.POINTER(C.c_int32), _VP]),
     "kmpc_rollout_is_fused": (_I, [_VP]),
+    "kmpc_rollout_plugin_status": (_I, [_VP, C.c_char_p, _I]),
+    "kmpc_rollout_plugin_prebuild": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.c_char_p, _I]),
     "kmpc_set_rollout_workgroup": (_I, [_I]),
     "kmpc_reset": (_I, [_VP, _VP]),
     "kmpc_state_init": (_I, [_VP, _D, _D, _VP]),

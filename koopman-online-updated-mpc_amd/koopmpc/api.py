@@ -537,6 +537,14 @@ class KoopmanMPC:
         """True if rollout() runs as one fused kernel launch for this configuration."""
         return bool(self.lib.kmpc_rollout_is_fused(self.h))
 
+    def rollout_plugin_status(self):
+        """(code, text): where the fused roll-out kernel of this controller comes from -- 0 the library's own instantiation, 1 a
+        plug-in made for this dimension set when the controller was created (text: its file, found in the kernel cache or compiled
+        with hipcc in so many seconds), -1 the plug-in could not be made (text: why; per-step launches), 2 no fused roll-out."""
+        buf = C.create_string_buffer(1024)
+        code = int(self.lib.kmpc_rollout_plugin_status(self.h, buf, len(buf)))
+        return code, buf.value.decode("utf-8", "replace")
+
     def algorithmic_bytes_per_step(self):
         return int(self.lib.kmpc_algorithmic_bytes_per_step(self.h))
 

@@ -366,3 +366,161 @@ def test_handle_waits_for_every_stream_it_was_used_on(torch_mod, KM):
     for two in (False, True):
         early, late = run(two)
         assert np.array_equal(early, late), "checkpoint taken before the roll-out on the other stream had finished (two_streams=%s)" % two
+
+
+# ------------------------------------------------------------------ the fused roll-out for ANY dimension set (roll-out plug-ins)
+_PLUGIN_SETS = [
+    # L,  N, output, out_rows, lift, layers, B,   steps, bound   (none of them has an instantiation inside libkoopmpc.so)
+    (12, 16, "Cx", 0, "mlp", 3, 40, 12, 2.0),      # register-state step, two output rows
+    (16, 24, "Cx", 1, "mlp", 2, 33, 10, 2.0),      # ... one output row (out_rows = 1), two hidden layers
+    (28, 32, "Cx", 0, "mlp", 3, 20, 8, 2.0),       # ... its largest horizon, L + 2 = 30 state rows in the lanes
+    (6, 12, "Cx", 0, "rbf", 0, 50, 12, 2.0),       # RBF lift: every wave lifts its own state
+    (14, 20, "Cx", 0, "rbf", 0, 300, 8, 2.0),
+    (12, 12, "lift", 0, "mlp", 3, 24, 10, 6.0),    # y = psi (vanderpol.py:456-459): the 8 x 8-grid step of step_body.h
+    (36, 24, "Cx", 0, "mlp", 3, 10, 6, 2.0),       # y = C x beyond the register-state form (L + 2 > 32): the LDS step
+]
+
+
+@pytest.mark.parametrize("L,N,output,out_rows,lift,layers,B,steps,bnd", _PLUGIN_SETS)
+def test_fused_rollout_of_dimension_sets_without_a_builtin_instantiation(torch_mod, KM, L, N, output, out_rows, lift, layers, B, steps, bnd):
+    """the fused roll-out is a property of the library, not of nine (L, N, q) triples.  The reference's dimensions
+    are constants edited in its scripts (duffing.py:66, 632-633); a controller of a set libkoopmpc.so has no instantiation for gets
+    its kernel as a plug-in when it is created (kernel cache, else hipcc on csrc/rollout_jit.hip).  Every set: kmpc_rollout is ONE
+    launch (rollout_is_fused, status code 1 = plug-in), closed loop across the plant switch against per-trajectory oracle controllers
+    (gain-form RLS, exact QP; duffing.py:847-984): inputs within 1e-6, states within 1e-9."""
+    torch = torch_mod
+    from koopmpc.synth import duffing_rk4, initial_states, offline_edmd, random_mlp_weights
+
+    rng = np.random.RandomState(L * N)
+    kw = dict(output=output, lb=-bnd, ub=bnd)
+    if out_rows:
+        kw.update(out_rows=out_rows, out_row0=0)
+    if lift == "mlp":
+        w = random_mlp_weights(2, 100, layers, L, seed=5)
+        mpc = KM(n=2, L=L, N=N, batch=B, weights=w, layers=layers, **kw)
+        lift_fn = lambda x: ko.mlp_lift(w, x)
+    else:
+        cx = 4 * rng.rand(L, 2) - 2
+        mpc = KM(n=2, L=L, N=N, batch=B, lift="rbf", centres=cx, **kw)
+        lift_fn = lambda x: ko.rbf_lift(x, cx)
+    code, text = mpc.rollout_plugin_status()
+    print("(%d, %d, %s): %s" % (L, N, output, text))
+    assert code == 1 and mpc.rollout_is_fused(), (code, text)
+    A0, B0, C0 = offline_edmd(lambda X: mpc.Encoder(X), plant=duffing_rk4)
+    mpc.set_model(A0, B0, C0)
+    q = L if output == "lift" else (out_rows or 2)
+    if output == "lift":
+        r = np.tile(lift_fn(np.array([[1.0], [0.0]])), (1, N))   # vanderpol.py:668-675
+    else:
+        r = np.tile(np.array([[1.0], [0.0]])[:q], (1, N))
+    X0 = initial_states(B, seed=3)
+    Xd = _t(torch, X0)
+    step0, sw = 99, 102
+    Ul, Xl = mpc.rollout("duffing", Xd, r, steps, step0=step0, switch_step=sw, log=True)
+    st = mpc.status.cpu().numpy()
+    assert (st <= (1 if output == "lift" else 0)).all()
+    Ul, Xl = Ul.cpu().numpy(), Xl.cpu().numpy()
+    worst_u = worst_x = 0.0
+    for b in range(min(B, 24)):
+        if st[b] != 0:
+            continue
+        ctl = ko.OracleController(lift_fn, L, 2, N, -bnd, bnd, A0, B0, C0, output=output, rls="gain")
+        x = X0[:, b].copy()
+        for k in range(steps):
+            psi = lift_fn(x.reshape(2, 1)).reshape(-1)
+            if ctl.prev is not None:
+                ppsi, pu = ctl.prev
+                ctl.gK, ctl.gP = ko.rls_update_gain(ctl.gK, ctl.gP, np.concatenate([ppsi, [pu]]), psi)
+                ctl.gC, ctl.gQ = ko.rls_update_gain(ctl.gC, ctl.gQ, ppsi, x)
+                ctl.A, ctl.B, ctl.C = ctl.gK[:, :-1].copy(), ctl.gK[:, -1:].copy(), ctl.gC.copy()
+            Co = None if output == "lift" else ctl.C[:q]
+            _, _, H, f, _ = ko.condense(ctl.A, ctl.B, Co, psi, r, N, ctl.Qw, ctl.Rw)
+            U, _ = ko.qp_exact(H, f, -bnd, bnd)
+            worst_u = max(worst_u, abs(Ul[k, b] - U[0]))
+            ctl.prev = (psi, float(Ul[k, b]))  # (both sides regress on the applied input and continue from the device's state)
+            xo = ko.plant_step("duffing", x, float(Ul[k, b]), switched=(step0 + k >= sw))
+            worst_x = max(worst_x, float(np.abs(Xl[k, :, b] - xo).max()))
+            x = Xl[k, :, b].copy()
+    print("   plug-in roll-out (%d, %d, q = %d, %s) vs oracle: max |u - u_oracle| %.2e, |x - x_oracle| %.2e" % (L, N, q, lift, worst_u, worst_x))
+    assert worst_u < 1e-6 and worst_x < 1e-9
+
+
+def test_matlab_twin_dimension_set_runs_fused(torch_mod, KM):
+    """The reference's own MATLAB controller runs L = 10, N = 10, liftFun = [x; Encoder(x)] - [0; Encoder(0)] (Koopman_update.m:67, 70,
+    113) -- not one of the built-in triples; round 5 served it with per-step launches.  KoopmanMPC(L=10, N=10, lift_offset="x_psi0") now
+    reports a fused roll-out (plug-in; __graft_entry__.build() pre-builds it into the tree's kernel cache), 30 closed-loop steps as ONE
+    launch with the reference encoder's weights match per-trajectory oracle controllers that lift the same way (u 1e-6), and the
+    per-step route (kmpc_step = one-step launches of the same kernel) gives the same loop."""
+    torch = torch_mod
+    w = ko.load_mlp_weights(np.load(os.path.join(G, "weights_duffing.npz")))
+    L, N, B, steps = 10, 10, 64, 30
+    rng = np.random.RandomState(11)
+    A = rng.randn(L, L) * 0.2 / np.sqrt(L)
+    Bm, Cm = rng.randn(L, 1) * 0.3, rng.randn(2, L) * 0.3
+    m = KM(n=2, L=L, N=N, batch=B, weights=w, lift_offset="x_psi0")
+    code, text = m.rollout_plugin_status()
+    print(text)
+    assert code == 1 and m.rollout_is_fused()
+    m.set_model(A, Bm, Cm)
+    m2 = KM(n=2, L=L, N=N, batch=B, weights=w, lift_offset="x_psi0")
+    m2.set_model(A, Bm, Cm)
+    lift = lambda x: ko.mlp_lift_offset(w, x, "x_psi0")
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X0 = 4 * rng.rand(2, B) - 2
+    X = _t(torch, X0)
+    Ul, Xl = m.rollout("duffing", X, r, steps, step0=90, switch_step=102, log=True)
+    assert int(m.status.max().item()) == 0
+    X2 = _t(torch, X0)
+    for k in range(steps):
+        u = m2.step(X2, r).clone()
+        assert float((u - Ul[k]).abs().max()) < 1e-9, k
+        X2 = m2.plant_step("duffing", X2, u, switched=(90 + k >= 102))
+    Ul, Xl = Ul.cpu().numpy(), Xl.cpu().numpy()
+    worst = 0.0
+    for b in range(16):
+        ctl = ko.OracleController(lift, L, 2, N, -2.0, 2.0, A, Bm, Cm, rls="gain")
+        x = X0[:, b].copy()
+        for k in range(steps):
+            uo, _, _ = ctl.step(x, r)
+            worst = max(worst, abs(Ul[k, b] - uo))
+            ctl.prev = (ctl.prev[0], float(Ul[k, b]))
+            x = Xl[k, :, b].copy()
+    print("MATLAB-twin set (10, 10, 2), [x; psi(x)] - [0; psi(0)] lift, 30 fused steps vs oracle: max |u - u_oracle| %.2e" % worst)
+    assert worst < 1e-6
+
+
+def test_plugin_is_compiled_on_the_box_when_the_cache_is_empty_and_f32_panels_get_theirs(torch_mod, KM, tmp_path, monkeypatch):
+    """The hipcc route itself, on the GPU box: with an empty kernel cache ($KMPC_KERNEL_CACHE -> a fresh directory; the dimension set is
+    one no other test uses, so the process table does not hold it either) kmpc_create compiles csrc/rollout_jit.hip, reports the
+    seconds it took, and the launch works; a KMPC_F32 controller of the set gets the float32-panel variant and equals the float64
+    launch rounded once (row g2's statement, for a plug-in set)."""
+    torch = torch_mod
+    from koopmpc.synth import initial_states, random_mlp_weights
+
+    monkeypatch.setenv("KMPC_KERNEL_CACHE", str(tmp_path))
+    L, N, B = 18, 14, 48
+    w = random_mlp_weights(2, 100, 3, L, seed=12)
+    rng = np.random.RandomState(3)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    A, Bm, Cm = f32(rng.randn(L, L) * 0.2 / np.sqrt(L)), f32(rng.randn(L, 1) * 0.3), f32(rng.randn(2, L) * 0.3)
+    m64 = KM(n=2, L=L, N=N, batch=B, weights=w)
+    code, text = m64.rollout_plugin_status()
+    print(text)
+    assert code == 1 and "compiled with hipcc" in text and str(tmp_path) in text, text
+    m32 = KM(n=2, L=L, N=N, batch=B, weights=w, dtype=torch.float32)
+    code32, text32 = m32.rollout_plugin_status()
+    print(text32)
+    assert code32 == 1 and "_f32_" in text32 and m32.rollout_is_fused()
+    for m in (m64, m32):
+        m.set_model(A, Bm, Cm)
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X0 = f32(initial_states(B, seed=4))
+    X64 = torch.tensor(X0, dtype=torch.float64, device="cuda:0").contiguous()
+    X32 = torch.tensor(X0, dtype=torch.float32, device="cuda:0").contiguous()
+    U64, _ = m64.rollout("duffing", X64, r, 12, log=True)
+    U32, _ = m32.rollout("duffing", X32, r, 12, log=True)
+    assert int(m64.status.max().item()) == 0 and int(m32.status.max().item()) == 0
+    assert torch.equal(U32, U64.float()) and torch.equal(X32, X64.float())
+    # a second controller of the set finds the plug-in in the process table: no second compile
+    m64b = KM(n=2, L=L, N=N, batch=B, weights=w)
+    assert m64b.rollout_plugin_status() == (code, text)

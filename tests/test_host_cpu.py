@@ -336,3 +336,52 @@ def test_bench_flop_and_byte_counts():
         c = bench.CONFIGS[name]
         ex, al = bench.executed_flops(name, c["L"], c["N"], q, 1.1), bench.algorithmic_flops(name, c["L"], c["N"], q, 1.1)
         assert 0 < ex < al
+
+
+# ------------------------------------------------------------------ roll-out plug-ins (no device needed: hipcc cross-compiles)
+def test_rollout_plugin_is_built_cached_and_self_contained(lib, tmp_path, monkeypatch):
+    """csrc/rollout_plugin.hip without a GPU: kmpc_rollout_plugin_prebuild for a dimension set libkoopmpc.so has no instantiation
+    for (7, 9, 2) compiles csrc/rollout_jit.hip with hipcc into $KMPC_KERNEL_CACHE (code 1, the text names the file and the seconds);
+    the object exports the three plug-in entry points and needs no symbol of libkoopmpc.so (it is loaded with RTLD_LOCAL into
+    processes that may hold another build of the library); a built-in set answers 0 and compiles nothing; a set the fused kernel
+    cannot take (four waves per trajectory: L = 64) answers 2; bad arguments -3."""
+    from koopmpc import _ffi
+
+    monkeypatch.setenv("KMPC_KERNEL_CACHE", str(tmp_path))
+    buf = ctypes.create_string_buffer(1024)
+
+    def pre(n, L, N, rows, lift, hidden, B, dtype):
+        rc = lib.kmpc_rollout_plugin_prebuild(n, L, N, rows, lift, hidden, B, dtype, buf, len(buf))
+        return rc, buf.value.decode()
+
+    rc, text = pre(2, 7, 9, 0, _ffi.KMPC_LIFT_RBF_PY, 0, 100, _ffi.KMPC_F64)
+    assert rc == 1 and "compiled with hipcc" in text and str(tmp_path) in text, (rc, text)
+    objs = [f for f in os.listdir(tmp_path) if f.endswith(".so")]
+    assert len(objs) == 1 and objs[0].startswith("rollout_L7_N9_q2_nw16_ksm1_f64_"), objs
+    assert not [f for f in os.listdir(tmp_path) if ".tmp." in f or ".log." in f]
+    path = os.path.join(str(tmp_path), objs[0])
+    dyn = subprocess.run(["nm", "-D", "--defined-only", path], capture_output=True, text=True).stdout
+    for sym in ("kmpc_rollout_plugin_abi", "kmpc_rollout_plugin_args_bytes", "kmpc_rollout_plugin_launch"):
+        assert sym in dyn
+    und = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True).stdout
+    assert "kmpc" not in und, und
+    # the same request again: the process table, no second object
+    rc2, text2 = pre(2, 7, 9, 0, _ffi.KMPC_LIFT_RBF_PY, 0, 100, _ffi.KMPC_F64)
+    assert (rc2, text2) == (rc, text)
+    assert pre(2, 20, 20, 0, _ffi.KMPC_LIFT_MLP, 100, 4096, _ffi.KMPC_F64)[0] == 0      # BASELINE cfg2: inside the library
+    assert pre(2, 64, 50, 0, _ffi.KMPC_LIFT_MLP, 100, 64, _ffi.KMPC_F64)[0] == 2        # cfg5: four waves per trajectory, per-step kernels
+    assert pre(2, 7, 9, 0, _ffi.KMPC_LIFT_MLP, 0, 100, _ffi.KMPC_F64)[0] == -3
+    assert len([f for f in os.listdir(tmp_path) if f.endswith(".so")]) == 1
+
+
+def test_rollout_plugin_failure_is_reported_not_fatal(lib, tmp_path, monkeypatch):
+    """No compiler: the plug-in cannot be made; the entry point says so (code -1, the compiler's name in the text) -- a handle of such
+    a set then works with per-step launches (kmpc_rollout_is_fused = 0; kmpc_rollout_plugin_status carries the same text)."""
+    from koopmpc import _ffi
+
+    monkeypatch.setenv("KMPC_KERNEL_CACHE", str(tmp_path))
+    monkeypatch.setenv("KMPC_HIPCC", "/nonexistent/hipcc")
+    buf = ctypes.create_string_buffer(1024)
+    rc = lib.kmpc_rollout_plugin_prebuild(2, 9, 7, 0, _ffi.KMPC_LIFT_RBF_PY, 0, 10, _ffi.KMPC_F64, buf, len(buf))
+    assert rc == -1 and "/nonexistent/hipcc" in buf.value.decode(), (rc, buf.value)
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".so")]
