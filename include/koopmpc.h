@@ -295,6 +295,16 @@ int kmpc_solve_dare(const void* A, const void* B, const double* Q, double R, int
 int kmpc_terminal_from_dare(kmpc_handle* h, const double* Q, double R, int maxiter, double eps,
                             int per_trajectory, double* PN_out, int32_t* iters_out, void* stream);
 
+/* The MATLAB controller recomputes its terminal ingredients with the UPDATED model at every iteration (Koopman_update.m:215
+ * K = -dlqr(A, B, ...), :381 Q_bar(end-n+1:end, ...) = C*P*C').  every > 0: kmpc_step / kmpc_rollout run the reference's Riccati iteration
+ * (solve_DARE, duffing.py:583-598; Q (L x L, host, row-major), R, maxiter, eps as there) on every trajectory's freshly updated [A B] at
+ * each `every`-th step -- after the RLS update, before the condensed QP is formed -- and rebuild its block Co P Co'.  For the fused
+ * roll-out this happens INSIDE the launch (a plug-in variant of the kernel, made by this call: kmpc_rollout_plugin_status); on the
+ * per-step route as RLS launch, Riccati kernel, QP launch.  Until a trajectory's first refresh its block is the handle's current one
+ * (kmpc_set_terminal_weight / kmpc_terminal_from_dare), else Qw I.  every = 0: off, the blocks stay what the last refresh left.
+ * float64 handles, per-trajectory models (not the shared-model mode).                                                            */
+int kmpc_set_terminal_refresh(kmpc_handle* h, int every, const double* Q_host, double R, int maxiter, double eps);
+
 /* ---- state hand-over / checkpoint ------------------------------------------------------ */
 /* bytes of the persistent state blob (P, K, bar_Q, C, psi_prev, u_prev, flags)              */
 int64_t kmpc_state_bytes(const kmpc_handle* h);

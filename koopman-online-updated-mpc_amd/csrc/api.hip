@@ -29,6 +29,7 @@ struct kmpc_handle {
   virtual int set_terminal_weight(const double* PN) = 0;
   virtual int terminal_from_dare(const double* Qh, double R, int maxiter, double eps, int per_traj, double* PN_out,
                                  int32_t* iters_out, hipStream_t s) = 0;
+  virtual int set_terminal_refresh(int every, const double* Qh, double R, int maxiter, double eps) = 0;
   virtual int rollout_is_fused() const = 0;
   virtual int rollout_plugin_status(std::string* text) const = 0;
   virtual int reset(hipStream_t s) = 0;
@@ -316,7 +317,7 @@ struct Impl : kmpc_handle {
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
                       (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
-                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet, (void*)dDelta, (void*)dQpList, (void*)dWork, (void*)dPerm})
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet, (void*)dDelta, (void*)dQpList, (void*)dWork, (void*)dPerm, (void*)dTermQ, (void*)dTermScr, (void*)dEyeL})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (evPlace) (void)hipEventDestroy(evPlace);
@@ -568,36 +569,8 @@ struct Impl : kmpc_handle {
       HIPCHK(hipMalloc(&tQl.p, sizeof(double) * (size_t)L * L));
       double* const dQl = tQl.as<double>();
       HIPCHK(hipMemcpyAsync(dQl, Qh, sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice, s));
-      if (dare_cap < nb) {
-        if (dDareP) (void)hipFree(dDareP);
-        if (dDareIt) (void)hipFree(dDareIt);
-        if (dWtB) (void)hipFree(dWtB);
-        dDareP = nullptr; dDareIt = nullptr; dWtB = nullptr;
-        HIPCHK(hipMalloc(&dDareP, sizeof(double) * (size_t)nb * L * L));
-        HIPCHK(hipMalloc(&dDareIt, sizeof(int32_t) * (size_t)nb));
-        HIPCHK(hipMalloc(&dWtB, sizeof(double) * (size_t)nb * q * q));
-        dare_cap = nb;
-      }
-      // y = psi (lifted output): Co = I, the block is P itself; y = C x: rows cy0 .. cy0+q-1 of C
-      const bool lift_out = cfg.output_kind == KMPC_OUT_LIFT;
-      double* dEye = nullptr;
-      if (lift_out) {
-        std::vector<double> eye((size_t)L * L, 0.0);
-        for (int i = 0; i < L; ++i) eye[(size_t)i * L + i] = 1.0;
-        HIPCHK(hipMalloc(&tEye.p, sizeof(double) * (size_t)L * L));
-        dEye = tEye.as<double>();
-        HIPCHK(hipMemcpyAsync(dEye, eye.data(), sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice, s));
-        HIPCHK(hipStreamSynchronize(s));  // (the host vector goes out of scope)
-      }
-      DareArgs d{};
-      d.nb = nb; d.L = L; d.q = q; d.maxiter = maxiter; d.shared_model = 0;
-      d.A = (const double*)dK; d.strideA = sK; d.ldA = p;
-      d.B = (const double*)dK + L; d.strideB = sK; d.incB = p;
-      d.Q = dQl; d.R = R; d.eps = eps;
-      d.Co = lift_out ? dEye : (const double*)dC + (size_t)cfg.out_row0 * L;
-      d.strideC = lift_out ? 0 : sC;
-      d.P = dDareP; d.K = nullptr; d.PN = dWtB; d.pn_sub_diag = cfg.Qw; d.iters = dDareIt;
-      HIPCHK(launch_dare(d, s));
+      { int rc = dare_buffers(nb); if (rc) return rc; }
+      { int rc = dare_blocks(nb, dQl, R, maxiter, eps, s); if (rc) return rc; }
       if (PN_out || iters_out) {
         HIPCHK(hipStreamSynchronize(s));
         if (PN_out) {
@@ -611,6 +584,93 @@ struct Impl : kmpc_handle {
       wterm_per_traj = per_traj != 0;
       wterm_from_dare = true;
       have_wterm = true;
+      return 0;
+    }
+  }
+
+  // Riccati workspace and the terminal block(s) for nb models (kmpc_terminal_from_dare, kmpc_set_terminal_refresh)
+  int dare_buffers(int nb) {
+    if (dare_cap >= nb) return 0;
+    double* nP = nullptr; int32_t* nIt = nullptr; double* nW = nullptr;
+    HIPCHK(hipMalloc(&nP, sizeof(double) * (size_t)nb * L * L));
+    HIPCHK(hipMalloc(&nIt, sizeof(int32_t) * (size_t)nb));
+    HIPCHK(hipMalloc(&nW, sizeof(double) * (size_t)nb * q * q));
+    if (dDareP) (void)hipFree(dDareP);
+    if (dDareIt) (void)hipFree(dDareIt);
+    if (dWtB) (void)hipFree(dWtB);
+    dDareP = nP; dDareIt = nIt; dWtB = nW;
+    dare_cap = nb;
+    return 0;
+  }
+  double* dEyeL = nullptr;  // L x L identity: the output map of y = psi
+  // P = DARE(A, B, Qdev, R) of the first nb trajectories' current [A B] and their blocks Co P Co' - Qw I -> dWtB   (dare_kernel)
+  int dare_blocks(int nb, const double* Qdev, double R, int maxiter, double eps, hipStream_t s) {
+    if constexpr (sizeof(T) == 8) {
+      // y = psi (lifted output): Co = I, the block is P itself; y = C x: rows cy0 .. cy0+q-1 of C
+      const bool lift_out = cfg.output_kind == KMPC_OUT_LIFT;
+      if (lift_out && !dEyeL) {
+        std::vector<double> eye((size_t)L * L, 0.0);
+        for (int i = 0; i < L; ++i) eye[(size_t)i * L + i] = 1.0;
+        HIPCHK(hipMalloc(&dEyeL, sizeof(double) * (size_t)L * L));
+        HIPCHK(hipMemcpy(dEyeL, eye.data(), sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice));
+      }
+      DareArgs d{};
+      d.nb = nb; d.L = L; d.q = q; d.maxiter = maxiter; d.shared_model = 0;
+      d.A = (const double*)dK; d.strideA = sK; d.ldA = p;
+      d.B = (const double*)dK + L; d.strideB = sK; d.incB = p;
+      d.Q = Qdev; d.R = R; d.eps = eps;
+      d.Co = lift_out ? dEyeL : (const double*)dC + (size_t)cfg.out_row0 * L;
+      d.strideC = lift_out ? 0 : sC;
+      d.P = dDareP; d.K = nullptr; d.PN = dWtB; d.pn_sub_diag = cfg.Qw; d.iters = dDareIt;
+      HIPCHK(launch_dare(d, s));
+    }
+    return 0;
+  }
+
+  // kmpc_set_terminal_refresh: the MATLAB controller recomputes its terminal ingredients with the updated model at EVERY iteration
+  // (Koopman_update.m:215 dlqr, :381 Q_bar(end) = C P C').  every > 0: kmpc_step / kmpc_rollout run the reference's Riccati iteration
+  // (duffing.py:583-598) on every trajectory's freshly updated [A B] each `every`-th step and rebuild its block Co P Co' before the
+  // condensed QP is formed -- INSIDE the launch for the fused roll-out (rollout_kernel<.., TERM>, a plug-in made here), as RLS launch /
+  // dare_kernel / QP launch on the per-step route.  0: off (the blocks stay what the last refresh left).
+  int term_every = 0, term_maxiter = 500, term_plugin_state = 0;
+  long term_count = 0;
+  double term_R = 0.01, term_eps = 0.01;
+  double *dTermQ = nullptr, *dTermScr = nullptr;
+  RolloutPluginKey term_key{};
+  std::string term_msg;
+  int set_terminal_refresh(int every, const double* Qh, double R, int maxiter, double eps) override {
+    if constexpr (sizeof(T) != 8) {
+      FAIL(-2, "kmpc_set_terminal_refresh: float64 handles only (the reference's Riccati iteration is float64)");
+    } else {
+      if (every < 0 || (every > 0 && (!Qh || maxiter < 1))) FAIL(-3, "kmpc_set_terminal_refresh: bad arguments");
+      if (every == 0) { term_every = 0; return 0; }
+      { int rc = sync_own(); if (rc) return rc; }
+      const bool had = have_wterm, had_per_traj = have_wterm && wterm_from_dare && wterm_per_traj;
+      const int old_cap = dare_cap;
+      std::vector<double> w0((size_t)q * q, 0.0);  // the block every trajectory holds until its first refresh: the current one, else Qw I
+      if (had && !had_per_traj) {
+        if (wterm_from_dare) HIPCHK(hipMemcpy(w0.data(), dWtB, sizeof(double) * w0.size(), hipMemcpyDeviceToHost));
+        else HIPCHK(hipMemcpy(w0.data(), dWt, sizeof(double) * w0.size(), hipMemcpyDeviceToHost));
+      }
+      if (!(had_per_traj && old_cap >= B)) {
+        { int rc = dare_buffers(B); if (rc) return rc; }
+        std::vector<double> wb((size_t)B * q * q);
+        for (int b = 0; b < B; ++b) std::copy(w0.begin(), w0.end(), wb.begin() + (size_t)b * q * q);
+        HIPCHK(hipMemcpy(dWtB, wb.data(), sizeof(double) * wb.size(), hipMemcpyHostToDevice));
+      }
+      if (!dTermQ) HIPCHK(hipMalloc(&dTermQ, sizeof(double) * (size_t)L * L));
+      HIPCHK(hipMemcpy(dTermQ, Qh, sizeof(double) * (size_t)L * L, hipMemcpyHostToDevice));
+      have_wterm = true; wterm_from_dare = true; wterm_per_traj = true;
+      term_R = R; term_maxiter = maxiter; term_eps = eps; term_count = 0;
+      // the fused roll-out of this configuration with the refresh inside: a plug-in of its own (also for the built-in dimension sets)
+      term_plugin_state = 0;
+      const bool rbf = cfg.lift_kind != KMPC_LIFT_MLP;
+      if (threads == 64 && n == 2 && plugin_state >= 0 && rollout_fused_available<double>(n, L, N, q, threads, rbf) &&
+          rollout_plugin_key(n, L, N, q, rbf, Lp, (hid + 3) / 4, Hp, B, false, &term_key, true)) {
+        term_plugin_state = rollout_plugin_get(term_key, &term_msg) ? 1 : -1;
+        if (term_plugin_state > 0 && !dTermScr) HIPCHK(hipMalloc(&dTermScr, sizeof(double) * (size_t)B * term_scratch_elems(L)));
+      }
+      term_every = every;
       return 0;
     }
   }
@@ -898,6 +958,20 @@ struct Impl : kmpc_handle {
     a.qp_carry = dQpCarry; a.qp_carry_set = dQpCarrySet;
     a.accumulate = accumulate ? 1 : 0;
     if (fuse_plant >= 0) { a.plant = fuse_plant; a.plant_switched = fuse_switched; a.plant_h = (T)fuse_h; a.X_rw = (T*)const_cast<void*>(X); }
+    if (term_every > 0) {
+      // per-step terminal refresh on the per-step route: the RLS update as a launch of its own, the Riccati iteration on the updated
+      // models (dare_kernel, every term_every-th step), then condensed QP and solve with the refreshed blocks
+      const int ph = a.phases;
+      if (ph & PH_RLS) {
+        StepArgs<T> a1 = a;
+        a1.phases = PH_RLS; a1.plant = -1; a1.U0 = nullptr; a1.Useq = nullptr; a1.u_store = nullptr; a1.status = nullptr; a1.iters = nullptr;
+        HIPCHK(launch_step<T>(a1, threads, s));
+      }
+      if (term_count % term_every == 0) { const int rc2 = dare_blocks(B, dTermQ, term_R, term_maxiter, term_eps, s); if (rc2) return rc2; }
+      a.phases = ph & ~PH_RLS;
+      a.Wterm = (T*)dWtB; a.wterm_per_traj = 1;
+      term_count += 1;
+    }
     HIPCHK(launch_step<T>(a, threads, s));
     if (rec) {
       HIPCHK(hipEventRecord(e2, s));
@@ -953,11 +1027,14 @@ struct Impl : kmpc_handle {
   bool fused_rollout_ok() const {
     static const bool off = dbg_env("KMPC_NO_FUSED_ROLLOUT") != nullptr;  // measurement aid: per-step launches
     if (core) return !off && core->fused_rollout_ok();  // (float32 panels around the float64 roll-out)
+    if (term_every > 0 && term_plugin_state <= 0) return false;  // (the refresh needs the TERM plug-in; else the per-step route)
     return !off && n == 2 && plugin_state >= 0 && rollout_fused_available<T>(n, L, N, q, threads, cfg.lift_kind != KMPC_LIFT_MLP);
   }
   // 0: the library's own instantiation, 1: a plug-in (text: its file and whether it was compiled now or found in the kernel cache),
   // -1: the plug-in could not be made (text: why; the handle works with per-step launches), 2: this configuration has no fused roll-out
   int rollout_plugin_status(std::string* text) const override {
+    if (term_every > 0 && term_plugin_state > 0) { if (text) *text = rollout_plugin_describe(term_key); return 1; }
+    if (term_every > 0 && term_plugin_state < 0) { if (text) *text = term_msg; return -1; }
     if (plugin_state > 0) { if (text) *text = rollout_plugin_describe(plugin_key); return 1; }
     if (plugin_state < 0) { if (text) *text = plugin_msg; return -1; }
     if (!fused_rollout_ok()) { if (text) *text = "no fused roll-out for this configuration (per-step launches)"; return 2; }
@@ -1005,6 +1082,15 @@ struct Impl : kmpc_handle {
     r.U_log = (T*)Ulog; r.X_log = (T*)Xlog;
     r.io_f32 = io32 ? 1 : 0;
     if (io32 && !r.s.U0) r.s.U0 = dU0;
+    if constexpr (sizeof(T) == 8) {
+      if (term_every > 0) {
+        if (io32) FAIL(-3, "the per-step terminal refresh is a float64 feature");
+        r.term_every = term_every; r.term_count0 = (int)(term_count % term_every); r.term_maxiter = term_maxiter;
+        r.term_R = term_R; r.term_eps = term_eps; r.term_Q = dTermQ; r.term_W = dWtB;
+        r.term_scratch = dTermScr; r.term_scratch_stride = term_scratch_elems(L); r.term_iters = dDareIt;
+        r.s.Wterm = dWtB; r.s.wterm_per_traj = 1;
+      }
+    }
     if (!dbg_env("KMPC_ROLLOUT_NO_PLACE")) {  // (the trajectories' solver work of the previous launch: RolloutArgs::work)
       if (!dWork) {
         HIPCHK(hipMalloc(&dWork, sizeof(int32_t) * (size_t)B));
@@ -1055,6 +1141,7 @@ struct Impl : kmpc_handle {
       HIPCHK(hipEventRecord(evPlace, s));
       place_stream = s;
     }
+    if (term_every > 0) term_count += steps;
     // the host-side flags follow the kernel's own bookkeeping
     if (update_on && (steps >= 2 || (steps == 1 && have_prev))) rls_fresh = false;
     have_prev = true;
@@ -1620,6 +1707,7 @@ int kmpc_solve_dare(const void* A, const void* B, const double* Q, double R, int
   (void)hipFree(dQl);
   return rc;
 }
+int kmpc_set_terminal_refresh(kmpc_handle* h, int every, const double* Q, double R, int maxiter, double eps) { NN(h); return h->set_terminal_refresh(every, Q, R, maxiter, eps); }
 int kmpc_rollout_is_fused(const kmpc_handle* h) { NN(h); return h->rollout_is_fused(); }
 // Makes (or finds) the plug-in a handle of this configuration would load -- no device needed: hipcc cross-compiles.  For builds that
 // want the kernel cache filled before the first kmpc_create (__graft_entry__.build(), an installer, the first rank of a node).

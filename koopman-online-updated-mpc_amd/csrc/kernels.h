@@ -141,7 +141,19 @@ template <typename T> struct RolloutArgs {
   // to wave 1 in reverse order (snake), ... -- so that every workgroup gets one trajectory of each of sixteen work strata (equal sums:
   // a 20-step launch is ONE round of workgroups and lasts as long as the slowest) and the heavy ones sit on the oldest waves.
   const int32_t* perm;
+  // Per-step terminal refresh (TERM instantiations of the kernel only): the MATLAB controller recomputes its terminal ingredients with the
+  // updated model at every iteration (Koopman_update.m:215 dlqr, :381 Q_bar(end) = C P C').  Every term_every-th step -- counted from
+  // term_count0 + k -- a trajectory runs the reference's Riccati iteration (solve_DARE, duffing.py:583-598) on the [A B] its RLS update
+  // has just produced and rebuilds its block Co P Co' - Qw I in term_W[b] (= s.Wterm with s.wterm_per_traj = 1), inside the launch.
+  int term_every, term_count0, term_maxiter;
+  T term_R, term_eps;
+  const T* term_Q;          // L x L lifted-state weight of the Riccati iteration (shared)
+  T* term_W;                // [B][q*q]
+  T* term_scratch;          // [B][term_scratch_stride]: A, X, M, X_next (L*L each), g, w, hu, hv, B (L each), 16 reduction slots
+  long term_scratch_stride;
+  int32_t* term_iters;      // [B] iterations of the last refresh, or null
 };
+static constexpr long term_scratch_elems(int L) { return 4L * L * L + 5L * L + 16; }
 // rank every trajectory by its work (descending, ties by index: deterministic) and write the slot -> trajectory table (RolloutArgs::perm)
 hipError_t launch_place(const int32_t* work, int B, int32_t* perm, hipStream_t s);
 
@@ -178,14 +190,15 @@ hipError_t launch_dare(const DareArgs& a, hipStream_t s);
 size_t step_lds_bytes(int n, int L, int q, int N, size_t elem, int* r1, int* r2, bool lds_tableau = true);
 
 // layout version of StepArgs / RolloutArgs as the roll-out plug-ins see them (rollout_jit.hip): bump with any change of the two structs
-#define KMPC_PLUGIN_ABI 6001
+#define KMPC_PLUGIN_ABI 6002
 template <typename T> hipError_t launch_step(const StepArgs<T>& a, int threads, hipStream_t s);
 // true if (T, n, L, N, q, threads, lift kind) has a fused roll-out instantiation that fits in LDS
 template <typename T> bool rollout_fused_available(int n, int L, int N, int q, int threads, bool rbf);
 template <typename T> hipError_t launch_rollout_fused(const RolloutArgs<T>& a, hipStream_t s);
 void set_rollout_workgroup(int trajectories);  // 0 = automatic, else 4 / 8 / 16 (process-wide)
 // ---- roll-out plug-ins (rollout_plugin.hip, rollout_jit.hip): the fused roll-out of a dimension set without a built-in instantiation
-struct RolloutPluginKey { int L, N, q, nw, ks, io32; };  // nw: trajectories per workgroup; ks: -1 RBF lift, 25 / 0 MLP lift (compile-time / run-time width)
+// nw: trajectories per workgroup; ks: -1 RBF lift, 25 / 0 MLP lift (compile-time / run-time width); term: with the per-step terminal refresh
+struct RolloutPluginKey { int L, N, q, nw, ks, io32, term; };
 typedef hipError_t (*rollout_plugin_fn)(const RolloutArgs<double>* a, int waves, hipStream_t s);
 bool rollout_plugin_dims(int n, int L, int N, int q);  // a plug-in can be generated for this set
 // the loaded plug-in (process table -> kernel cache on disk -> hipcc), or null with *err saying why
@@ -193,7 +206,8 @@ rollout_plugin_fn rollout_plugin_get(const RolloutPluginKey& k, std::string* err
 std::string rollout_plugin_describe(const RolloutPluginKey& k);
 bool rollout_builtin(int L, int N, int q, bool io32);  // libkoopmpc.so itself holds the instantiations of this set
 // the plug-in a launch of this configuration needs; false: none (built-in set, or the set does not fit the fused kernel at all)
-bool rollout_plugin_key(int n, int L, int N, int q, bool rbf, int Lp, int KS, int Hp, int B, bool io32, RolloutPluginKey* out);
+// (term: the variant with the per-step terminal refresh -- always a plug-in, also for the built-in sets)
+bool rollout_plugin_key(int n, int L, int N, int q, bool rbf, int Lp, int KS, int Hp, int B, bool io32, RolloutPluginKey* out, bool term = false);
 // wave image of one trajectory's state (step_v2.h): [column pair][slot][2] doubles, layer 2 then layer 1
 struct V2Dims {
   int L, n, p, cp, s2, s1;

@@ -11,6 +11,7 @@
 //                           and keeps the code objects on disk): the fused path is a property of the library, not of a list
 #include "step_body.h"
 #include "step_v2.h"
+#include "dare_device.h"
 #ifdef KMPC_ROLLOUT_JIT_TU
 // a plug-in is self-contained: the library decides the workgroup size and hands it over, no debug switches are read
 #define dbg_env(name) ((const char*)nullptr)
@@ -109,7 +110,10 @@ template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads(
 // IOT: element type of the caller-owned panels (X, ref, U0, Useq, U_log, X_log): double, or float for the float32-I/O roll-out of a
 // KMPC_F32 handle (row g2; register-state dimension sets only) -- the state, the handle's own vectors and all arithmetic stay float64,
 // and x_{k+1} is carried from step to step in LDS in float64: only what crosses the boundary is rounded (step_body.h io_ld / io_st)
-template <int L_, int N_, int Q_, int NW, int KS_, typename IOT = double>
+// TERM: with the per-step terminal refresh (RolloutArgs::term_*; Koopman_update.m:215, 381): the step runs in two parts -- RLS, then
+// condensed QP and solve -- with the reference's Riccati iteration on the freshly updated model between them (dare_device.h).  These
+// instantiations are always plug-ins (kmpc_set_terminal_refresh loads them); the kernels without it are what they were.
+template <int L_, int N_, int Q_, int NW, int KS_, typename IOT = double, bool TERM = false>
 __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollout_kernel(const RolloutArgs<double> ra) {
   static_assert(sizeof(IOT) == 8 || ro_v2<L_, N_, Q_>(), "float32 I/O: register-state dimension sets only");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -452,7 +456,43 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       //  registers, 109.7 -> 117.8 M steps/s; its crawling solves are 14 of 327 680 on that workload)
       constexpr bool LOWREG = ro_max_threads<L_, N_, Q_, NW, KS_>() == 1024 && N_ > 24;
       // (y = psi, Q_ == L_: ill-conditioned H, crawling solves are common -- those instantiations keep the register safeguard)
-      if constexpr (V2) {
+      if constexpr (TERM) {
+        // part 1: the RLS update (the model it leaves is in global memory: wave image / dense blocks)
+        StepVar<double> sv1 = sv, sv2 = sv;
+        sv1.phases = sv.phases & PH_RLS;
+        sv1.cov_ahead = 0;
+        sv2.phases = sv.phases & ~PH_RLS;
+        double* imgb = V2 ? R.img + (size_t)bk * R.img_stride : nullptr;
+        if (sv1.phases) {
+          if constexpr (V2) step_v2<L_, N_, Q_, LOWREG, !LOWREG, IOT, 1>(a, sv1, bk, wsm, imgb);
+          else step_body<double, 64, L_, N_, Q_, LOWREG, !LOWREG || Q_ == L_, ro_one_region<L_, N_, Q_, KS_>()>(a, sv1, bk, wsm);
+        }
+        __threadfence_block();
+        block_sync<64>();
+        // the Riccati iteration on this trajectory's current [A B] and its block Co P Co' - Qw I, every term_every-th step
+        if (R.term_every > 0 && ((R.term_count0 + k) % R.term_every) == 0) {
+          double* const scr = R.term_scratch + (size_t)bk * R.term_scratch_stride;
+          double* const Wb = R.term_W + (size_t)bk * Q_ * Q_;
+          int itd;
+          if constexpr (V2) {
+            const V2Dims vd(L_, 2);
+            const int cy0 = a.cy0;
+            itd = wave_dare(L_, Q_, [&](int i, int j) { return imgb[vd.off1(i, j)]; }, [&](int r, int j) { return imgb[vd.off1(L_ + cy0 + r, j)]; },
+                            R.term_Q, R.term_R, R.term_eps, R.term_maxiter, a.Qw, scr, Wb);
+          } else {
+            const double* const Kb = a.K + (size_t)bk * a.strideK;
+            const double* const Cb = a.C + (size_t)bk * a.strideC;
+            const int cy0 = a.cy0;
+            itd = wave_dare(L_, Q_, [&](int i, int j) { return Kb[i * (L_ + 1) + j]; },
+                            [&](int r, int j) { return Q_ == L_ ? (r == j ? 1.0 : 0.0) : Cb[(cy0 + r) * L_ + j]; },
+                            R.term_Q, R.term_R, R.term_eps, R.term_maxiter, a.Qw, scr, Wb);
+          }
+          if (R.term_iters && lane == 0) R.term_iters[bk] = itd;
+        }
+        // part 2: condensed QP (its terminal block is term_W[b]: StepArgs::Wterm, per trajectory) and the solve
+        if constexpr (V2) step_v2<L_, N_, Q_, LOWREG, !LOWREG, IOT, 2>(a, sv2, bk, wsm, imgb);
+        else step_body<double, 64, L_, N_, Q_, LOWREG, !LOWREG || Q_ == L_, ro_one_region<L_, N_, Q_, KS_>()>(a, sv2, bk, wsm);
+      } else if constexpr (V2) {
         double* imgb = R.img + (size_t)bk * R.img_stride;
         step_v2<L_, N_, Q_, LOWREG, !LOWREG, IOT>(a, sv, bk, wsm, imgb);
       } else {
@@ -561,18 +601,18 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
   return 0;
 }
-template <int L_, int N_, int Q_, int NW, int KS_, typename IOT = double>
+template <int L_, int N_, int Q_, int NW, int KS_, typename IOT = double, bool TERM = false>
 static hipError_t launch_rollout_nw(const RolloutArgs<double>& k, int waves, size_t lds, hipStream_t s) {
   static size_t configured_dev[16] = {};  // (function attributes are per device)
   size_t& configured = configured_dev[device_slot()];
   if (lds > 64 * 1024 && lds > configured) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW, KS_, IOT>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_kernel<L_, N_, Q_, NW, KS_, IOT, TERM>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
     configured = lds;
   }
   const int grid = (k.s.B + waves - 1) / waves;
-  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_, IOT>), dim3(grid), dim3(64 * waves), lds, s, k);
+  hipLaunchKernelGGL((rollout_kernel<L_, N_, Q_, NW, KS_, IOT, TERM>), dim3(grid), dim3(64 * waves), lds, s, k);
   return hipGetLastError();
 }
 
@@ -607,7 +647,10 @@ template <int L_, int N_, int Q_, typename IOT = double> static hipError_t launc
   constexpr int JKS = KMPC_JIT_KS, JNW = JKS < 0 ? 16 : KMPC_JIT_NW;
   if (rbf != (JKS < 0)) return hipErrorInvalidValue;
   if (!rbf && (waves != JNW || ks25 != (JKS == 25))) return hipErrorInvalidValue;
-  return launch_rollout_nw<L_, N_, Q_, JNW, JKS, IOT>(k, waves, lds, s);
+  if ((a.term_every > 0) != (KMPC_JIT_TERM != 0)) return hipErrorInvalidValue;
+  if (a.term_every > 0 && (!a.term_Q || !a.term_W || !a.term_scratch || a.term_scratch_stride < term_scratch_elems(L_) || !a.s.Wterm || !a.s.wterm_per_traj))
+    return hipErrorInvalidValue;
+  return launch_rollout_nw<L_, N_, Q_, JNW, JKS, IOT, KMPC_JIT_TERM != 0>(k, waves, lds, s);
 #else
   if (rbf) return launch_rollout_nw<L_, N_, Q_, 16, -1, IOT>(k, waves, lds, s);
   if constexpr (sizeof(IOT) == 4) {  // (float32 I/O: workgroups of sixteen and eight trajectories -- what rollout_waves picks for these sets)
@@ -681,13 +724,14 @@ template <typename T> bool rollout_fused_available(int n, int L, int N, int q, i
   const bool inst = rollout_builtin(L, N, q, false) || rollout_plugin_dims(n, L, N, q);
   return inst && rollout_waves(n, L, q, N, rbf, 64) > 0;  // (Lp <= 64)
 }
-bool rollout_plugin_key(int n, int L, int N, int q, bool rbf, int Lp, int KS, int Hp, int B, bool io32, RolloutPluginKey* out) {
-  if (rollout_builtin(L, N, q, io32) || !rollout_plugin_dims(n, L, N, q)) return false;
+bool rollout_plugin_key(int n, int L, int N, int q, bool rbf, int Lp, int KS, int Hp, int B, bool io32, RolloutPluginKey* out, bool term) {
+  if ((!term && rollout_builtin(L, N, q, io32)) || !rollout_plugin_dims(n, L, N, q)) return false;
+  if (term && io32) return false;  // (the refresh is a float64 feature, as kmpc_terminal_from_dare)
   if (io32 && !step_v2_dims(L, N, q)) return false;
   int waves = rollout_waves(n, L, q, N, rbf, Lp, B);
   if (io32 && !rbf && waves == 4) waves = 8;  // (float32 panels: launch_rollout_impl)
   if (waves == 0) return false;
-  out->L = L; out->N = N; out->q = q; out->io32 = io32 ? 1 : 0;
+  out->L = L; out->N = N; out->q = q; out->io32 = io32 ? 1 : 0; out->term = term ? 1 : 0;
   out->ks = rbf ? -1 : ((KS == 25 && Hp == 112) ? 25 : 0);
   out->nw = rbf ? 16 : waves;  // (the RBF kernel never uses the template's tiling: one object serves every workgroup size)
   return true;
@@ -695,7 +739,7 @@ bool rollout_plugin_key(int n, int L, int N, int q, bool rbf, int Lp, int KS, in
 static hipError_t launch_rollout_plugin(const RolloutArgs<double>& a, hipStream_t s) {
   RolloutPluginKey k{};
   const bool rbf = a.lift_rbf != 0;
-  if (!rollout_plugin_key(a.s.n, a.s.L, a.s.N, a.s.q, rbf, a.Lp, a.KS, a.Hp, a.s.B, a.io_f32 != 0, &k)) return hipErrorInvalidValue;
+  if (!rollout_plugin_key(a.s.n, a.s.L, a.s.N, a.s.q, rbf, a.Lp, a.KS, a.Hp, a.s.B, a.io_f32 != 0, &k, a.term_every > 0)) return hipErrorInvalidValue;
   // (a handle loads its plug-in when it is created; a launch only compiles when the workgroup size was changed afterwards)
   const rollout_plugin_fn fn = rollout_plugin_get(k, nullptr);
   if (!fn) return hipErrorInvalidValue;
@@ -709,7 +753,7 @@ template <> hipError_t launch_rollout_fused<double>(const RolloutArgs<double>& a
   if (a.s.B <= 0 || a.steps <= 0) return hipSuccess;
   if (!a.lift_rbf && (a.Hp > 128 || (a.Hp & 15) || a.Lp > 64 || a.KS > 32 || a.nhh < 0 || a.nhh > 2 || a.s.n > 4))
     return hipErrorInvalidValue;
-  if (!rollout_builtin(a.s.L, a.s.N, a.s.q, a.io_f32 != 0)) return launch_rollout_plugin(a, s);
+  if (a.term_every > 0 || !rollout_builtin(a.s.L, a.s.N, a.s.q, a.io_f32 != 0)) return launch_rollout_plugin(a, s);
   if (a.io_f32) return launch_rollout_io32(a, s);
   if (a.s.L == 20 && a.s.N == 20 && a.s.q == 2) return launch_rollout_impl<20, 20, 2>(a, s);
   if (a.s.L == 8 && a.s.N == 30 && a.s.q == 2) return launch_rollout_impl<8, 30, 2>(a, s);  // BASELINE cfg3 (RBF lift, y = Cx)

@@ -46,11 +46,13 @@ struct Loaded {
   double build_s = 0.0;
 };
 std::mutex g_mu;
-std::map<std::tuple<int, int, int, int, int, int>, Loaded> g_loaded;
-std::map<std::tuple<int, int, int, int, int, int>, std::string> g_failed;  // (a set that failed once is not compiled again and again)
+typedef std::tuple<int, int, int, int, int, int, int> KeyTuple;
+KeyTuple tuple_of(const RolloutPluginKey& k) { return std::make_tuple(k.L, k.N, k.q, k.nw, k.ks, k.io32, k.term); }
+std::map<KeyTuple, Loaded> g_loaded;
+std::map<KeyTuple, std::string> g_failed;  // (a set that failed once is not compiled again and again)
 
 const char* const kFlags[] = {"-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-ffp-contract=fast", "-Wno-pass-failed", "-Wno-unused-function", "-shared"};
-const char* const kSources[] = {"rollout_jit.hip", "rollout_kernel.hip", "step_body.h", "step_v2.h", "qp_rl.h", "kernels.h", "plant_device.h"};
+const char* const kSources[] = {"rollout_jit.hip", "rollout_kernel.hip", "step_body.h", "step_v2.h", "qp_rl.h", "kernels.h", "plant_device.h", "dare_device.h"};
 
 std::string lib_dir() {
   Dl_info info{};
@@ -149,8 +151,8 @@ bool run_hipcc(const std::vector<std::string>& args, const std::string& log, std
 
 std::string object_name(const RolloutPluginKey& k, unsigned long long h) {
   char buf[160];
-  snprintf(buf, sizeof(buf), "rollout_L%d_N%d_q%d_nw%d_ks%s%d_%s_%016llx.so", k.L, k.N, k.q, k.nw, k.ks < 0 ? "m" : "", k.ks < 0 ? -k.ks : k.ks,
-           k.io32 ? "f32" : "f64", h);
+  snprintf(buf, sizeof(buf), "rollout_L%d_N%d_q%d_nw%d_ks%s%d_%s%s_%016llx.so", k.L, k.N, k.q, k.nw, k.ks < 0 ? "m" : "", k.ks < 0 ? -k.ks : k.ks,
+           k.io32 ? "f32" : "f64", k.term ? "_term" : "", h);
   return buf;
 }
 
@@ -185,7 +187,7 @@ bool rollout_plugin_dims(int n, int L, int N, int q) {
 }
 
 rollout_plugin_fn rollout_plugin_get(const RolloutPluginKey& k, std::string* err, bool build_if_missing) {
-  const auto key = std::make_tuple(k.L, k.N, k.q, k.nw, k.ks, k.io32);
+  const auto key = tuple_of(k);
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_loaded.find(key);
   if (it != g_loaded.end()) return it->second.fn;
@@ -236,6 +238,7 @@ rollout_plugin_fn rollout_plugin_get(const RolloutPluginKey& k, std::string* err
     args.push_back("-DKMPC_JIT_NW=" + std::to_string(k.nw));
     args.push_back("-DKMPC_JIT_KS=" + std::to_string(k.ks));
     args.push_back("-DKMPC_JIT_IO32=" + std::to_string(k.io32 ? 1 : 0));
+    args.push_back("-DKMPC_JIT_TERM=" + std::to_string(k.term ? 1 : 0));
     args.push_back("-I" + src);
     args.push_back(src + "/rollout_jit.hip");
     args.push_back("-o");
@@ -262,7 +265,7 @@ rollout_plugin_fn rollout_plugin_get(const RolloutPluginKey& k, std::string* err
 }
 
 std::string rollout_plugin_describe(const RolloutPluginKey& k) {
-  const auto key = std::make_tuple(k.L, k.N, k.q, k.nw, k.ks, k.io32);
+  const auto key = tuple_of(k);
   std::lock_guard<std::mutex> lk(g_mu);
   auto it = g_loaded.find(key);
   if (it != g_loaded.end()) return "plug-in " + it->second.path + " (" + it->second.how + ")";

@@ -207,7 +207,10 @@ template <int N_> __device__ __forceinline__ double* v2_cov_slot(double* sm) { r
 template <int L_> __device__ __forceinline__ int v2_cov_index(int lane) { return lane < 32 ? lane : (lane - 32 < L_ ? lane : 32 + L_ - 1 + (L_ & 1)); }
 
 // sv.psi_now_v / psi_prev_v: lane with (lane & 31) = i < L carries psi_i (BOTH halves).  img: this trajectory's wave image.
-template <int L_, int N_, int Q_, bool LOWREG, bool ASREG, typename IOT = double>
+// PART (the roll-out with the per-step terminal refresh calls the step in two parts with the Riccati iteration between them):
+//   0 the whole step;  1 the RLS phase only (the updated model is in the image when it returns);  2 condensed QP and solve only (the model
+//   comes from the image)
+template <int L_, int N_, int Q_, bool LOWREG, bool ASREG, typename IOT = double, int PART = 0>
 __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar<double>& sv, const int b, double* const sm, double* const img) {
   typedef double d2_t __attribute__((ext_vector_type(2)));
   constexpr int P_ = L_ + 1, CP = (L_ + 2) / 2, NC = 2 * CP, NX = 2, S2 = 2 * L_ + 1, S1 = L_ + NX;
@@ -257,7 +260,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   const d2_t* const im = reinterpret_cast<const d2_t*>(img);
   d2_t* const imw = reinterpret_cast<d2_t*>(img);
   const double psin = sv.psi_now_v;
-  if (sv.phases & PH_RLS) {
+  if (PART != 2 && (sv.phases & PH_RLS)) {
     const bool fu = sv.first_update != 0;
     if (!fu) {
 #pragma unroll
@@ -315,13 +318,14 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
       }
     }
     KTRACE(4);
-  } else {
+  } else if (PART != 1) {
 #pragma unroll
     for (int c = 0; c < CP; ++c) {
       const d2_t v = im[CP * S2 + c * S1 + slot1];
       R1[2 * c] = v.x; R1[2 * c + 1] = v.y;
     }
   }
+  if constexpr (PART == 1) return;
 
   // =====================================================================================
   // phase 2: condensed QP.  v_{j+1} = A v_j (v_0 = B) in lanes 0-31, w_{j+1} = A w_j (w_0 = psi) in lanes 32-63; the rows of C

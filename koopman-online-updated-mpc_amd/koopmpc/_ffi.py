@@ -49,6 +49,7 @@ SIGNATURES = {
     "kmpc_set_terminal_weight": (_I, [_VP, _DP]),
     "kmpc_solve_dare": (_I, [_VP, _VP, _DP, _D, _I, _D, _I, _I, _VP, _VP, _VP, _VP]),
     "kmpc_terminal_from_dare": (_I, [_VP, _DP, _D, _I, _D, _I, _DP, C.POINTER(C.c_int32), _VP]),
+    "kmpc_set_terminal_refresh": (_I, [_VP, _I, _DP, _D, _I, _D]),
     "kmpc_rollout_is_fused": (_I, [_VP]),
     "kmpc_rollout_plugin_status": (_I, [_VP, C.c_char_p, _I]),
     "kmpc_rollout_plugin_prebuild": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.c_char_p, _I]),

@@ -197,6 +197,16 @@ class KoopmanMPC:
                                                    self._stream()), "kmpc_terminal_from_dare")
         return (PN, it) if per_trajectory else (PN[0], int(it[0]))
 
+    def set_terminal_refresh(self, every=1, Q=None, R=0.01, maxiter=500, eps=0.01):
+        """The MATLAB controller's per-iteration terminal ingredients (Koopman_update.m:215 dlqr with the updated model, :381
+        Q_bar(end) = C*P*C'): every `every`-th step each trajectory runs the reference's Riccati iteration (solve_DARE,
+        duffing.py:583-598; Q defaults to its 10 I, R to its 0.01) on its freshly updated [A B] and rebuilds its terminal block before
+        the QP is formed -- inside the launch for fused roll-outs.  every=0 switches it off."""
+        Qh = np.ascontiguousarray(10.0 * np.eye(self.L) if Q is None else Q, dtype=np.float64)
+        if Qh.shape != (self.L, self.L):
+            raise ValueError("Q must be (%d, %d)" % (self.L, self.L))
+        self._chk(self.lib.kmpc_set_terminal_refresh(self.h, int(every), _dptr(Qh), float(R), int(maxiter), float(eps)), "kmpc_set_terminal_refresh")
+
     def offline_fit(self, X, Y, U, ridge=0.0, init_rls=False):
         """K_hat = PHIY pinv([PHIX; U]), C = X pinv(PHIX) (duffing.py:152-177) on the device in Gram form
         (Koopman_update.m:94-101): lift, MFMA Gram sums, p x p solve.  X, Y (n, M), U (M,).  The result

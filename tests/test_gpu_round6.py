@@ -554,3 +554,87 @@ def test_plugin_is_compiled_on_the_box_when_the_cache_is_empty_and_f32_panels_ge
     # a second controller of the set finds the plug-in in the process table: no second compile
     m64b = KM(n=2, L=L, N=N, batch=B, weights=w)
     assert m64b.rollout_plugin_status() == (code, text)
+
+
+# ------------------------------------------------------------------ per-step terminal refresh inside the roll-out
+@pytest.mark.parametrize("L,N,B,lift,lift_offset,every", [(8, 10, 48, "mlp", None, 1), (10, 10, 40, "mlp", "x_psi0", 1), (8, 10, 30, "rbf", None, 1),
+                                                          (20, 20, 24, "mlp", None, 3)])
+def test_terminal_refresh_inside_the_rollout(torch_mod, KM, L, N, B, lift, lift_offset, every):
+    """VERDICT r5 item 6.  The MATLAB controller recomputes its terminal ingredients with the updated model at EVERY iteration
+    (Koopman_update.m:215 K = -dlqr(A, B, ...), :381 Q_bar(end) = C*P*C'; P from the Riccati iteration as stand-in for its LMI,
+    duffing.py:583-613).  kmpc_set_terminal_refresh(every): 30 closed-loop steps as ONE launch -- RLS update, then the Riccati iteration
+    on the trajectory's fresh [A B] inside the kernel, then the condensed QP with Co P Co' as terminal block -- against an oracle loop
+    that calls solve_dare + terminal_block with the updated model at each refresh step (u <= 1e-6, x <= 1e-9), and against the same
+    loop taken step by step (kmpc_step; for the RBF set that is the per-step route: RLS launch, dare_kernel, QP launch: 1e-9).  (20, 20) is a built-in dimension set: the
+    refreshing kernel is a plug-in there too; every = 3 holds the block between refreshes."""
+    torch = torch_mod
+    from koopmpc.synth import random_mlp_weights
+
+    rng = np.random.RandomState(100 * L + N)
+    if lift == "mlp":
+        w = ko.load_mlp_weights(np.load(os.path.join(G, "weights_duffing.npz"))) if L in (8, 10) else random_mlp_weights(2, 100, 3, L, seed=5)
+        make = lambda: KM(n=2, L=L, N=N, batch=B, weights=w, lift_offset=lift_offset)
+        lift_fn = (lambda x: ko.mlp_lift_offset(w, x, lift_offset)) if lift_offset else (lambda x: ko.mlp_lift(w, x))
+    else:
+        cx = 4 * rng.rand(L, 2) - 2
+        make = lambda: KM(n=2, L=L, N=N, batch=B, lift="rbf", centres=cx)
+        lift_fn = lambda x: ko.rbf_lift(x, cx)
+    A = rng.randn(L, L) * 0.5 / np.sqrt(L)
+    Bm, Cm = rng.randn(L, 1) * 0.3, rng.randn(2, L) * 0.3
+    Qd, Rd = 10.0 * np.eye(L), 0.01
+    m, ms = make(), make()
+    for c in (m, ms):
+        c.set_model(A, Bm, Cm)
+        c.set_terminal_refresh(every, Qd, Rd)
+    code, text = m.rollout_plugin_status()
+    print(text)
+    assert code == 1 and "_term_" in text and m.rollout_is_fused()
+    r = np.tile(np.array([[1.0], [0.0]]), (1, N))
+    X0 = 4 * rng.rand(2, B) - 2
+    steps = 30
+    X = _t(torch, X0)
+    Ul, Xl = m.rollout("duffing", X, r, steps, step0=95, switch_step=102, log=True)
+    assert int(m.status.max().item()) == 0
+    # the same loop step by step on a second handle (kmpc_step: one-step launches of the refreshing kernel for the MLP sets, the per-step
+    # route -- RLS launch, dare_kernel, QP launch -- for the RBF set)
+    X2 = _t(torch, X0)
+    worst_step = 0.0
+    for k in range(steps):
+        u2 = ms.step(X2, r).clone()
+        worst_step = max(worst_step, float((u2 - Ul[k]).abs().max()))
+        X2 = ms.plant_step("duffing", X2, u2, switched=(95 + k >= 102))
+    Ul, Xl = Ul.cpu().numpy(), Xl.cpu().numpy()
+    worst_u = worst_x = 0.0
+    for b in range(min(B, 16)):
+        ctl = ko.OracleController(lift_fn, L, 2, N, -2.0, 2.0, A, Bm, Cm, rls="gain")
+        PN = None
+        x = X0[:, b].copy()
+        for k in range(steps):
+            psi = lift_fn(x.reshape(2, 1)).reshape(-1)
+            if ctl.prev is not None:
+                ppsi, pu = ctl.prev
+                ctl.gK, ctl.gP = ko.rls_update_gain(ctl.gK, ctl.gP, np.concatenate([ppsi, [pu]]), psi)
+                ctl.gC, ctl.gQ = ko.rls_update_gain(ctl.gC, ctl.gQ, ppsi, x)
+                ctl.A, ctl.B, ctl.C = ctl.gK[:, :-1].copy(), ctl.gK[:, -1:].copy(), ctl.gC.copy()
+            if k % every == 0:  # K = -dlqr(A, B, ...) / P with the UPDATED model; Q_bar(end) = C*P*C'   (Koopman_update.m:215, 381)
+                P, _ = ko.solve_dare(ctl.A, ctl.B, Qd, Rd)
+                PN = ko.terminal_block(ctl.C, P)
+            _, _, H, f, _ = ko.condense(ctl.A, ctl.B, ctl.C, psi, r, N, ctl.Qw, ctl.Rw, PN=PN)
+            U, _ = ko.qp_exact(H, f, -2.0, 2.0)
+            worst_u = max(worst_u, abs(Ul[k, b] - U[0]))
+            ctl.prev = (psi, float(Ul[k, b]))
+            xo = ko.plant_step("duffing", x, float(Ul[k, b]), switched=(95 + k >= 102))
+            worst_x = max(worst_x, float(np.abs(Xl[k, :, b] - xo).max()))
+            x = Xl[k, :, b].copy()
+    print("terminal refresh every %d step(s) inside ONE launch, (%d, %d, %s): vs oracle loop with solve_dare + terminal_block max |u - u_oracle| %.2e, "
+          "|x - x_oracle| %.2e; vs the per-step route %.2e" % (every, L, N, lift, worst_u, worst_x, worst_step))
+    assert worst_u < 1e-6 and worst_x < 1e-9 and worst_step < 1e-9
+    # the blocks the launch left are those kmpc_terminal_from_dare computes for the same (final) models -- when the last step refreshed
+    if (steps - 1) % every == 0:
+        PNk, itk = m.terminal_from_dare(Qd, Rd, per_trajectory=True)
+        PNo = []
+        Af, Bf, Cf = [t.cpu().numpy() for t in m.get_model()]
+        for b in range(4):
+            P, _ = ko.solve_dare(Af[b], Bf[b], Qd, Rd)
+            PNo.append(ko.terminal_block(Cf[b], P))
+        assert np.abs(PNk[:4] - np.array(PNo)).max() <= 1e-8 * max(1.0, np.abs(np.array(PNo)).max())
