@@ -191,14 +191,19 @@ __device__ __forceinline__ void lc_load_afrags(const double* Wp, int KS, int til
 // Gram tiles, wave t keeps output tile t in its accumulator across the workgroup's trajectory tiles and writes it as the workgroup's
 // partial when the kernel ends (summed in a fixed order by gram_reduce_kernel, as before).  One launch and one round trip of psi through
 // memory less per shared-model step (lift 12.2 + Gram 10.4 us -> one kernel).
-constexpr int LC_GLD = 17;  // leading dimension of the Gram panel [rows][16 trajectories]
-template <int KS_, bool GRAM>
+// Round 6: CT column tiles per pass.  With CT = 2 a wave multiplies every weight fragment it has fetched with the activations of TWO
+// tiles (32 trajectories per workgroup and pass): the same MFMAs, half the passes, half the fragment traffic -- used where a workgroup
+// would otherwise walk two or more tiles one after the other (cfg4: 512 tiles on 256 workgroups; 16.9 -> 15.3 us,
+// profiles/r6_cfg4_lift_gram.txt).  DEV_SKIP: measurement builds only (see the profile record).
+template <int KS_, bool GRAM, int CT>
 __global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> a, const GramArgs<double> g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-  double* const sAct0 = reinterpret_cast<double*>(smem_raw);
-  double* const sAct1 = sAct0 + LC_ACT;
-  double* const sXn = sAct1 + LC_ACT;  // 16 x 4
-  double* const sR = sXn + 64;         // GRAM: [Rp][LC_GLD] panel of the sixteen transitions
+  constexpr int NC = 16 * CT;          // trajectories per pass
+  constexpr int GLD = NC + 1;          // leading dimension of the Gram panel [rows][NC trajectories]
+  double* const sAct0 = reinterpret_cast<double*>(smem_raw);   // [CT][LC_ACT]
+  double* const sAct1 = sAct0 + CT * LC_ACT;
+  double* const sXn = sAct1 + CT * LC_ACT;  // [CT][16 x 4]
+  double* const sR = sXn + CT * 64;         // GRAM: [Rp][GLD] panel of the transitions of the pass
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int B = a.B, n = a.n, L = a.L;
@@ -210,30 +215,30 @@ __global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> 
   const int gmt = wv / gNT, gnt = wv - gmt * gNT;
   const bool gmine = GRAM && wv < gMT * gNT;
   d4 gacc = {0.0, 0.0, 0.0, 0.0};
-  for (int bt = blockIdx.x; bt * 16 < B; bt += gridDim.x) {
-    const int b0 = bt * 16;
-    __syncthreads();  // (the previous tile's activations have been consumed)
-    if (tid < 64) {
-      const int c = tid >> 2, i = tid & 3, b = b0 + c;
+  for (int bt = blockIdx.x; bt * NC < B; bt += gridDim.x) {
+    const int b0 = bt * NC;
+    __syncthreads();  // (the previous pass's activations have been consumed)
+    if (tid < 64 * CT) {
+      const int c = tid >> 2, i = tid & 3, b = b0 + c;  // (column c of the pass: tile c >> 4, its column c & 15)
       sXn[tid] = (b < B && i < n) ? a.X[(size_t)i * B + b] : 0.0;
     }
     if constexpr (GRAM) {
       // rows 0 .. L-1: psi_prev, row L: u_prev, rows p + L ..: x_now (psi_now is written by the output layer below); zeros beyond B / R
-      for (int e = tid; e < gMT * 16 * 16; e += 1024) {
-        const int r = e >> 4, c = e & 15, b = b0 + c;
+      for (int e = tid; e < gMT * 16 * NC; e += 1024) {
+        const int r = e / NC, c = e - r * NC, b = b0 + c;
         double v = 0.0;
         if (b < B) {
           if (r < L) v = g.psi_prev[(size_t)r * g.pp_sl + (size_t)b * g.pp_sb];
           else if (r == L) v = g.u_prev[b];
           else if (r >= gp + L && r < gR) v = a.X[(size_t)(r - gp - L) * B + b];
         }
-        if (r < gp || r >= gp + L) sR[r * LC_GLD + c] = v;
+        if (r < gp || r >= gp + L) sR[r * GLD + c] = v;
       }
     }
     double af[2][LC_KB];
     if (nhh > 0) { if (hid) lc_load_afrags(a.Whp[0], KS, wv, 0, lane, af[0]); }
     else if (out) lc_load_afrags(a.Wop, KS, wv, 0, lane, af[0]);
-    // layer 1 (K = n <= 4: one k-step, W1 zero-padded to 4 columns): one MFMA per hidden tile, bias as the accumulator input
+    // layer 1 (K = n <= 4: one k-step, W1 zero-padded to 4 columns): one MFMA per hidden tile and column tile, bias as the accumulator input
     double a1 = 0.0;
     d4 c1 = {0.0, 0.0, 0.0, 0.0};
     if (hid) {
@@ -243,11 +248,14 @@ __global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> 
     }
     __syncthreads();
     if (hid) {
-      c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sXn[4 * (lane & 15) + (lane >> 4)], c1, 0, 0, 0);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int row = 16 * wv + (lane >> 4) + 4 * r;
-        sAct0[(row >> 2) * 64 + ((row & 3) << 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
+      for (int ct = 0; ct < CT; ++ct) {
+        const d4 c = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sXn[ct * 64 + 4 * (lane & 15) + (lane >> 4)], c1, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 16 * wv + (lane >> 4) + 4 * r;
+          sAct0[ct * LC_ACT + (row >> 2) * 64 + ((row & 3) << 4) + (lane & 15)] = c[r] > 0.0 ? c[r] : 0.0;
+        }
       }
     }
     __syncthreads();
@@ -258,29 +266,40 @@ __global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> 
       double* actn = (h & 1) ? sAct0 : sAct1;
       const double* Wp = last ? a.Wop : a.Whp[h & 1];
       const double* bias = last ? a.bo : a.bh[h & 1];
-      d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+      d4 acc0[CT], acc1[CT];
       if (mine) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc0[r] = bias[16 * wv + (lane >> 4) + 4 * r];
+        for (int ct = 0; ct < CT; ++ct) {
+          acc1[ct] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc0[ct][r] = bias[16 * wv + (lane >> 4) + 4 * r];
+        }
 #pragma unroll
         for (int bt2 = 0; bt2 < 32 / LC_KB; ++bt2) {
           const int kb = bt2 * LC_KB;
           if (kb + LC_KB < KS) lc_load_afrags(Wp, KS, wv, kb + LC_KB, lane, af[(bt2 + 1) & 1]);
 #pragma unroll
           for (int i = 0; i < LC_KB; i += 2) {
-            if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt2 & 1][i], act[(kb + i) * 64 + lane], acc0, 0, 0, 0);
-            if (kb + i + 1 < KS) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt2 & 1][i + 1], act[(kb + i + 1) * 64 + lane], acc1, 0, 0, 0);
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {  // (every fragment meets the activations of all the pass's column tiles)
+              if (kb + i < KS) acc0[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt2 & 1][i], act[ct * LC_ACT + (kb + i) * 64 + lane], acc0[ct], 0, 0, 0);
+              if (kb + i + 1 < KS) acc1[ct] = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt2 & 1][i + 1], act[ct * LC_ACT + (kb + i + 1) * 64 + lane], acc1[ct], 0, 0, 0);
+            }
           }
         }
         const int col = lane & 15;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int row = 16 * wv + (lane >> 4) + 4 * r;
-          const double v = acc0[r] + acc1[r];
-          if (last) {
-            if (row < L && b0 + col < B) a.Psi[(size_t)row * a.ps_l + (size_t)(b0 + col) * a.ps_b] = v;
-            if constexpr (GRAM) { if (row < L) sR[(gp + row) * LC_GLD + col] = b0 + col < B ? v : 0.0; }
-          } else actn[(row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+        for (int ct = 0; ct < CT; ++ct) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * wv + (lane >> 4) + 4 * r;
+            const double v = acc0[ct][r] + acc1[ct][r];
+            const int bc = b0 + 16 * ct + col;
+            if (last) {
+              if (row < L && bc < B) a.Psi[(size_t)row * a.ps_l + (size_t)bc * a.ps_b] = v;
+              if constexpr (GRAM) { if (row < L) sR[(gp + row) * GLD + 16 * ct + col] = bc < B ? v : 0.0; }
+            } else actn[ct * LC_ACT + (row >> 2) * 64 + ((row & 3) << 4) + col] = v > 0.0 ? v : 0.0;
+          }
         }
       }
       if (!last) {  // the next layer's first fragments travel across the barrier
@@ -290,13 +309,14 @@ __global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> 
       }
     }
     if constexpr (GRAM) {
-      __syncthreads();  // (psi_now of the sixteen trajectories is in the panel)
+      __syncthreads();  // (psi_now of the pass's trajectories is in the panel)
       if (gmine) {
         // out[i][j] += sum_k R[i][k] Z[j][k]: A lane l: R[16 mt + (l & 15)][4 ks + (l >> 4)], B lane l: Z[16 nt + (l & 15)][4 ks + (l >> 4)]
-        const double* const pa = sR + (16 * gmt + (lane & 15)) * LC_GLD + (lane >> 4);
-        const double* const pb = sR + (16 * gnt + (lane & 15)) * LC_GLD + (lane >> 4);
+        // (the transitions are summed in the order of their index whatever CT is: k-steps 0 .. 4 CT - 1 of pass after pass)
+        const double* const pa = sR + (16 * gmt + (lane & 15)) * GLD + (lane >> 4);
+        const double* const pb = sR + (16 * gnt + (lane & 15)) * GLD + (lane >> 4);
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], gacc, 0, 0, 0);
+        for (int ks = 0; ks < 4 * CT; ++ks) gacc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * ks], pb[4 * ks], gacc, 0, 0, 0);
       }
     }
   }
@@ -313,8 +333,8 @@ static hipError_t launch_lift_coop(const LiftArgs<double>& a, hipStream_t s) {
   const int ntiles = (a.B + 15) / 16;
   const int grid = ntiles < 2048 ? ntiles : 2048;
   const GramArgs<double> g{};
-  if (a.KSp == 25 && a.Hp == 112) hipLaunchKernelGGL((lift_coop_kernel<25, false>), dim3(grid), dim3(1024), lds, s, a, g);
-  else hipLaunchKernelGGL((lift_coop_kernel<0, false>), dim3(grid), dim3(1024), lds, s, a, g);
+  if (a.KSp == 25 && a.Hp == 112) hipLaunchKernelGGL((lift_coop_kernel<25, false, 1>), dim3(grid), dim3(1024), lds, s, a, g);
+  else hipLaunchKernelGGL((lift_coop_kernel<0, false, 1>), dim3(grid), dim3(1024), lds, s, a, g);
   return hipGetLastError();
 }
 // lift + Gram sums of the step's transitions in one launch (float64 MLP lift, the cooperative encoder): g.partial receives one partial
@@ -327,14 +347,29 @@ bool lift_gram_available(const LiftArgs<double>& a) {
 hipError_t launch_lift_gram(const LiftArgs<double>& a, const GramArgs<double>& g, int* nblocks, hipStream_t s) {
   if (a.B <= 0 || !lift_gram_available(a)) return hipErrorInvalidValue;
   const int p = a.L + 1, R = p + a.L + a.n, MT = (R + 15) / 16;
-  const size_t lds = (size_t)(2 * LC_ACT + 64 + MT * 16 * LC_GLD) * sizeof(double);
   const int ntiles = (a.B + 15) / 16;
-  int grid = ntiles < g.max_blocks ? ntiles : g.max_blocks;
+  // two column tiles per pass where a workgroup would otherwise walk two or more tiles one after the other (cfg4: 512 tiles, 256 blocks)
+  static const bool one = dbg_env("KMPC_LIFT_GRAM_CT1") != nullptr;  // measurement / test aid: one tile per pass as in round 5
+  const int ct = (ntiles > g.max_blocks && !one) ? 2 : 1;
+  const size_t lds = (size_t)(ct * (2 * LC_ACT + 64) + MT * 16 * (16 * ct + 1)) * sizeof(double);
+  const int npass = (ntiles + ct - 1) / ct;
+  int grid = npass < g.max_blocks ? npass : g.max_blocks;
   if (grid < 1) grid = 1;
   *nblocks = grid;
-  if (a.KSp == 25 && a.Hp == 112) hipLaunchKernelGGL((lift_coop_kernel<25, true>), dim3(grid), dim3(1024), lds, s, a, g);
-  else hipLaunchKernelGGL((lift_coop_kernel<0, true>), dim3(grid), dim3(1024), lds, s, a, g);
-  return hipGetLastError();
+  const bool ks25 = a.KSp == 25 && a.Hp == 112;
+  auto go = [&](auto kern) -> hipError_t {
+    static size_t configured_dev[16] = {};  // (function attributes are per device)
+    size_t& configured = configured_dev[device_slot()];
+    if (lds > 64 * 1024 && lds > configured) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      configured = lds;
+    }
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(1024), lds, s, a, g);
+    return hipGetLastError();
+  };
+  if (ct == 2) return ks25 ? go(&lift_coop_kernel<25, true, 2>) : go(&lift_coop_kernel<0, true, 2>);
+  return ks25 ? go(&lift_coop_kernel<25, true, 1>) : go(&lift_coop_kernel<0, true, 1>);
 }
 
 // ---------------------------------------------------------------------------------------
