@@ -324,7 +324,12 @@ __global__ __launch_bounds__(1024) void lift_coop_kernel(const LiftArgs<double> 
     if (gmine) {  // this workgroup's partial tile -> [block][Rp][16 NT] (gram_reduce_kernel)
       double* const outp = g.partial + (size_t)blockIdx.x * (gMT * 16) * (16 * gNT);
 #pragma unroll
-      for (int r = 0; r < 4; ++r) outp[(16 * gmt + (lane >> 4) + 4 * r) * (16 * gNT) + 16 * gnt + (lane & 15)] = gacc[r];
+      for (int r = 0; r < 4; ++r) {
+        // (only what the reduction reads: the padding of the tiles is 42 % of the block's bytes at cfg4's 67 x 33, and every byte written
+        //  here is written back through L2 when the kernel ends)
+        const int gi = 16 * gmt + (lane >> 4) + 4 * r, gj = 16 * gnt + (lane & 15);
+        if (gi < gR && gj < gp) outp[gi * (16 * gNT) + gj] = gacc[r];
+      }
     }
   }
 }
