@@ -304,6 +304,13 @@ class KoopmanMPC:
 
     # ------------------------------------------------------------------ a5-a8 MPC
     def _ref(self, r):
+        # (fast path: a reference that already is a contiguous device tensor of the handle's dtype and shape -- the loop of a running
+        #  controller hands the same tensor over at every call; the conversions below cost ~10 us of host time per call otherwise)
+        if torch.is_tensor(r) and r.dtype == self.dtype and r.device == self.device and r.is_contiguous():
+            if r.dim() == 2 and tuple(r.shape) == (self.q, self.N):
+                return r, 0
+            if r.dim() == 3 and tuple(r.shape) == (self.B, self.q, self.N):
+                return r, 1
         r = self._dev(r)
         if r.dim() == 2:
             return r.reshape(self.q, self.N).contiguous(), 0
