@@ -68,6 +68,11 @@ CONFIGS = {
                      text="BASELINE cfg3 with L = 20 centres (SURVEY 8d asks for it beside L = 8): Van der Pol closed loop as "
                           "vanderpol_RBF.py, 20 thin-plate RBF observables, y = C x, box +-2, storage update, horizon N=30, RK4 plant on "
                           "device, parameter switch at step 102"),
+    # not a BASELINE configuration: the dimension set of the reference's own MATLAB controller (Koopman_update.m:67, 70, 113: L = 10 =
+    # [x; Encoder(x)] - [0; Encoder(0)], N = 10), for which libkoopmpc.so holds no instantiation -- its fused kernel is a roll-out plug-in
+    "twin": dict(L=10, N=10, B=4096, plant="duffing", lift="mlp", layers=3, lift_offset="x_psi0", output="Cx", lb=-2.0, ub=2.0, P0=1e4, barQ0=100.0,
+                 settle=200, text="the reference's MATLAB-twin dimension set: Duffing closed loop, lift [x; psi(x)] - [0; psi(0)] with an 8-output "
+                                  "MLP encoder (2-100-100-100-8, random init seed 2024), L = 10, N = 10, box +-2, per-trajectory RLS, RK4 plant on device"),
     "cfg4": dict(L=32, N=40, B=8192, plant="tank", lift="mlp", layers=2, shared=True, settle=260,
                  text="BASELINE cfg4: cascaded tanks (Tank_System.m), 32-dim MLP lift (2-100-100-32, random init seed 9), N=40, "
                       "delta-u form with Cy = [0 1], ONE model for all trajectories of all ranks from the all-reduced EDMD Gram "
@@ -99,10 +104,22 @@ def workload_inputs(name, L, N):
         w["data"] = (X, Y, U)
         w["ref"] = np.tile(np.array([[1.0], [0.0]]), (1, N))
     else:
-        w["weights"] = random_mlp_weights(2, 100, 3, L, seed=2024)
+        w["weights"] = random_mlp_weights(2, 100, 3, L - (2 if c.get("lift_offset") == "x_psi0" else 0), seed=2024)
         w["data"] = offline_data()
         w["ref"] = np.tile(np.array([[1.0], [0.0]]), (1, N))
     return w
+
+
+def oracle_lift(w):
+    """the oracle's lift of a workload (MLP, MLP with the MATLAB offset form, RBF)"""
+    from oracle import koopman_oracle as ko
+
+    c = w["cfg"]
+    if c.get("lift") == "rbf":
+        return lambda x: ko.rbf_lift(x, w["centres"])
+    if c.get("lift_offset"):
+        return lambda x: ko.mlp_lift_offset(w["weights"], x, c["lift_offset"])
+    return lambda x: ko.mlp_lift(w["weights"], x)
 
 
 def initial_states_for(name, B, seed):
@@ -130,10 +147,7 @@ def _cpu_worker(args):
     w = workload_inputs(name, L, N)
     c = w["cfg"]
     X, Y, U = w["data"]
-    if c["lift"] == "rbf":
-        lift = lambda x: ko.rbf_lift(x, w["centres"])
-    else:
-        lift = lambda x: ko.mlp_lift(w["weights"], x)
+    lift = oracle_lift(w)
     PX, PY = lift(X), lift(Y)
     Z = np.concatenate([PX, U[None, :]], 0)
     K0 = PY @ np.linalg.pinv(Z)  # the reference's one-off fit (duffing.py:152-177)
@@ -220,7 +234,7 @@ def _probe_worker(path):
     name, L, N = str(d["name"]), int(d["L"]), int(d["N"])
     w = workload_inputs(name, L, N)
     c = w["cfg"]
-    lift = (lambda x: ko.rbf_lift(x, w["centres"])) if c.get("lift") == "rbf" else (lambda x: ko.mlp_lift(w["weights"], x))
+    lift = oracle_lift(w)
     X, A, Bm, Cm, u_gpu, uprev, r = d["X"], d["A"], d["B"], d["C"], d["u"], d["uprev"], w["ref"]
     worst = 0.0
     for i in range(X.shape[1]):
@@ -372,7 +386,7 @@ class Loop:
             self.m.offline_fit(*w["data"], ridge=1e-9, init_rls=True)
         else:
             self.m = KoopmanMPC(n=2, L=L, N=N, batch=B, weights=w["weights"], dtype=dtype, threads=threads, device=dev,
-                                cold_start=cold, lb=c["lb"], ub=c["ub"])
+                                cold_start=cold, lb=c["lb"], ub=c["ub"], lift_offset=c.get("lift_offset"))
             self.m.offline_fit(*w["data"])
         self.X = torch.tensor(initial_states_for(name, B, 101 + rank), dtype=dtype, device=dev).contiguous()
         self.r = torch.tensor(w["ref"], dtype=dtype, device=dev)
@@ -521,6 +535,7 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
     pr = main_loop.m.profile_read()
     main_loop.m.profile(False)
     mpc = main_loop.m
+    measure_config.last_plugin = mpc.rollout_plugin_status()
     worst_status = int(mpc.status.max().item())
     newton_per_step = float(mpc.iters.double().mean().item()) / (max(1, args.steps) if (not main_loop.shared or main_loop.native) else 1)
     newton_max = int(mpc.iters.max().item())
@@ -841,6 +856,9 @@ def main():
                                           o["x_ok"], ro.get("parity_probe_max_abs_u_err"), ro["executed_flop_frac"]]
                 if ro["bound"] != "hbm":  # (compute-bound set: frac is over the executed flops, the nominal dense-H figure beside it)
                     others[label or oname].append({"nominal_flop_frac": ro["nominal_flop_frac"]})
+                if oname == "twin":
+                    code, text = getattr(measure_config, "last_plugin", (None, ""))
+                    others[label or oname].append({"kernel": "roll-out plug-in (no instantiation of this set inside libkoopmpc.so): " + text if code == 1 else text})
                 if a_.dtype == "f32":
                     others[label or oname].append({"io": "float32 panels, float64 state and arithmetic inside the launch (SURVEY G6): frac is over the float64 state's bytes",
                                                    "fused": ro["steps_per_launch"] > 1, "frac_on_f32_formula_bytes": ro.get("frac_on_f32_formula_bytes")})
@@ -850,6 +868,9 @@ def main():
 
         for oname in ("cfg4", "cfg3", "cfg3-L20", "cfg5"):
             leg(oname, args)
+        # the fused path is a property of the library, not of a list of dimension sets: the reference's MATLAB-twin set (10, 10, 2) has
+        # no instantiation inside libkoopmpc.so and runs on a roll-out plug-in made when the controller is created
+        leg("twin", args, "matlab-twin-L10-N10")
         # the headline's kernel with a state that no longer fits the 256 MB Infinity Cache (348 MB at 16384 trajectories; four rounds of
         # workgroups): does the rate hold when the state really streams from HBM?  
         leg("cfg2", args, "cfg2-B16384", batch=16384)
