@@ -1082,13 +1082,51 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
       isF = own && ((Fmask >> myvar) & 1ull);
       pdir = matvec(Tel, isF ? g : T(0));
       if (carried) {
+        // Round 6 -- every refinement pass also CORRECTS the tableau (symmetric rank-one secant update).  A pass applies d_k = T r_k and
+        // finds the next residual r_{k+1} = r_k + 2 H d_k: the pair (y, d_k), y = r_{k+1} - r_k = 2 H d_k, is exact information about
+        // H -- the true tableau T* = -(2 H_FF)^-1 maps y to -d_k.  With c = T r_{k+1} (the product the pass computes anyway),
+        // T y = c - d_k, so the error on y is v = -d_k - T y = -c and
+        //     T <- T + v v' / (v' y) = T - c c' / (c' y)
+        // makes T exact on y at the cost of two dot products and RM^2 multiply-adds per thread -- no further product -- and the
+        // correction the UPDATED tableau gives for r_{k+1} is beta c with beta = 1 - (c' r_{k+1}) / (c' y).  What a plain pass
+        // (T unchanged, p += c) gains is a factor |I - T 2H| per pass, the same factor again at the next step: the tableau a
+        // trajectory carries was an exact inverse once and falls behind H by one model update per step (round-4 trace: 4 - 6 passes for
+        // a carried solve, 16 % of the solves gave up after six and paid the N sweeps of a rebuild on top, 31 % started from 2 H because
+        // their last solve had needed five passes).  With the correction the error is deflated in exactly the directions the
+        // closed loop's gradients excite, and it STAYS corrected in the tableau the next step starts from.  The answer does not depend on
+        // any of it: the KKT test is evaluated with H.  (profiles/r6_cfg5_secant.txt)
         bool stale = false;
+        T rprev = isF ? g : T(0);
         for (int kr = 0;; ++kr) {
           const T hp = matvec(Hel, isF ? pdir : T(0));
           const T rr = isF ? g + T(2) * hp : T(0);
           if (!__syncthreads_or(!(tabs(rr) <= (T)1e-13 * gs) && isF)) break;
           if (kr >= 6) { stale = true; break; }
-          pdir += matvec(Tel, rr);
+          const T cn = matvec(Tel, rr);
+          const T cF = isF ? cn : T(0);
+          T da = cF * rr, db = cF * (rr - rprev);
+          block_sum2<T, 256, true>(da, db, red);
+          // (vector of the update by variable, for the rows and the columns of every thread's block: the sweeps' column buffer is idle here)
+          if (own) colb[myvar] = cF;
+          else if (tid >= N_ && tid < 64) colb[tid] = T(0);  // (the padding of the blocks stays zero)
+          block_sync_lds<256>();
+          T beta = T(1);
+          if (tabs(db) > T(0) && tabs(da) < T(4) * tabs(db)) {  // (safeguard: a pair without curvature information corrects nothing)
+            const T coef = -T(1) / db;
+            beta = T(1) - da / db;
+            T cr[RM], cc[RM];
+#pragma unroll
+            for (int r = 0; r < RM; ++r) cr[r] = colb[ti + 16 * r] * coef;
+#pragma unroll
+            for (int c = 0; c < RM; ++c) cc[c] = colb[tj + 16 * c];
+#pragma unroll
+            for (int r = 0; r < RM; ++r)
+#pragma unroll
+              for (int c = 0; c < RM; ++c) Tm[r][c] += cr[r] * cc[c];
+            ++nsw;  // (the tableau in registers is no longer the one global memory holds)
+          }
+          pdir += beta * cn;
+          rprev = rr;
           ++nref;
         }
         if (stale) {  // the carried tableau does not contract: this direction again from 2H
@@ -1180,7 +1218,8 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
     if (a.x_warm) a.x_warm[(size_t)myvar * B + b] = x;
   }
   if (a.qp_carry) {  // the tableau stays for the next solve (a carried one that needed many iterations does not: 2H next time)
-    const bool keep = status == 0 && !(carried && (it >= 4 || nref >= 5));
+    // (round 6: the refinement passes correct the tableau they use, so the number of passes a solve needed is no reason to drop it any more)
+    const bool keep = status == 0 && !(carried && it >= 4);
     // (a carried tableau that saw no sweep is what global memory already holds: half of the settled solves, 20 KB each at N = 50)
     if (keep && !(carried && nsw == 0)) {
       T* const Tg = a.qp_carry + (size_t)b * N_ * N_;
