@@ -701,6 +701,8 @@ hipError_t launch_rollout_io32(const RolloutArgs<double>& a, hipStream_t s);
 // the dimension sets whose instantiations libkoopmpc.so holds itself (BASELINE.json's configurations, the reference's scripts); every
 // other set of rollout_plugin_dims gets its kernel as a plug-in when a handle is created (rollout_plugin.hip)
 bool rollout_builtin(int L, int N, int q, bool io32) {
+  static const bool force = dbg_env("KMPC_FORCE_PLUGIN") != nullptr;  // measurement aid: every set on a plug-in compiled from the shipped sources
+  if (force) return false;
 #ifdef KMPC_DEV_CFG2_ONLY
   if (io32) return L == 20 && N == 20 && q == 2;
   return (L == 20 && N == 20 && q == 2) || (L == 8 && N == 30 && q == 2);

@@ -149,7 +149,22 @@ bool run_hipcc(const std::vector<std::string>& args, const std::string& log, std
   return true;
 }
 
+// measurement aid (KMPC_DEBUG only): extra compiler flags for the plug-ins, e.g. -DSOME_SWITCH=1 -- part of the object's hash, so that
+// two settings are two objects (tools/dbg/ab_plugin.sh alternates them on one box; with KMPC_FORCE_PLUGIN the built-in sets run on plug-ins)
+std::vector<std::string> extra_flags() {
+  std::vector<std::string> out;
+  const char* e = dbg_env("KMPC_PLUGIN_FLAGS");
+  if (!e) return out;
+  std::string cur;
+  for (const char* p = e;; ++p) {
+    if (*p == ' ' || *p == 0) { if (!cur.empty()) out.push_back(cur); cur.clear(); if (!*p) break; }
+    else cur.push_back(*p);
+  }
+  return out;
+}
 std::string object_name(const RolloutPluginKey& k, unsigned long long h) {
+  for (const auto& f : extra_flags())
+    for (char ch : f) { h ^= (unsigned char)ch; h *= 1099511628211ull; }
   char buf[160];
   snprintf(buf, sizeof(buf), "rollout_L%d_N%d_q%d_nw%d_ks%s%d_%s%s_%016llx.so", k.L, k.N, k.q, k.nw, k.ks < 0 ? "m" : "", k.ks < 0 ? -k.ks : k.ks,
            k.io32 ? "f32" : "f64", k.term ? "_term" : "", h);
@@ -239,6 +254,7 @@ rollout_plugin_fn rollout_plugin_get(const RolloutPluginKey& k, std::string* err
     args.push_back("-DKMPC_JIT_KS=" + std::to_string(k.ks));
     args.push_back("-DKMPC_JIT_IO32=" + std::to_string(k.io32 ? 1 : 0));
     args.push_back("-DKMPC_JIT_TERM=" + std::to_string(k.term ? 1 : 0));
+    for (const auto& f : extra_flags()) args.push_back(f);
     args.push_back("-I" + src);
     args.push_back(src + "/rollout_jit.hip");
     args.push_back("-o");

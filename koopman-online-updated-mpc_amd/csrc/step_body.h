@@ -1104,12 +1104,12 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
           if (kr >= 6) { stale = true; break; }
           const T cn = matvec(Tel, rr);
           const T cF = isF ? cn : T(0);
-          T da = cF * rr, db = cF * (rr - rprev);
-          block_sum2<T, 256, true>(da, db, red);
-          // (vector of the update by variable, for the rows and the columns of every thread's block: the sweeps' column buffer is idle here)
+          // (vector of the update by variable, for the rows and the columns of every thread's block: the sweeps' column buffer is idle
+          //  here; the barriers of the sums below publish it)
           if (own) colb[myvar] = cF;
           else if (tid >= N_ && tid < 64) colb[tid] = T(0);  // (the padding of the blocks stays zero)
-          block_sync_lds<256>();
+          T da = cF * rr, db = cF * (rr - rprev);
+          block_sum2<T, 256, true>(da, db, red);
           T beta = T(1);
           if (tabs(db) > T(0) && tabs(da) < T(4) * tabs(db)) {  // (safeguard: a pair without curvature information corrects nothing)
             const T coef = -T(1) / db;
