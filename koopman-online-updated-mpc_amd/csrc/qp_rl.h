@@ -182,8 +182,7 @@ struct QpCarry {  // what a solve leaves for the next one (registers of the step
 //  tools/experiments/qp_rl_active_set_variant.h.txt.  Crawling solves are finished by the active-set loop of qp_lds, step_v2.h.)
 template <int N_, typename IOT = double>
 __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const StepArgs<double>& a, const StepVar<double>& sv, const int b,
-                                      double* qx_out, double* u_slot, double (&M)[N_], double& rs, double& rsi, QpCarry& cs, double up, double xw_pre,
-                                      double* xpp = nullptr) {
+                                      double* qx_out, double* u_slot, double (&M)[N_], double& rs, double& rsi, QpCarry& cs, double up, double xw_pre) {
   typedef double d2_t __attribute__((ext_vector_type(2)));
   static_assert(N_ <= 32, "qp_rl: one variable per lane of a 32-lane half (ownmask, row_newbcast index, diagonal lane)");
   const int tid = local_tid<64>(), half = tid >> 5, t = tid & 31;
@@ -246,12 +245,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   // The carried tableau is that face's, so the first Newton point costs no sweeps; a wrong guess is an input at a bound with an
   // inward gradient, which the first KKT test frees again.
   const bool held = carried && !warm && !((Smask >> t) & 1u);
-  double xstart = xw_pre;
-  if (xpp) {  // experiment: linear extrapolation of the last two minimisers
-    const double x2 = xpp[t];
-    if (own && x2 < 1e299) xstart = 2.0 * xw_pre - x2;
-  }
-  double x = own ? (warm ? tclip(xstart, lb, ub) : (held ? (((cs.umask >> t) & 1u) ? ub : lb) : c0)) : 0.0;
+  double x = own ? (warm ? tclip(xw_pre, lb, ub) : (held ? (((cs.umask >> t) & 1u) ? ub : lb) : c0)) : 0.0;
   double hx;
   {
     double lo, hi;
@@ -472,7 +466,6 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     cs.valid = 0;
     return true;
   }
-  if (xpp && own && !half) xpp[t] = xw_pre;
   if (own && !half) {
     if (a.Useq) io_st<IOT>(a.Useq, (size_t)t * B + b, x);
     if (a.x_warm) a.x_warm[(size_t)t * B + b] = x;

@@ -47,11 +47,7 @@ static constexpr int v2_carry_elems(int L) { return 66 + v2_cov_elems(L); }
 // long horizons (N >= 30): the recursion's stores are masked instead of sending the lanes without an output to a dump area --
 // the kilobyte is the difference between 14 and 16 trajectories per CU there
 static constexpr bool v2_chain_dump(int N) { return N < 30; }
-#ifndef KMPC_WARM_EXTRAP
-#define KMPC_WARM_EXTRAP 0
-#endif
-static constexpr int v2_xpp_elems(int N) { return (KMPC_WARM_EXTRAP && N <= 24) ? 32 : 0; }  // experiment: the minimiser before the last one
-static constexpr int v2_vec_elems(int q, int N) { return 16 + 2 * ((N + 1) & ~1) + (q + 2 * N * q) + imax(2 * N, (N + 1) * q + (v2_chain_dump(N) ? (N + 1) * q + 64 : 0)) + 2 + v2_xpp_elems(N); }
+static constexpr int v2_vec_elems(int q, int N) { return 16 + 2 * ((N + 1) & ~1) + (q + 2 * N * q) + imax(2 * N, (N + 1) * q + (v2_chain_dump(N) ? (N + 1) * q + 64 : 0)) + 2; }
 static constexpr size_t v2_lds_elems(int L, int q, int N) { return ((size_t)v2_region1(N) + v2_carry_elems(L) + v2_vec_elems(q, N) + 1) & ~(size_t)1; }
 
 // ---------------------------------------------------------------------------------------
@@ -469,8 +465,7 @@ __device__ __forceinline__ void step_v2(const StepArgs<double>& a, const StepVar
   // phase 3: box QP (rows in lanes, carried tableau: qp_rl.h)
   // =====================================================================================
   if (sv.phases & PH_QP) {
-    double* const sXpp = v2_xpp_elems(N_) ? vec + v2_vec_elems(Q_, N_) - 34 : nullptr;
-    if (qp_rl<N_, IOT>(sR, sf, a, sv, b, qxo, red + 15, M, rs, rsi, cs, up, xw_pre, sXpp)) {
+    if (qp_rl<N_, IOT>(sR, sf, a, sv, b, qxo, red + 15, M, rs, rsi, cs, up, xw_pre)) {
       // crawling solve (rare): H moves to this trajectory's global scratch block, the active-set loop of qp_lds works with an
       // LDS tableau in its place
 #ifdef KMPC_TRACE
@@ -520,10 +515,6 @@ template <int L_, int N_, int Q_> __device__ __forceinline__ void step_v2_init(d
     ci[3] = 0;
   }
   for (int e = tid; e < N_ * Q_; e += 64) sEr[N_ * Q_ + e] = 0.0;
-  if (v2_xpp_elems(N_)) {
-    double* const sXpp = sCs + v2_carry_elems(L_) + v2_vec_elems(Q_, N_) - 34;
-    if (tid < 32) sXpp[tid] = 1e300;  // (no minimiser before the last one yet)
-  }
 }
 
 }  // namespace kmpc
