@@ -847,8 +847,10 @@ def main():
         def leg(oname, a_, label=None, batch=0):
             oc = CONFIGS[oname]
             try:
-                o = measure_config(oname, a_, None, dev, 0, 1, oc["L"], oc["N"], batch or oc["B"], oc["settle"], extras=False, spin_seconds=0.3,
-                                   probe=not a_.no_probe)
+                # (the clock ramp in front of a leg: 0.3 s of its own launches; cfg5's launches are 2.4 ms each -- six replicas of its window
+                #  are not a ramp: 1 s, as the stand-alone run of the configuration has)
+                o = measure_config(oname, a_, None, dev, 0, 1, oc["L"], oc["N"], batch or oc["B"], oc["settle"], extras=False,
+                                   spin_seconds=1.0 if oname == "cfg5" else 0.3, probe=not a_.no_probe)
                 ro = o["roofline"]
                 # [steps/s, frac of the governing roofline, bound, kernel ms per launch, steps per launch, worst QP status, finite,
                 #  parity probe max |u - u_oracle|, executed-flop fraction]
