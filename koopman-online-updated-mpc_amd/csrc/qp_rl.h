@@ -169,8 +169,11 @@ struct QpCarry {  // what a solve leaves for the next one (registers of the step
   unsigned umask;   // of the others (held at a bound by that solve): those at the UPPER bound
   // how the carried tableaux of this trajectory have fared: bits 0-7 consecutive solves whose carried tableau did not contract
   // (stale), bits 8-15 solves since the last one that was given the full pass budget.  A trajectory whose model still moves a lot
-  // from step to step (2 stale solves in a row) gets 2 refinement passes instead of 6 before the tableau is given up -- it paid 6
-  // passes AND the N sweeps at every step --, and the full budget again every fourth solve (so that it finds its way back)
+  // from step to step (2 stale solves in a row) gets 3 refinement passes instead of 8 before the tableau is given up -- it paid the
+  // full budget AND the N sweeps at every step --, and the full budget again every fourth solve (so that it finds its way back).
+  // (Round 6: 8 / 3 passes and "kept unless a direction needed 7" instead of 6 / 2 and 5 -- the three numbers were swept with the
+  //  plug-in A/B tool, every setting its own kernel on one box: the window moves by - 3.5 % ... + 4 % with them, the code object is the
+  //  same to the instruction; profiles/r6_cfg2_pass_budget_ab.txt)
   int trust;
 };
 
@@ -217,7 +220,7 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
   bool carried = cs.valid != 0;  // the tableau in lanes 0-31 is last step's
   const int nstale0 = cs.trust & 0xff, probe_age = (cs.trust >> 8) & 0xff;
   const bool full_budget = nstale0 < 2 || probe_age >= 3;
-  const int kr_max = full_budget ? 6 : 2;
+  const int kr_max = full_budget ? 8 : 3;
   bool went_stale = false;
   const bool carried_at_start = carried;
   unsigned Smask = carried ? cs.smask : 0u;
@@ -498,9 +501,9 @@ __device__ __forceinline__ bool qp_rl(double* const sR, const double* sf, const 
     }
   }
   // the tableau takes H's place in LDS until the next solve.  A solve that worked with the carried tableau and needed many
-  // iterations, or five refinement passes for one direction (the contraction |I - T 2H| has worn: a solve from clip(0) refines a
-  // gradient of full size and takes three or four), leaves nothing: the next one starts from 2H.
-  const bool keep = status == 0 && !(carried && (it >= 4 || nref >= (warm ? 5 : 7)));
+  // iterations, or seven refinement passes for one direction (the contraction |I - T 2H| has worn), leaves nothing: the next one
+  // starts from 2H.
+  const bool keep = status == 0 && !(carried && (it >= 4 || nref >= 7));
   if (keep && own && !half) {
     double* const trow = sR + t * NS;
     if constexpr ((N_ & 1) == 0) {
