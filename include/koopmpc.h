@@ -334,6 +334,11 @@ int kmpc_rollout_plugin_status(const kmpc_handle* h, char* text, int text_bytes)
  * Returns 0 / 1 / -1 / 2 as kmpc_rollout_plugin_status, -3 for bad arguments.                                                   */
 int kmpc_rollout_plugin_prebuild(int n, int L, int N, int out_rows, int lift_kind, int hidden_eff, int batch, int dtype, char* text,
                                  int text_bytes);
+/* The placement pass kmpc_rollout runs behind a fused launch, as a function of its own (tests, tools): from every trajectory's solver-work
+ * counter work_dev[B] (B a multiple of 16, at most 2^20) the slot -> trajectory table of the next launch -- trajectories ranked by work
+ * (descending, ties by index: every pair compared up to 16384 trajectories, a stable radix sort by one workgroup, O(B), beyond), rank r dealt to wave r / (B/16) of workgroup r mod (B/16) in
+ * snake order.  perm_dev must hold 3 B int32: the table in its first B entries, the sort's buffers behind it.                        */
+int kmpc_rank_by_work(const int32_t* work_dev, int B, int32_t* perm_dev, void* stream);
 /* Trajectories per workgroup of the fused roll-out kernel (MLP lift): 4, 8 or 16; 0 = automatic (most
  * trajectories per CU, ties to the larger workgroup).  Process-wide tuning / test knob: every
  * trajectory's arithmetic is the same for every choice, only the scheduling differs.

@@ -1100,7 +1100,7 @@ struct Impl : kmpc_handle {
       static const int tail = dbg_env("KMPC_PLACE_TAIL") ? atoi(dbg_env("KMPC_PLACE_TAIL")) : 5;  // (measurement aid; 0 = the whole launch)
       r.work_tail = tail;
       // ... across the workgroups too where the batch allows the card deal (whole workgroups; the rank kernel is O(B^2 / lanes))
-      if (place_valid && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= 16384 && !dbg_env("KMPC_ROLLOUT_NO_GLOBAL_PLACE")) r.perm = dPerm;
+      if (place_valid && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= (1 << 20) && !dbg_env("KMPC_ROLLOUT_NO_GLOBAL_PLACE")) r.perm = dPerm;
       // (work and perm were written on the stream of the previous call: a call on another stream waits for them -- a torn perm would
       //  hand one trajectory to two waves and skip another: ADVICE r4)
       if (evPlace && place_stream != s) HIPCHK(hipStreamWaitEvent(s, evPlace, 0));
@@ -1129,9 +1129,9 @@ struct Impl : kmpc_handle {
       ev_used += 3;
       prof_steps += steps;
     }
-    if (r.work && steps >= 4 && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= 16384) {
-      if (!dPerm) HIPCHK(hipMalloc(&dPerm, sizeof(int32_t) * (size_t)B));
-      HIPCHK(launch_place(dWork, B, dPerm, s));  // (the next launch's deal: RolloutArgs::perm)
+    if (r.work && steps >= 4 && cfg.lift_kind == KMPC_LIFT_MLP && (B & 15) == 0 && B <= (1 << 20)) {
+      if (!dPerm) HIPCHK(hipMalloc(&dPerm, sizeof(int32_t) * (size_t)B * 3));  // (perm, then the sort's two ping-pong buffers)
+      HIPCHK(launch_place(dWork, B, dPerm, reinterpret_cast<uint32_t*>(dPerm + B), s));  // (the next launch's deal: RolloutArgs::perm)
       place_valid = true;
     } else {
       place_valid = false;
@@ -1732,6 +1732,13 @@ int kmpc_rollout_plugin_status(const kmpc_handle* h, char* text, int text_bytes)
   const int rc = h->rollout_plugin_status(&t);
   if (text && text_bytes > 0) { snprintf(text, (size_t)text_bytes, "%s", t.c_str()); }
   return rc;
+}
+// The placement pass of the fused roll-out as a function of its own (tests, tools): perm_dev receives, in its first B entries, the
+// slot -> trajectory table of the card deal for the per-trajectory work counters work_dev[B]; it must hold 3 B int32 (the sort's buffers).
+int kmpc_rank_by_work(const int32_t* work_dev, int B, int32_t* perm_dev, void* s) {
+  if (!work_dev || !perm_dev) return -3;
+  const hipError_t e = kmpc::launch_place(work_dev, B, perm_dev, reinterpret_cast<uint32_t*>(perm_dev + B), (hipStream_t)s);
+  return e == hipSuccess ? 0 : -(1000 + (int)e);
 }
 int kmpc_set_rollout_workgroup(int trajectories) {
   if (trajectories != 0 && trajectories != 4 && trajectories != 8 && trajectories != 16) return -1;

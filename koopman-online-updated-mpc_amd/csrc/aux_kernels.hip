@@ -253,11 +253,95 @@ template <typename S, typename D> hipError_t launch_cast(const S* src, D* dst, s
 template hipError_t launch_cast<float, double>(const float*, double*, size_t, hipStream_t);
 template hipError_t launch_cast<double, float>(const double*, float*, size_t, hipStream_t);
 
-// place_kernel: rank of every trajectory by last launch's solver work, then the card deal of RolloutArgs::perm.  Sixteen lanes share
-// the scan of one element (B / 16 comparisons each): 256 workgroups of 256 threads for B = 4096, ~3 us.
-__global__ __launch_bounds__(256) void place_kernel(const int32_t* __restrict__ work, int B, int32_t* __restrict__ perm) {
+// place_kernel: rank of every trajectory by last launch's solver work (descending, ties by index), then the card deal of RolloutArgs::perm.
+// Round 6: a stable least-significant-digit radix sort by ONE workgroup, O(B), for batches beyond 16 384 -- rounds 4-5 compared every pair
+// (O(B^2 / 16): 9 us at B = 4096, 62 us at 16 384) and had NO deal beyond; place_pairs_kernel below still serves B <= 16384.  The key is the work clipped to 12 bits and inverted (heavy first); three passes of four
+// bits over ping-pong buffers of packed (key << 20 | index) words in global memory (L2-resident: B words); the elements start in index
+// order and every pass is stable, so ties stay in index order: the result is a function of `work` alone (deterministic, as before).
+// A pass: every thread counts the digits of its contiguous chunk (16 counters), the 16 x 1024 counts are scanned digit-major in LDS,
+// every thread scatters its chunk in order.
+constexpr int PLACE_T = 1024;
+__global__ __launch_bounds__(PLACE_T) void place_kernel(const int32_t* __restrict__ work, int B, uint32_t* __restrict__ buf0, uint32_t* __restrict__ buf1,
+                                                        int32_t* __restrict__ perm) {
+  __shared__ int sCnt[16 * PLACE_T];   // [digit][thread]
+  __shared__ int sPart[PLACE_T];
+  const int t = threadIdx.x;
+  const int C = (B + PLACE_T - 1) / PLACE_T, e0 = t * C, e1 = e0 + C < B ? e0 + C : B;
+  for (int e = e0; e < e1; ++e) {
+    int w = work[e];
+    w = w < 0 ? 0 : (w > 4095 ? 4095 : w);
+    buf0[e] = ((uint32_t)(4095 - w) << 20) | (uint32_t)e;
+  }
+  __syncthreads();
+  uint32_t* src = buf0;
+  uint32_t* dst = buf1;
+  for (int pass = 0; pass < 3; ++pass) {
+    const int sh = 20 + 4 * pass;
+    int cnt[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) cnt[d] = 0;
+    for (int e = e0; e < e1; ++e) {
+      const int d = (src[e] >> sh) & 15;
+#pragma unroll
+      for (int dd = 0; dd < 16; ++dd) cnt[dd] += (dd == d) ? 1 : 0;  // (no dynamic register index)
+    }
+#pragma unroll
+    for (int d = 0; d < 16; ++d) sCnt[d * PLACE_T + t] = cnt[d];
+    __syncthreads();
+    // exclusive scan of the 16 x 1024 counts in digit-major order: thread t owns entries 16 t .. 16 t + 15 of the flattened array
+    int loc[16], sum = 0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { loc[i] = sum; sum += sCnt[16 * t + i]; }
+    // (1024 partial sums: inclusive scan inside each wave by shuffles, the sixteen wave totals through LDS)
+    int inc = sum;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int v = __shfl_up(inc, off, 64);
+      if ((t & 63) >= off) inc += v;
+    }
+    if ((t & 63) == 63) sPart[t >> 6] = inc;
+    __syncthreads();
+    int wbase = 0;
+    for (int wv2 = 0; wv2 < (t >> 6); ++wv2) wbase += sPart[wv2];
+    const int base = wbase + inc - sum;  // exclusive
+    __syncthreads();  // (sPart is rewritten by the next pass)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sCnt[16 * t + i] = base + loc[i];
+    __syncthreads();
+    int pos[16];
+#pragma unroll
+    for (int d = 0; d < 16; ++d) pos[d] = sCnt[d * PLACE_T + t];
+    for (int e = e0; e < e1; ++e) {
+      const uint32_t v = src[e];
+      const int d = (v >> sh) & 15;
+      int p = 0;
+#pragma unroll
+      for (int dd = 0; dd < 16; ++dd) { if (dd == d) { p = pos[dd]; pos[dd] += 1; } }
+      dst[p] = v;
+    }
+    __threadfence_block();
+    __syncthreads();
+    uint32_t* const tmp = src; src = dst; dst = tmp;
+  }
+  // rank r -> slot of the card deal: stratum p = r / G goes to wave p of the G workgroups, in snake order
+  const int G = B >> 4;
+  for (int r = t; r < B; r += PLACE_T) {
+    const int e = (int)(src[r] & 0xfffffu);
+    const int p = r / G;
+    int g = r - p * G;
+    if (p & 1) g = G - 1 - g;
+    // (stratum p -> wave p: age order.  Measured and dropped: strata 4-7 / 12-15 in reverse order so that the four SIMDs carry equal
+    //  sums -- it undoes the gain: heavy solves on the OLDEST waves is what pays, profiles/r4_cfg2_placement_ab.txt)
+    perm[g * 16 + p] = e;
+  }
+}
+// The same table by comparing every pair (rounds 4-5): sixteen lanes share the scan of one element, B / 16 workgroups of 256 threads with
+// the work panel in LDS (B <= 16384: 64 KB).  O(B^2 / 16), but spread over the whole chip: 8.7 us at B = 4096 and 62 us at 16 384, where
+// the one-workgroup sort takes 28 and 93 us (three passes of global-memory round trips, strided chunk reads, barriers of sixteen waves:
+// ~6 us per 1024 trajectories) -- it serves the batches up to 16 384, the sort everything beyond (where there was no deal at all).
+__global__ __launch_bounds__(256) void place_pairs_kernel(const int32_t* __restrict__ work, int B, int32_t* __restrict__ perm) {
   extern __shared__ int32_t sW[];  // the whole work panel (B <= 16384: 64 KB): the scan reads it 16 times per workgroup
-  for (int c = threadIdx.x; c < B; c += 256) sW[c] = work[c];
+  for (int c = threadIdx.x; c < B; c += 256) { const int w = work[c]; sW[c] = w < 0 ? 0 : (w > 4095 ? 4095 : w); }  // (the sort's key)
   __syncthreads();
   const int e = blockIdx.x * 16 + (threadIdx.x >> 4), part = threadIdx.x & 15;
   const int we = e < B ? sW[e] : 0;
@@ -272,19 +356,23 @@ __global__ __launch_bounds__(256) void place_kernel(const int32_t* __restrict__ 
     const int G = B >> 4, p = r / G;
     int g = r - p * G;
     if (p & 1) g = G - 1 - g;
-    // (stratum p -> wave p: age order.  Measured and dropped: strata 4-7 / 12-15 in reverse order so that the four SIMDs carry equal
-    //  sums -- it undoes the gain: heavy solves on the OLDEST waves is what pays, profiles/r4_cfg2_placement_ab.txt)
     perm[g * 16 + p] = e;
   }
 }
-hipError_t launch_place(const int32_t* work, int B, int32_t* perm, hipStream_t s) {
-  if (B <= 0 || (B & 15)) return hipErrorInvalidValue;
-  static bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&place_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    configured = true;
+// scratch: 2 B words (the sort's buffers).  B a multiple of 16, at most 2^20 trajectories.
+hipError_t launch_place(const int32_t* work, int B, int32_t* perm, uint32_t* scratch, hipStream_t s) {
+  if (B <= 0 || (B & 15) || B > (1 << 20) || !scratch) return hipErrorInvalidValue;
+  if (B <= 16384) {
+    static bool configured_dev[16] = {};  // (function attributes are per device)
+    bool& configured = configured_dev[device_slot()];
+    if (!configured) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&place_pairs_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+      configured = true;
+    }
+    hipLaunchKernelGGL(place_pairs_kernel, dim3(B / 16), dim3(256), (size_t)B * sizeof(int32_t), s, work, B, perm);
+  } else {
+    hipLaunchKernelGGL(place_kernel, dim3(1), dim3(PLACE_T), 0, s, work, B, scratch, scratch + B, perm);
   }
-  hipLaunchKernelGGL(place_kernel, dim3(B / 16), dim3(256), (size_t)B * sizeof(int32_t), s, work, B, perm);
   return hipGetLastError();
 }
 

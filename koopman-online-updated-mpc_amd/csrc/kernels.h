@@ -155,7 +155,8 @@ template <typename T> struct RolloutArgs {
 };
 static constexpr long term_scratch_elems(int L) { return 4L * L * L + 5L * L + 16; }
 // rank every trajectory by its work (descending, ties by index: deterministic) and write the slot -> trajectory table (RolloutArgs::perm)
-hipError_t launch_place(const int32_t* work, int B, int32_t* perm, hipStream_t s);
+// (scratch: 2 B 32-bit words of device memory)
+hipError_t launch_place(const int32_t* work, int B, int32_t* perm, uint32_t* scratch, hipStream_t s);
 
 // K7: Gram sums of one step's transitions (rows [psi_prev; u_prev; psi_now; x_now] against [psi_prev; u_prev])
 template <typename T> struct GramArgs {

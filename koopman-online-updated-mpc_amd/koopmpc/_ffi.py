@@ -54,6 +54,7 @@ SIGNATURES = {
     "kmpc_rollout_plugin_status": (_I, [_VP, C.c_char_p, _I]),
     "kmpc_rollout_plugin_prebuild": (_I, [_I, _I, _I, _I, _I, _I, _I, _I, C.c_char_p, _I]),
     "kmpc_set_rollout_workgroup": (_I, [_I]),
+    "kmpc_rank_by_work": (_I, [_VP, _I, _VP, _VP]),
     "kmpc_reset": (_I, [_VP, _VP]),
     "kmpc_state_init": (_I, [_VP, _D, _D, _VP]),
     "kmpc_state_init_from": (_I, [_VP, _DP, _DP, _DP, _DP, _VP]),
