@@ -30,7 +30,9 @@ The default run (cfg2, one GPU) appends `other_configs`: short legs of cfg4, cfg
 with the same K / W, and beside the headline: `replicas` (the timed window five more times: min / median / max of the
 kernel's fraction), `switch_window_*` (K steps from step 95 of a run that starts at the RLS reset: the plant's
 parameter switch of duffing.py:991-992 lies inside), `cold_start_*` (every QP from clip(0) like the reference) and
-`post_reset_*` (the same K steps right after the reset).  `cpu_baseline` times the NumPy oracle run the way the reference runs (per-trajectory Python
+`post_reset_*` (the same K steps right after the reset).  With N > 1 ranks the default run appends `roofline.multi_rank.cfg4`: a short leg of the
+shared-model configuration -- the only one with a collective on its step path -- on all ranks, behind the headline, on a watched thread.
+`cpu_baseline` times the NumPy oracle run the way the reference runs (per-trajectory Python
 loop, SciPy L-BFGS-B on the shooting cost, duffing.py:857-859) on a bounded sample of the same workload IN
 THE SAME REGIME (the settle steps after the reset are set-up, the steps after them are timed): one worker
 process per host core the process may use (affinity mask, capped by the cgroup quota; the count is in the line), forked before
@@ -883,19 +885,63 @@ def main():
             a32.dtype = "f32"
             leg("cfg2", a32, "cfg2-f32")
 
+    # ---- N > 1: the ONE configuration with a collective on its step path (cfg4: the all-reduced Gram block inside kmpc_shared_rollout),
+    # as a short leg BEHIND the headline of the driver's scaling run -- the pool's boxes have one GPU, so this is the only place where
+    # the multi-rank RCCL path can run on hardware (VERDICT r5 missing #1, weak #13; DESIGN 6 holds the prediction it is read against).
+    # Everything that touches a multi-rank communicator after the headline's measurement runs on a watched thread: if it does not come
+    # back in time, the line is printed with the reason and the process leaves without the collective teardown.
+    def watched(fn, seconds, what):
+        import threading
+
+        box = {}
+
+        def body():
+            try:
+                torch.cuda.set_device(dev)  # (the current device is per thread)
+                box["value"] = fn()
+            except Exception as e:
+                box["error"] = "%s: %s" % (type(e).__name__, e)
+
+        th = threading.Thread(target=body, daemon=True)
+        th.start()
+        th.join(seconds)
+        if th.is_alive():
+            return None, "%s did not return within %g s" % (what, seconds), True
+        return box.get("value"), box.get("error"), False
+
+    hung = False
+    multi_rank = None
+    if dist is not None and world > 1 and name == "cfg2" and not args.no_extras and not (args.batch or args.L or args.N or args.cold_start):
+        import copy
+
+        oc = CONFIGS["cfg4"]
+        a4 = copy.copy(args)
+        a4.dtype = "f64"
+        o, err, hung = watched(lambda: measure_config("cfg4", a4, dist, dev, rank, world, oc["L"], oc["N"], oc["B"], oc["settle"], extras=False,
+                                                      spin_seconds=0.3, probe=False),
+                               float(os.environ.get("KMPC_BENCH_MULTI_RANK_LEG_SECONDS", "300")), "the cfg4 leg on %d ranks" % world)
+        if err is not None:
+            multi_rank = {"cfg4": {"error": err}}
+        else:
+            multi_rank = {"cfg4": {"value": o["value"], "unit": "steps/s", "n_gpus": world, "ms_per_step": o["ms_per_step"], "trajectories_per_gpu": oc["B"],
+                                   "worst_qp_status": o["worst_status"], "finite": o["x_ok"],
+                                   "collective": "all-reduce of the %d x %d Gram block inside kmpc_shared_rollout, once per step (%s)"
+                                                 % (2 * oc["L"] + 3, oc["L"] + 1, "RCCL, enqueued from C++" if args.backend == "nccl" else "gloo rehearsal: host-side sum")}}
+
     # how many ranks RCCL itself reports (ncclCommCount of this process's communicator -- the one the shared-model loop all-reduces
     # on; a per-trajectory configuration creates one here, after the measurement, only to be able to say so): lets SCALE be checked
     rccl_ranks_seen = None
-    if dist is not None and args.backend == "nccl":
+    if dist is not None and args.backend == "nccl" and not hung:
         from koopmpc.sharding import process_communicator
 
-        try:
-            rccl_ranks_seen = process_communicator(dev).count()
-        except Exception as e:  # (reported in the line; the measurement above stands)
-            rccl_ranks_seen = "%s: %s" % (type(e).__name__, e)
+        rccl_ranks_seen, err, hung = watched(lambda: process_communicator(dev).count(), 120.0, "ncclCommInitRank / ncclCommCount")
+        if err is not None:  # (reported in the line; the measurement above stands)
+            rccl_ranks_seen = err
     if rank == 0:
         total = B * world
         roof = res["roofline"]
+        if multi_rank:
+            roof["multi_rank"] = multi_rank
         if others:
             roof["other_configs"] = others
             roof["other_configs_fields"] = "steps/s, frac, bound, kernel_ms, steps_per_launch, worst_qp_status, finite, parity_probe, executed_flop_frac"
@@ -958,6 +1004,10 @@ def main():
     if dist is not None:
         from koopmpc.sharding import destroy_process_communicator
 
+        if hung:  # (a rank is still inside a collective that will not end: no barrier, no communicator teardown)
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
         dist.barrier()
         destroy_process_communicator()
         dist.destroy_process_group()
