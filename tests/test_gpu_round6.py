@@ -687,3 +687,49 @@ def test_rank_by_work_is_a_stable_descending_sort(torch_mod, B):
     key = np.clip(w, 0, 4095)
     want = np.argsort(-key.astype(np.int64), kind="stable")
     assert np.array_equal(order, want)
+
+
+def test_round6_entry_points_refuse_bad_arguments(torch_mod, KM):
+    """The entry points added in round 6 answer bad arguments with an error code (never a launch): the placement pass with a batch that is
+    no multiple of 16 / above 2^20 / null buffers, the terminal refresh with a negative period, no Q, no iterations or on a float32
+    handle, the plug-in pre-build with dimensions outside the single-wave kernels, and the status query with a tiny text buffer."""
+    torch = torch_mod
+    import ctypes as C
+
+    from koopmpc import _ffi
+
+    lib = _ffi.load()
+    w = torch.zeros(64, dtype=torch.int32, device="cuda:0")
+    perm = torch.zeros(3 * 64, dtype=torch.int32, device="cuda:0")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.kmpc_rank_by_work(C.c_void_p(w.data_ptr()), 24, C.c_void_p(perm.data_ptr()), s) != 0
+    assert lib.kmpc_rank_by_work(C.c_void_p(w.data_ptr()), 0, C.c_void_p(perm.data_ptr()), s) != 0
+    assert lib.kmpc_rank_by_work(C.c_void_p(w.data_ptr()), (1 << 20) + 16, C.c_void_p(perm.data_ptr()), s) != 0
+    assert lib.kmpc_rank_by_work(None, 64, C.c_void_p(perm.data_ptr()), s) != 0
+    assert lib.kmpc_rank_by_work(C.c_void_p(w.data_ptr()), 64, None, s) != 0
+    torch.cuda.synchronize()
+
+    from koopmpc.synth import random_mlp_weights
+
+    wts = random_mlp_weights(2, 16, 2, 8, seed=3)
+    m = KM(n=2, L=8, N=10, batch=16, weights=wts, hidden=16, layers=2)
+    Q = np.ascontiguousarray(10.0 * np.eye(8))
+    qp = Q.ctypes.data_as(C.POINTER(C.c_double))
+    assert lib.kmpc_set_terminal_refresh(m.h, -1, qp, 0.01, 500, 0.01) != 0
+    assert lib.kmpc_set_terminal_refresh(m.h, 1, None, 0.01, 500, 0.01) != 0
+    assert lib.kmpc_set_terminal_refresh(m.h, 1, qp, 0.01, 0, 0.01) != 0
+    assert lib.kmpc_set_terminal_refresh(m.h, 0, None, 0.01, 0, 0.01) == 0      # switching it off needs nothing
+    with pytest.raises(ValueError):
+        m.set_terminal_refresh(every=1, Q=np.eye(7))
+    m32 = KM(n=2, L=8, N=10, batch=16, weights=wts, hidden=16, layers=2, dtype=torch.float32)
+    assert lib.kmpc_set_terminal_refresh(m32.h, 1, qp, 0.01, 500, 0.01) != 0
+
+    buf = C.create_string_buffer(256)
+    for bad in [(3, 8, 10, 0, 0, 16, 64, 1), (2, 0, 10, 0, 0, 16, 64, 1), (2, 8, 0, 0, 0, 16, 64, 1), (2, 8, 10, 0, 0, 0, 64, 1),
+                (2, 8, 10, 0, 0, 200, 64, 1), (2, 8, 10, 0, 0, 16, 0, 1), (2, 8, 10, 0, 0, 16, 64, 7)]:
+        assert lib.kmpc_rollout_plugin_prebuild(*bad, buf, 256) == -3, bad
+    assert lib.kmpc_rollout_plugin_prebuild(2, 80, 10, 0, 0, 16, 64, 1, buf, 256) == 2   # (81^2 > 2048: no single-wave kernel, not an error)
+    tiny = C.create_string_buffer(4)
+    code = lib.kmpc_rollout_plugin_status(m.h, tiny, 4)
+    assert code in (0, 1, 2, -1) and len(tiny.value) <= 3
+    assert lib.kmpc_rollout_plugin_status(None, buf, 256) == -100
