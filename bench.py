@@ -919,7 +919,7 @@ def main():
         a4.dtype = "f64"
         o, err, hung = watched(lambda: measure_config("cfg4", a4, dist, dev, rank, world, oc["L"], oc["N"], oc["B"], oc["settle"], extras=False,
                                                       spin_seconds=0.3, probe=False),
-                               float(os.environ.get("KMPC_BENCH_MULTI_RANK_LEG_SECONDS", "300")), "the cfg4 leg on %d ranks" % world)
+                               float(os.environ.get("KMPC_BENCH_MULTI_RANK_LEG_SECONDS", "180")), "the cfg4 leg on %d ranks" % world)
         if err is not None:
             multi_rank = {"cfg4": {"error": err}}
         else:
@@ -934,7 +934,7 @@ def main():
     if dist is not None and args.backend == "nccl" and not hung:
         from koopmpc.sharding import process_communicator
 
-        rccl_ranks_seen, err, hung = watched(lambda: process_communicator(dev).count(), 120.0, "ncclCommInitRank / ncclCommCount")
+        rccl_ranks_seen, err, hung = watched(lambda: process_communicator(dev).count(), 60.0, "ncclCommInitRank / ncclCommCount")
         if err is not None:  # (reported in the line; the measurement above stands)
             rccl_ranks_seen = err
     if rank == 0:
