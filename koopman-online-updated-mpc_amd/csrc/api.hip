@@ -317,7 +317,7 @@ struct Impl : kmpc_handle {
                       (void*)dbo, (void*)dcx, (void*)dTmp, (void*)dU0, (void*)dGram, (void*)dPartial, (void*)dKs, (void*)dCs,
                       (void*)dHs, (void*)dFs, (void*)df0s, (void*)dWt, (void*)dWhp[0], (void*)dWhp[1], (void*)dWop,
                       (void*)dDareP, (void*)dDareIt, (void*)dWtB, (void*)dQpScr, (void*)dMsK, (void*)dMsC, (void*)dMsH,
-                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet, (void*)dDelta, (void*)dQpList, (void*)dWork, (void*)dPerm, (void*)dTermQ, (void*)dTermScr, (void*)dEyeL})
+                      (void*)dMsf, (void*)dMsc, (void*)dMsW, (void*)dTs, (void*)dNeed, (void*)dImg, (void*)dQpCarry, (void*)dQpCarrySet, (void*)dDelta, (void*)dQpList, (void*)dWork, (void*)dPerm, (void*)dTermQ, (void*)dTermScr, (void*)dEyeL, (void*)dFastPack})
       if (ptr) (void)hipFree(ptr);
     for (auto e : ev) (void)hipEventDestroy(e);
     if (evPlace) (void)hipEventDestroy(evPlace);
@@ -1201,6 +1201,8 @@ struct Impl : kmpc_handle {
   // ---- shared-model mode -----------------------------------------------------------------------------
   double *dGram = nullptr, *dPartial = nullptr;
   T *dKs = nullptr, *dCs = nullptr, *dHs = nullptr, *dFs = nullptr, *df0s = nullptr, *dTs = nullptr;
+  double* dFastPack = nullptr;   // F, T0, H of the shared model as shared_fast_kernel's operand fragments (SharedModel2Args::pack)
+  bool fast_pack_valid = false;  // ... written by the last model launch
   int32_t* dNeed = nullptr;  // [B] flags of shared_fast_kernel
   int32_t* dWork = nullptr;  // [B] solver work of every trajectory in the last fused launch (RolloutArgs::work)
   int32_t* dPerm = nullptr;  // [B] slot -> trajectory for the next fused launch (RolloutArgs::perm); valid after a launch that wrote dWork
@@ -1352,11 +1354,23 @@ struct Impl : kmpc_handle {
           m.Qw = cfg.Qw; m.Rw = cfg.Rw;
           m.Kio = (double*)dKs; m.Cio = (double*)dCs; m.Hout = (double*)dHs; m.Fout = (double*)dFs; m.f0out = (double*)df0s; m.Tout = (double*)dTs;
           m.Wt = (const double*)wt; m.du_mode = cfg.delta_u ? 1 : 0; m.cy0 = cy0;
+          // (F, T0, H once more as the operand fragments of shared_fast_kernel: written by the model kernel beside the dense blocks)
+          int fmt = 0, fk1 = 0, fk2 = 0;
+          if (N <= 64 && shared_fast_shape(N, L + (cfg.delta_u ? 1 : 0), &fmt, &fk1, &fk2)) {
+            if (!dFastPack) {
+              const size_t bytes = sizeof(double) * shared_fast_pack_elems(fmt, fk1, fk2);
+              HIPCHK(hipMalloc(&dFastPack, bytes));
+              HIPCHK(hipMemsetAsync(dFastPack, 0, bytes, s));  // (the padding of the fragments stays zero: only elements of the matrices are written)
+            }
+            m.pack = dFastPack; m.pack_mt = fmt; m.pack_ks1 = fk1; m.pack_ks2 = fk2;
+          }
           HIPCHK(launch_shared_model2(m, s));
           on16 = true;
+          fast_pack_valid = m.pack != nullptr;
         }
       }
       if (!on16) {
+        fast_pack_valid = false;
         HIPCHK(launch_shared_model<T>(dGram, have_prev ? delta : nullptr, cfg.lambda, (const T*)ref, L, n, q, N, 1.0 / cfg.P0, 1.0 / cfg.barQ0, 1, have_prev ? 1 : 0, cfg.Qw,
                                       cfg.Rw, dKs, dCs, dHs, dFs, df0s, dTs, wt, cfg.delta_u ? 1 : 0, cy0, s));
       }
@@ -1374,6 +1388,7 @@ struct Impl : kmpc_handle {
     a.phases = PH_QP;
     a.H_in = dHs; a.h_shared = 1; a.F_in = dFs; a.f0_in = df0s;
     a.T_in = one_launch ? dTs : nullptr;
+    a.fast_pack = (one_launch && fast_pack_valid) ? dFastPack : nullptr;
     a.psi_now = dPsi[cur]; a.pn_sl = 1; a.pn_sb = L;
     a.U0 = (T*)U0; a.Useq = (T*)Useq; a.u_store = dUprev; a.status = st; a.iters = it;
     a.x_warm = cfg.cold_start ? nullptr : dWarm;

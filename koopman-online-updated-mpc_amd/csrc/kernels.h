@@ -60,6 +60,7 @@ struct StepArgs {
   int h_shared;                  // H_in is ONE matrix for the whole batch (shared-model mode)
   const T* T_in;                 // shared-model mode: -(2 H_in)^-1 (N x N), the swept tableau of the free set "all inputs"; or null
   const T* F_in; const T* f0_in; // shared-model mode: f_b = F psi_b + f0 (F: N x L), psi from psi_now
+  const double* fast_pack;       // ... and F, T0, H as shared_fast_kernel's operand fragments (SharedModel2Args::pack), or null
   const int32_t* qp_need;        // shared-model mode: [B] flags written by shared_fast_kernel -- 0: that kernel has already written this
                                  // trajectory's result (its unconstrained minimiser lies inside the box), the solve-only kernel skips it
   // ... and the flagged trajectories as a list (round 4): shared_fast_kernel appends them to qp_list with one atomic per trajectory
@@ -267,7 +268,13 @@ struct SharedModel2Args {
   double dP, dQ; int have_samples; double Qw, Rw;
   double *Kio, *Cio, *Hout, *Fout, *f0out, *Tout;
   const double* Wt; int du_mode, cy0;
+  // F, T0 and H once more as the MFMA A-fragments shared_fast_kernel reads (shared_fast_shape / shared_fast_pack_elems; zero-padded:
+  // the buffer is cleared when it is allocated and only elements inside the matrices are ever written); null: not written
+  double* pack; int pack_mt, pack_ks1, pack_ks2;
 };
+// shape of shared_fast_kernel's instantiation for (N, Lf = L + du_mode): row tiles, k-steps of F's and of T0's / H's inner dimension
+bool shared_fast_shape(int N, int Lf, int* MT, int* KS1, int* KS2);
+inline size_t shared_fast_pack_elems(int MT, int KS1, int KS2) { return (size_t)(KS1 + 2 * KS2) * MT * 64; }
 bool shared_model2_available(int Lm, int n, int q, int N, int du_mode);
 hipError_t launch_shared_model2(const SharedModel2Args& a, hipStream_t s);
 template <typename T> hipError_t launch_broadcast(T* dst, long stride, const T* src, int count, int B, hipStream_t s);
