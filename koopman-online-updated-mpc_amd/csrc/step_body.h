@@ -978,6 +978,7 @@ __device__ __forceinline__ bool qp_regs256(const T* sH, const T* sf, const StepA
   T J0 = block_sum<T, 256, true>(own ? x * (hx + fi) : T(0), red);
   unsigned long long Smask = Smask0;
   int it = 0, status = 1, refresh = 0, polish = 0, nsw = 0, rtot = 0, nref = 0;
+  (void)nref;  // (read by the trace build only)
   bool rebuild = false;
   bool nopredict = false;
   KTRACE(8);
