@@ -480,17 +480,22 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
         torch.cuda.synchronize(dev)
 
     def timed(loop, steps, step0, profile=False):
-        """barrier + synchronize | steps | synchronize + barrier; MAX over ranks"""
+        """barrier + synchronize | steps | synchronize + barrier + synchronize; MAX over ranks.  With more than one rank the region holds
+        the trailing barrier (a small all-reduce: tens of microseconds against a K = 20 window of 0.6 ms): timed.own is the MAX over
+        ranks of each rank's time up to its OWN synchronize behind the K steps, reported beside the contract's figure."""
         sync_all()
         if profile:
             loop.m.profile(True)
         t0 = time.perf_counter()
         loop.advance(steps, step0)
         torch.cuda.synchronize(dev)
+        t_own = time.perf_counter() - t0
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize(dev)
-        return max_over_ranks(time.perf_counter() - t0, device=dev)
+        dt_all = max_over_ranks(time.perf_counter() - t0, device=dev)
+        timed.own = max_over_ranks(t_own, device=dev) if dist is not None else t_own
+        return dt_all
 
     def spin(loop, seconds, steps, step0, snap):
         """bring the GPU out of its idle power state with the timed region's own launches on a scratch controller"""
@@ -534,6 +539,7 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
                 scratch.advance(settle + args.warmup, 0)
             spin(scratch, spin_seconds, args.steps, step0, snap)
     dt = timed(main_loop, args.steps, step0, profile=True)
+    dt_own = timed.own
     pr = main_loop.m.profile_read()
     main_loop.m.profile(False)
     mpc = main_loop.m
@@ -751,7 +757,7 @@ def measure_config(name, args, dist, dev, rank, world, L, N, B, settle, extras=T
             except Exception as e:  # (the check must not take the measurement with it; it is reported)
                 pp = {"error": "%s: %s" % (type(e).__name__, e)}
             roof["parity_probe_max_abs_u_err"] = pp.get("max_abs_u_err")
-    return {"dt": dt, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "roofline": roof, "extras": ex,
+    return {"dt": dt, "dt_own": dt_own, "value": B * world * args.steps / dt, "ms_per_step": dt / args.steps * 1e3, "roofline": roof, "extras": ex,
             "worst_status": worst_status, "x_ok": x_ok, "newton_per_step": newton_per_step, "newton_max": newton_max,
             "shared": main_loop.shared, "q": mpc.q, "text": c["text"], "parity_probe": pp}
 
@@ -963,7 +969,12 @@ def main():
                             "warm-up are set-up; arithmetic in %s" % (B, world, settle, args.dtype),
                 "global_batch": total,
                 "process_group": {"world_size": pg_world, "backend": pg_backend, "ranks_share_device": bool(args.same_device),
-                                  "rccl_ranks_seen": rccl_ranks_seen},
+                                  "rccl_ranks_seen": rccl_ranks_seen,
+                                  # `value` / `ms_per_step` follow the contract: the clock stops behind the trailing barrier + synchronize.
+                                  # What the ranks themselves took -- MAX over ranks of the time to each rank's own synchronize behind
+                                  # the K steps, the trailing barrier (a small all-reduce) not billed -- is reported beside it
+                                  **({"ms_per_step_rank_max_without_trailing_barrier": res["dt_own"] / args.steps * 1e3,
+                                      "value_without_trailing_barrier": B * world * args.steps / res["dt_own"]} if world > 1 else {})},
                 **({"rehearsal": "ranks share cuda:0 / gloo collectives: exercises the multi-rank code path, NOT a scaling measurement"}
                    if (args.same_device or (world > 1 and args.backend != "nccl")) else {}),
                 "parallelism": ("trajectory-sharded x%d, one RCCL all-reduce of the %d-element Gram block per step" % (world, (2 * L + 3) * (L + 1))) if res["shared"]
