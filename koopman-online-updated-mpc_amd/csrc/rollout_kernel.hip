@@ -107,6 +107,111 @@ template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads(
   constexpr size_t waves = (KS_ >= 0 && N_ > 24 && fit > 8 && !ro_one_region<L_, N_, Q_, KS_>()) ? 8 : fit;
   return waves > 8 ? 1024 : (waves > 4 ? 512 : 256);  // 4 / 2 / 1 waves per SIMD
 }
+// Which dimension sets call the encoder as a function (ro_encoder_tiles) and which keep it inline.  Measured (old / new library on one box,
+// bench.py --config cfg2 --L .. --N .., K = 20, kernel ms): (20, 30) 1.515 -> 1.225 (84 -> 19 spilled registers), (8, 30) 2.24 -> 2.19,
+// (20, 20) 0.618 -> 0.611 (15 -> 2; 6.35 -> 6.26 at K = 200) -- but (8, 10) 0.495 -> 0.737: with a horizon of ten the step keeps its
+// state in registers from step to step, and across a call those have to be saved.  Hence: inline for N < 16.
+template <int L_, int N_, int Q_> constexpr bool ro_encoder_call() { return N_ >= 16; }
+// The tile waves' part of the cooperative encoder -- layer 1, then every further layer as tile = wave over the full K range, the A-fragments in
+// two alternating batches of 8 k-steps (the first batch of a layer is requested a layer ahead and travels across the barrier, every further
+// batch while the previous one is being multiplied) -- as a FUNCTION OF ITS OWN (round 6): inlined, the encoder's 72 registers were part of
+// the kernel's register allocation problem and the kernel spilled 15 vector registers (60 bytes of scratch per lane) around the box QP; as a
+// call the kernel spills 2, the function needs no stack at all (it lives in the call-clobbered registers; the 6 - 15 values the kernel keeps
+// across the lift sit in the preserved ones), and the window is 1.5 - 2.5 % shorter at K = 20, 3.5 - 4 % at K = 200
+// (profiles/r6_cfg2_lift_ksplit.txt).  The arguments arrive in vector registers: the wave-uniform ones go back to scalar registers, the
+// pointers to their address spaces (generic pointers are flat loads, which wait for both counters).
+template <int KS_, int NW>
+__device__ __attribute__((noinline)) void ro_encoder_tiles(const int wv_, const int lane, const int b0_, const int KSr_, const bool hid_, const bool out_, const int nhh_,
+                                                        const double* W1_, const double* b1_, const double* Wh0_, const double* Wh1_, const double* Wo_,
+                                                        const double* bh0_, const double* bh1_, const double* bo_, const double* sXn_, double* sAct0_,
+                                                        double* sAct1_, double* sPsi_) {
+  typedef double d4_t __attribute__((ext_vector_type(4)));
+  typedef const double __attribute__((address_space(1))) * gp_t;
+  typedef double __attribute__((address_space(3))) * lp_t;
+  auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+  auto unip = [&](const double* q) {
+    const unsigned long long a = (unsigned long long)q;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32));
+    return (gp_t)(((unsigned long long)hi << 32) | lo);
+  };
+  const int wv = uni(wv_), KSr = uni(KSr_), nhh = uni(nhh_), b0 = uni(b0_);
+  (void)b0;  // (the stamps of the trace build)
+  const bool hid = uni(hid_ ? 1 : 0) != 0, out = uni(out_ ? 1 : 0) != 0;
+  const gp_t W1 = unip(W1_), b1 = unip(b1_), Wh0 = unip(Wh0_), Wh1 = unip(Wh1_), Wo = unip(Wo_), bh0 = unip(bh0_), bh1 = unip(bh1_), bo = unip(bo_);
+  const lp_t sXn = (lp_t)sXn_, sAct0 = (lp_t)sAct0_, sAct1 = (lp_t)sAct1_, sPsi = (lp_t)sPsi_;
+  // B-fragment layout of an activation set: [k-step][4 k x 16 columns]; eight-trajectory workgroups store eight columns
+  // ([k-step][4 k x 8]) and the lanes of columns 8-15 read columns 0-7 again (their outputs are never stored)
+  constexpr int AR = NW == 8 ? 32 : 64;
+  const int bl = NW == 8 ? ((lane >> 4) << 3) + (lane & 7) : lane;
+  const int KS = KS_ > 0 ? KS_ : KSr;
+  double af[2][RO_KB2];
+  auto loadf = [&](gp_t Wp_, int ks0, double (&dst)[RO_KB2]) {
+#pragma unroll
+    for (int i = 0; i < RO_KB2; ++i) dst[i] = ks0 + i < KS ? Wp_[((size_t)wv * KS + ks0 + i) * 64 + lane] : 0.0;
+  };
+  if (nhh > 0) { if (hid) loadf(Wh0, 0, af[0]); }
+  else if (out) loadf(Wo, 0, af[0]);
+  double a1 = 0.0;
+  d4_t c1 = {0.0, 0.0, 0.0, 0.0};
+  if (hid) {
+    a1 = W1[4 * (16 * wv + (lane & 15)) + (lane >> 4)];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) c1[r] = b1[16 * wv + (lane >> 4) + 4 * r];
+  }
+  __syncthreads();  // every wave is done with its LDS region (previous step); x_{k} of all trajectories is in sXn
+  LSTAMP(0);
+  if (hid) {
+    c1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, sXn[4 * (lane & 15) + (lane >> 4)], c1, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * wv + (lane >> 4) + 4 * r;
+      if (NW != 8 || (lane & 15) < 8) sAct0[(row >> 2) * AR + (row & 3) * (AR / 4) + (lane & 15)] = c1[r] > 0.0 ? c1[r] : 0.0;
+    }
+  }
+  LSTAMP(1);
+  __syncthreads();
+  LSTAMP(2);
+  // ---- hidden -> hidden layers, then the output layer, all as: tile = wave, full K
+  for (int h = 0; h <= nhh; ++h) {
+    const bool last = h == nhh;
+    const bool mine = last ? out : hid;
+    const lp_t act = (h & 1) ? sAct1 : sAct0;
+    const lp_t actn = (h & 1) ? sAct0 : sAct1;
+    const gp_t Wp = last ? Wo : ((h & 1) ? Wh1 : Wh0);
+    const gp_t bias = last ? bo : ((h & 1) ? bh1 : bh0);
+    d4_t acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    if (mine) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc0[r] = bias[16 * wv + (lane >> 4) + 4 * r];
+#pragma unroll
+      for (int bt = 0; bt < 32 / RO_KB2; ++bt) {
+        const int kb = bt * RO_KB2;
+        if (kb + RO_KB2 < KS) loadf(Wp, kb + RO_KB2, af[(bt + 1) & 1]);
+#pragma unroll
+        for (int i = 0; i < RO_KB2; i += 2) {
+          if (kb + i < KS) acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i], act[(kb + i) * AR + bl], acc0, 0, 0, 0);
+          if (kb + i + 1 < KS) acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(af[bt & 1][i + 1], act[(kb + i + 1) * AR + bl], acc1, 0, 0, 0);
+        }
+      }
+      const int col = lane & 15;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wv + (lane >> 4) + 4 * r;
+        const double v = acc0[r] + acc1[r];
+        if (last) sPsi[row * 16 + col] = v;
+        else if (NW != 8 || col < 8) actn[(row >> 2) * AR + (row & 3) * (AR / 4) + col] = v > 0.0 ? v : 0.0;
+      }
+    }
+    // the next layer's first fragments travel across the barrier
+    if (!last) {
+      if (h + 1 < nhh) { if (hid) loadf(((h + 1) & 1) ? Wh1 : Wh0, 0, af[0]); }
+      else if (out) loadf(Wo, 0, af[0]);
+    }
+    LSTAMP(3 + 2 * h);
+    __syncthreads();  // (after the last layer: psi is outside the overlay, the waves go their own way)
+    LSTAMP(4 + 2 * h);
+  }
+}
 // IOT: element type of the caller-owned panels (X, ref, U0, Useq, U_log, X_log): double, or float for the float32-I/O roll-out of a
 // KMPC_F32 handle (row g2; register-state dimension sets only) -- the state, the handle's own vectors and all arithmetic stay float64,
 // and x_{k+1} is carried from step to step in LDS in float64: only what crosses the boundary is rounded (step_body.h io_ld / io_st)
@@ -317,10 +422,6 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
       // waves only take part in the barriers.
       const int KS = KS_ > 0 ? KS_ : R.KS, Hp = KS_ > 0 ? (KS_ <= 28 ? 112 : 128) : R.Hp, MTH = Hp >> 4, MTO = R.Lp >> 4;
       const bool hid = wv < MTH, out = wv < MTO;
-      // B-fragment layout of an activation set: [k-step][4 k x 16 columns]; eight-trajectory workgroups store eight columns
-      // ([k-step][4 k x 8]) and the lanes of columns 8-15 read columns 0-7 again (their outputs are never stored)
-      constexpr int AR = NW == 8 ? 32 : 64;
-      const int bl = NW == 8 ? ((lane >> 4) << 3) + (lane & 7) : lane;
       if (V2 && !hid && !out) {
         // A wave without a tile of the encoder only takes part in its barriers (2 + layers of them).  Register-state step: it
         // does the covariance half of its trajectory's RLS update meanwhile -- inv_K_G, bar_Q only need [psi(x_{k-1}); u_{k-1}]
@@ -343,7 +444,13 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
           }
         }
         for (int i = 0; i < R.nhh; ++i) __syncthreads();
+      } else if constexpr (ro_encoder_call<L_, N_, Q_>()) {
+        // the tile waves: the products of all layers (ro_encoder_tiles, a function of its own)
+        ro_encoder_tiles<KS_, NW>(wv, lane, b0, KS, hid, out, R.nhh, R.W1, R.b1, R.Whp[0], R.Whp[1], R.Wop, R.bh[0], R.bh[1], R.bo, sXn, sAct0, sAct1, sPsi);
       } else {
+      // (the same products inline -- the short-horizon sets, see ro_encoder_call)
+      constexpr int AR = NW == 8 ? 32 : 64;
+      const int bl = NW == 8 ? ((lane >> 4) << 3) + (lane & 7) : lane;
       // A-fragments in two alternating batches of 8 k-steps: the first batch of a layer is requested a layer ahead
       // (it travels across the barrier), every further batch while the previous one is being multiplied
       double af[2][RO_KB2];
