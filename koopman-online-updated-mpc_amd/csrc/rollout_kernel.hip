@@ -89,6 +89,8 @@ template <int L_, int N_, int Q_, int KS_> constexpr bool ro_one_region() { retu
 static bool ro_one_region_rt(int L, int N, int q, bool) { return N > 24 && q != L && q > 0; }
 // dimension sets whose step keeps the state in registers (step_v2.h): their roll-out reads and writes the handle's wave image
 template <int L_, int N_, int Q_> constexpr bool ro_v2() { return step_v2_dims(L_, N_, Q_); }
+// RBF sets whose step does not fit 128 registers by far (the (32, 40) sets: 758 spilled with sixteen waves per CU): eight waves, 256 registers
+static constexpr bool ro_rbf_eight(int L, int N, int q) { return !step_v2_dims(L, N, q) && L >= 24 && N > 32; }
 template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads() {
   if constexpr (ro_v2<L_, N_, Q_>()) {  // (LDS per trajectory <= 10 KB: sixteen trajectories per CU, 128 registers)
     constexpr size_t pw2 = v2_lds_elems(L_, Q_, N_), cap2 = 160 * 1024 / sizeof(double), wgs2 = cap2 / (pw2 * NW);
@@ -99,6 +101,13 @@ template <int L_, int N_, int Q_, int NW, int KS_> constexpr int ro_max_threads(
                             ? (((size_t)step_region1(L_, N_) + (2 * L_ <= N_ * Q_ ? 0 : ((2 * L_ + 1) & ~1)) + vec_elems_one_region(2, L_, Q_, N_) + 1) & ~(size_t)1)
                             : ((step_lds_elems(2, L_, Q_, N_, step_tableau_in_lds<64, N_, L_>()) + 1) & ~(size_t)1);
   constexpr size_t cap = 160 * 1024 / sizeof(double);
+  if constexpr (KS_ < 0) {
+    // RBF lift: the waves of a workgroup never meet and rollout_waves launches as many as the LDS holds (NW is a placeholder here): the
+    // register budget follows THAT number.  (Until late in round 6 the placeholder's sixteen set it: the (32, 40) sets, four waves per
+    // CU, were compiled for 128 registers -- 758 of them spilled -- while three quarters of the register file stood empty.)
+    constexpr size_t wf = cap / pw, wr0 = wf > 16 ? 16 : (wf < 4 ? 4 : wf), wr = (ro_rbf_eight(L_, N_, Q_) && wr0 > 8) ? 8 : wr0;
+    return wr > 8 ? 1024 : (wr > 4 ? 512 : 256);
+  }
   constexpr size_t wgs = cap / (pw * NW);
   constexpr size_t fit = wgs * NW > 16 ? 16 : (wgs * NW < (size_t)NW ? (size_t)NW : wgs * NW);
   // long horizons with the MLP lift: at most 8 trajectories per CU, 256 registers each (the N = 30 solver keeps H and
@@ -704,7 +713,7 @@ static int rollout_waves(int n, int L, int q, int N, bool rbf, int Lp, int B = 1
     if (best == 16 && wgs(8) * 8 >= 16 && (B + 15) / 16 < cus) return 8;
     return best;
   }
-  for (int w = 16; w >= 4; --w)  // (RBF lift: the waves of a workgroup never meet, any number of them will do)
+  for (int w = ro_rbf_eight(L, N, q) ? 8 : 16; w >= 4; --w)  // (RBF lift: the waves of a workgroup never meet, any number of them will do)
     if (rollout_lds_elems(n, L, q, N, true, w, Lp, nullptr) <= cap) return w;
   return 0;
 }
