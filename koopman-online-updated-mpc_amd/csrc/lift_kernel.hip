@@ -392,6 +392,12 @@ template <typename T> __global__ __launch_bounds__(256) void lift_rbf_kernel(con
     for (int i = 0; i < 4; ++i) x[i] = (i < n) ? a.X[(size_t)i * B + b] : T(0);
     for (int j = 0; j < L; ++j) {
       T v;
+      if constexpr (std::is_same<T, double>::value) {
+        if (n == 2) {  // (the fused roll-out's function: bit for bit its observables)
+          a.Psi[(size_t)j * a.ps_l + (size_t)b * a.ps_b] = kmpc_rbf_psi2(x[0], x[1], scx[j * 2], scx[j * 2 + 1], a.eps, a.rbf_matlab);
+          continue;
+        }
+      }
       if (a.rbf_matlab) {
         T r2 = T(0);
         for (int i = 0; i < n; ++i) {

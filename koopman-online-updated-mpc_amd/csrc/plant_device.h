@@ -85,5 +85,26 @@ template <typename T> __device__ __forceinline__ T kmpc_logT(T x);
 //  trajectory whose state is not finite ends as status 2 there whichever non-finite value its lift carries.)
 template <> __device__ __forceinline__ double kmpc_logT<double>(double x) { return x < __builtin_inf() ? kmpc_log(x) : x; }
 template <> __device__ __forceinline__ float kmpc_logT<float>(float x) { return logf(x); }
+// One thin-plate observable of a TWO-state plant in float64 (vanderpol_RBF.py:20-23: sklearn's euclidean distance, d^2 log(d + eps);
+// rbf.m:24-29: r2 log(sqrt(r2)), NaN -> 0) as a FUNCTION OF ITS OWN, shared by the stand-alone lift and the fused roll-out: the
+// logarithm's coefficients and its division are not the step loop's registers or code (cfg3: kernel 1.479 -> 1.435 ms), and both
+// callers run the SAME machine code -- inlined, the two contexts contracted the sums differently in the last bit, which a saturated
+// lifted-output controller turns into a flipped input.
+static __device__ __attribute__((noinline)) double kmpc_rbf_psi2(double x0, double x1, double c0, double c1, double eps, int matlab) {
+  if (matlab) {
+    const double d0 = x0 - c0, d1 = x1 - c1;
+    double r2 = 0.0;
+    r2 += d0 * d0;
+    r2 += d1 * d1;
+    return r2 > 0.0 ? r2 * kmpc_logT<double>(sqrt(r2)) : 0.0;  // NaN -> 0 (rbf.m:28)
+  }
+  double xx = 0.0, cc = 0.0, xc = 0.0;
+  xx += x0 * x0; cc += c0 * c0; xc += x0 * c0;
+  xx += x1 * x1; cc += c1 * c1; xc += x1 * c1;
+  double d2 = xx - 2.0 * xc + cc;
+  d2 = d2 < 0.0 ? 0.0 : d2;  // (np.maximum(d2, 0) of sklearn's euclidean_distances: a NaN stays a NaN)
+  const double d = sqrt(d2);
+  return d * d * kmpc_logT<double>(d + eps);
+}
 
 }  // namespace kmpc

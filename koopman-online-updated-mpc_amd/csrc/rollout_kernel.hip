@@ -304,23 +304,10 @@ __global__ __launch_bounds__((ro_max_threads<L_, N_, Q_, NW, KS_>())) void rollo
     }
     double psi_i = 0.0;  // lane i < L: psi_i(x_k) of this wave's trajectory
     if constexpr (RBF) {
-      if (live && (lane & PSI_MASK) < L) {
-        double x[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) x[i] = (i < n) ? io_ld<IOT>(a.X_rw, (size_t)i * B + b) : 0.0;
+      if (live && (lane & PSI_MASK) < L) {  // (n = 2: the plants of the roll-outs are two-state systems)
+        const double x0 = io_ld<IOT>(a.X_rw, (size_t)b), x1 = io_ld<IOT>(a.X_rw, (size_t)B + b);
         const double* c = R.cx + (size_t)(lane & PSI_MASK) * n;
-        if (R.rbf_matlab) {
-          double r2 = 0.0;
-          for (int i = 0; i < n; ++i) { const double d = x[i] - c[i]; r2 += d * d; }
-          psi_i = r2 > 0.0 ? r2 * kmpc_log(sqrt(r2)) : 0.0;
-        } else {
-          double xx = 0.0, cc = 0.0, xc = 0.0;
-          for (int i = 0; i < n; ++i) { xx += x[i] * x[i]; cc += c[i] * c[i]; xc += x[i] * c[i]; }
-          double d2 = xx - 2.0 * xc + cc;
-          d2 = d2 < 0.0 ? 0.0 : d2;  // (np.maximum: a NaN stays a NaN)
-          const double d = sqrt(d2);
-          psi_i = d * d * kmpc_log(d + R.eps);
-        }
+        psi_i = kmpc_rbf_psi2(x0, x1, c[0], c[1], R.eps, R.rbf_matlab);  // (plant_device.h: the stand-alone lift's code)
       }
     } else if constexpr (NW == 4) {  // (written for 4 or 8 columns; with 8 the 16x16x4 path below measures better: 89 vs 87 M steps/s)
       // Four or eight trajectories per workgroup (four / two workgroups per CU, which drift apart: a SIMD then holds
