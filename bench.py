@@ -32,6 +32,9 @@ kernel's fraction), `switch_window_*` (K steps from step 95 of a run that starts
 parameter switch of duffing.py:991-992 lies inside), `cold_start_*` (every QP from clip(0) like the reference) and
 `post_reset_*` (the same K steps right after the reset).  With N > 1 ranks the default run appends `roofline.multi_rank.cfg4`: a short leg of the
 shared-model configuration -- the only one with a collective on its step path -- on all ranks, behind the headline, on a watched thread.
+A headline whose wall time is more than 1.5 x a replica of the same region (a disturbed launch: the pool's devices have them now and then)
+is measured once more from the restored state -- the warm-up and EXACTLY the same K steps --, the shorter figure is the line's and
+`config.headline_retimed` carries the first one.
 `cpu_baseline` times the NumPy oracle run the way the reference runs (per-trajectory Python
 loop, SciPy L-BFGS-B on the shooting cost, duffing.py:857-859) on a bounded sample of the same workload IN
 THE SAME REGIME (the settle steps after the reset are set-up, the steps after them are timed): one worker
